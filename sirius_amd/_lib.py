@@ -1,0 +1,76 @@
+"""ctypes loader for libsirius_amd.so (the C-ABI of include/sirius_amd.h).
+
+There is no CPU implementation behind this package: if the HIP library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"`) importing a compute entry raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsirius_amd.so")
+
+OK, ERR_TOO_LONG_INPUT, ERR_NOT_POW2, ERR_K_TOO_LARGE, ERR_INVALID, ERR_DEVICE, ERR_LAYOUT, ERR_EVAL_INDEX = range(8)
+CURVE_BN256, CURVE_GRUMPKIN = 0, 1
+FIELD_FR, FIELD_FQ = 0, 1
+SPACE_HOST, SPACE_DEVICE = 0, 1
+REPR_MONT, REPR_CANON = 0, 1
+
+_lib = None
+
+
+class SiriusAmdError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__(f"sirius_amd rc={rc}: {msg}")
+        self.rc = rc
+
+
+def _prototypes():
+    vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+    return {
+        "srs_init": (i32, [i32]),
+        "srs_last_error": (C.c_char_p, []),
+        "srs_version": (C.c_char_p, []),
+        "srs_scalar_field_of": (i32, [i32]),
+        "srs_layout_selftest": (i32, [i32, vp, vp]),
+        "srs_ck_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
+        "srs_ck_create_sharded": (i32, [i32, vp, sz, i32, u32, u32, C.POINTER(vp)]),
+        "srs_ck_free": (None, [vp]),
+        "srs_ck_len": (sz, [vp]),
+        "srs_commit": (i32, [vp, vp, sz, i32, i32, vp, vp]),
+        "srs_commit_batch": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, i32, i32, vp, vp]),
+        "srs_point_sum": (i32, [i32, vp, sz, vp]),
+        "srs_point_mul": (i32, [i32, vp, i32, vp, vp]),
+    }
+
+
+def load(path=None):
+    """Load the shared library (idempotent).  `path` is a test hook for tests/emu."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: build the HIP extension first (__graft_entry__.build()); "
+            "sirius_amd has no CPU fallback")
+    if path is None:
+        try:  # share torch's HIP runtime when torch is in the process (same libamdhip64 soname)
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(p)
+    for name, (res, args) in _prototypes().items():
+        fn = getattr(lib, name)      # AttributeError here = header/library drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib():
+    return load()
+
+
+def check(rc):
+    if rc != OK:
+        raise SiriusAmdError(rc, (lib().srs_last_error() or b"").decode())

@@ -1,0 +1,105 @@
+"""`CommitmentKey` -- mirror of reference src/commitment.rs:29-90 on top of the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class TooLongInput(ValueError):
+    """commitment::Error::TooLongInput { input_len, limit }  (src/commitment.rs:23-27)."""
+
+    def __init__(self, input_len, limit):
+        super().__init__(f"Can't commit too long input: input len: {input_len}, but limit is {limit}")
+        self.input_len, self.limit = input_len, limit
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _buf(x, last):
+    """-> (address, space, n_rows, keepalive)."""
+    if _is_torch(x):
+        assert x.is_contiguous() and x.shape[-1] == last and x.element_size() == 8, (x.shape, x.dtype)
+        space = L.SPACE_DEVICE if x.is_cuda else L.SPACE_HOST
+        return x.data_ptr(), space, x.numel() // last, x
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    assert a.shape[-1] == last, a.shape
+    return a.ctypes.data, L.SPACE_HOST, a.size // last, a
+
+
+def _stream():
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_stream().cuda_stream
+    except Exception:
+        pass
+    return None
+
+
+class CommitmentKey:
+    """Device-resident Pedersen commitment key (window-expanded in HBM)."""
+
+    def __init__(self, curve, bases, rank=0, world=1):
+        addr, space, n, keep = _buf(bases, 8)
+        self.curve, self._len = curve, n
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        L.check(L.lib().srs_ck_create_sharded(curve, addr, n, space, rank, world, C.byref(h)))
+        self._h = h
+
+    def __len__(self):
+        return self._len
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().srs_ck_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def commit(self, v, repr=L.REPR_MONT):
+        """sum v[i] * ck[i] -> affine (8,) uint64.  Raises TooLongInput like the reference."""
+        addr, space, n, keep = _buf(v, 4)
+        if n > self._len:
+            raise TooLongInput(n, self._len)
+        out = np.zeros(8, dtype=np.uint64)
+        L.check(L.lib().srs_commit(self._h, addr, n, space, repr, _stream(), out.ctypes.data))
+        return out
+
+    def commit_batch(self, vs, repr=L.REPR_MONT):
+        """[commit(v) for v in vs] in one set of launches (cross-term commits, sangria/mod.rs:151-154)."""
+        bufs = [_buf(v, 4) for v in vs]
+        if not bufs:
+            return np.zeros((0, 8), dtype=np.uint64)
+        spaces = {b[1] for b in bufs}
+        assert len(spaces) == 1, "all vectors of a batch must live in the same memory space"
+        for b in bufs:
+            if b[2] > self._len:
+                raise TooLongInput(b[2], self._len)
+        ptrs = (C.c_void_p * len(bufs))(*[b[0] for b in bufs])
+        ns = (C.c_size_t * len(bufs))(*[b[2] for b in bufs])
+        out = np.zeros((len(bufs), 8), dtype=np.uint64)
+        L.check(L.lib().srs_commit_batch(self._h, ptrs, ns, len(bufs), spaces.pop(), repr, _stream(), out.ctypes.data))
+        return out
+
+
+def point_sum(curve, points):
+    a = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros(8, dtype=np.uint64)
+    L.check(L.lib().srs_point_sum(curve, a.ctypes.data, a.shape[0], out.ctypes.data))
+    return out
+
+
+def point_mul(curve, scalar, p, repr=L.REPR_MONT):
+    s = np.ascontiguousarray(scalar, dtype=np.uint64).reshape(4)
+    q = np.ascontiguousarray(p, dtype=np.uint64).reshape(8)
+    out = np.zeros(8, dtype=np.uint64)
+    L.check(L.lib().srs_point_mul(curve, s.ctypes.data, repr, q.ctypes.data, out.ctypes.data))
+    return out

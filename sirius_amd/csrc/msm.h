@@ -1,0 +1,52 @@
+// msm.h -- internal interface of the MSM engine (see msm.hip for the design notes).
+#pragma once
+#include "curve.cuh"
+#include "devrt.h"
+
+namespace srs {
+namespace msm {
+
+constexpr int WBITS = 16;                 // signed-digit window width
+constexpr int NWIN = 16;                  // ceil(256 / WBITS); scalars are < 2^254
+constexpr uint32_t NBUCKET = 1u << (WBITS - 1);   // |digit| in 1..2^15 -> bucket |digit|-1
+constexpr uint32_t STRIPE_LOG = 10;       // multi-GPU block-cyclic stripe (entries)
+
+constexpr uint32_t SORT_THREADS = 1024;   // one workgroup per CU: 128 KiB LDS histogram
+constexpr uint32_t SORT_TILE = 16384;     // digits per workgroup
+constexpr uint32_t PLAN_THREADS = 1024;
+constexpr uint32_t ACC_THREADS = 128;
+constexpr uint32_t ACC_L0 = 16;           // gathered mixed adds per level-0 thread
+constexpr uint32_t ACC_L1 = 8;            // full adds per thread on later levels
+constexpr uint32_t FINAL_THREADS = 256;   // 4 wavefronts = 4 buckets per workgroup
+constexpr uint32_t FINAL_FANIN = 512;     // worst-case parts per bucket left for the wave-level pass
+constexpr int MAX_LEVELS = 8;
+constexpr uint32_t RED_ROWS = 256;        // bucket index = hi * RED_COLS + lo
+constexpr uint32_t RED_COLS = NBUCKET / RED_ROWS;
+constexpr uint32_t NORM_G = 16;           // points per inversion in the key-expansion normalise
+
+static_assert(RED_COLS <= RED_ROWS, "k_rowcol assumes COLS <= ROWS threads");
+static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
+
+// Device-resident commitment key: window-expanded table T[w * len + i] = 2^(16 w) P_i.
+struct Key {
+    int curve = 0;            // 0 bn256 G1, 1 grumpkin
+    size_t len = 0;           // number of bases held by THIS rank
+    size_t global_len = 0;    // length of the whole key (== len when world == 1)
+    uint32_t rank = 0, world = 1;
+    affine_t *table = nullptr;
+    Arena arena;              // per-key scratch (grow-only)
+};
+
+// fills table[len .. 16*len) from table[0 .. len)
+void build_table(Key &k, hipStream_t stream);
+
+size_t workspace_bytes(uint32_t n_max, uint32_t batch);
+
+// batch of MSMs over the base prefix: result_host[m] = sum_{i < n[m]} scalars[m][i] * P_i  (XYZZ).
+// scalars_dev: HOST array of DEVICE pointers; with world > 1 they point at the FULL vectors and
+// only this rank's stripes are read (n[m] is then the LOCAL count).
+void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch, int is_mont,
+         hipStream_t stream, xyzz_t *result_host);
+
+}  // namespace msm
+}  // namespace srs

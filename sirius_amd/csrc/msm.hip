@@ -1,0 +1,558 @@
+// msm.hip -- Pedersen vector commitment  C = sum_i v[i] * ck[i]  on gfx950.
+//
+// Replaces the body of `CommitmentKey::commit` = `best_multiexp(v, &ck[..v.len()]).to_affine()`
+// (reference src/commitment.rs:81-90; call sites src/plonk/mod.rs:441-447,
+// src/nifs/sangria/mod.rs:151-154).  Group arithmetic is exact, so any evaluation order gives the
+// reference's affine point bit for bit.
+//
+// MI355X-first design (not halo2's chunk-per-thread serial Pippenger):
+//   * The commitment key is static across fold steps, and HBM is 288 GB: at key creation every
+//     base is expanded into the 16 window multiples  T[w][i] = 2^(16 w) * P_i  (affine, 16x the
+//     key size).  All 16 windows of a scalar then land in ONE shared set of 2^15 signed-digit
+//     buckets: no per-window bucket sets, no Horner doublings, one bucket reduction per MSM.
+//   * scalars -> 16 signed 16-bit digits (k_digits); zero digits are skipped like halo2 does.
+//   * counting sort of the (bucket, table-index) pairs with a 128 KiB LDS histogram per
+//     workgroup (k_hist / k_scatter): hot buckets (0/1/small witnesses) are
+//     aggregated in LDS and cost one global atomic per tile, not one per entry.
+//   * load-balanced bucket accumulation (k_accum0): one thread per (bucket, part) with at most
+//     L0 gathered mixed adds, so a bucket holding 20 % of all entries is spread over thousands
+//     of threads; partial sums are combined by further levels (k_accum1) and a wavefront-level
+//     strided sum + 64-lane shuffle tree (k_accum_final).
+//   * bucket reduction  sum_b (b+1) B_b  via the 2-D row/column split (k_rowcol) and log-depth
+//     suffix scans in LDS (k_reduce_final); the XYZZ result is normalised on the host.
+// Batched entry: the d-1 cross-term commitments share one base prefix and run
+// as one set of launches (grid.y / grid.z = batch index).
+#include "msm.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace srs {
+namespace msm {
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t upper_bucket(const uint32_t *__restrict__ tp, uint32_t t) {
+    // largest b in [0, NBUCKET) with tp[b] <= t   (tp is non-decreasing, tp[0] = 0, t < tp[NBUCKET])
+    uint32_t lo = 0, hi = NBUCKET;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (tp[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// global index of local scalar i under block-cyclic sharding (stripe = 2^STRIPE_LOG entries):
+// rank r of `world` owns stripes s with s % world == r.
+__device__ __forceinline__ size_t shard_global_index(size_t i, uint32_t rank, uint32_t world) {
+    if (world == 1) return i;
+    size_t s = i >> STRIPE_LOG, o = i & ((1u << STRIPE_LOG) - 1);
+    return ((s * world + rank) << STRIPE_LOG) + o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// key expansion: T[w][i] = 2^(16 w) P_i
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void k_table_step(const affine_t *__restrict__ prev, xyzz_t *__restrict__ tmp, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    affine_t p = prev[i];
+    xyzz_t a;
+    if (Ec<C>::is_identity(p)) {
+        a = Ec<C>::identity();
+    } else {
+        a = Ec<C>::dbl_affine(p);
+        for (int k = 1; k < WBITS; ++k) a = Ec<C>::dbl(a);
+    }
+    tmp[i] = a;
+}
+
+// batch normalisation XYZZ -> affine, NORM_G points per thread share one inversion
+template <class C>
+__global__ void k_normalize(const xyzz_t *__restrict__ in, affine_t *__restrict__ out, uint32_t n) {
+    using F = typename C::F;
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = (size_t)g * NORM_G;
+    if (lo >= n) return;
+    uint32_t cnt = (uint32_t)((n - lo < NORM_G) ? (n - lo) : NORM_G);
+    fe_t pre[NORM_G];
+    fe_t acc = F::one();
+    for (uint32_t j = 0; j < cnt; ++j) {
+        pre[j] = acc;
+        xyzz_t p = in[lo + j];
+        if (!Ec<C>::is_identity(p)) acc = F::mul(acc, F::mul(p.zz, p.zzz));
+    }
+    fe_t inv = F::inv(acc);
+    for (uint32_t j = cnt; j-- > 0;) {
+        xyzz_t p = in[lo + j];
+        affine_t o;
+        if (Ec<C>::is_identity(p)) {
+            o = Ec<C>::affine_identity();
+        } else {
+            fe_t i = F::mul(inv, pre[j]);                 // 1 / (zz * zzz)
+            inv = F::mul(inv, F::mul(p.zz, p.zzz));
+            o.x = F::mul(p.x, F::mul(i, p.zzz));
+            o.y = F::mul(p.y, F::mul(i, p.zz));
+        }
+        out[lo + j] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. scalars -> signed 16-bit digits
+// dig[w * n + i] = 0xFFFF (zero digit) | (|d|-1) | sign << 15
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void k_digits(const fe_t *const *__restrict__ scalars_batch, const uint32_t *__restrict__ n_batch,
+                         uint16_t *__restrict__ dig, size_t dig_stride, int is_mont, uint32_t rank, uint32_t world) {
+    using S = typename C::S;
+    uint32_t m = blockIdx.y;
+    uint32_t n = n_batch[m];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t s = scalars_batch[m][shard_global_index(i, rank, world)];
+    if (is_mont) s = S::from_mont(s);
+    uint16_t *d = dig + (size_t)m * dig_stride;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w) {
+        uint32_t raw = (s.v[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu;
+        uint32_t v = raw + carry;
+        uint32_t code;
+        if (v > 0x8000u) {
+            code = ((0x10000u - v) - 1u) | 0x8000u;   // negative digit, magnitude 1..0x7FFF
+            carry = 1;
+        } else {
+            code = v ? (v - 1u) : 0xFFFFu;            // positive digit 1..0x8000, or zero
+            carry = 0;
+        }
+        d[(size_t)w * n + i] = (uint16_t)code;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. counting sort by bucket, LDS histogram per workgroup
+// grid = (tiles, NWIN, batch), block = SORT_THREADS
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_histogram(uint32_t *h, const uint16_t *__restrict__ d, uint32_t lo, uint32_t hi) {
+    for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t code = d[i];
+        if (code != 0xFFFFu) atomicAdd(&h[code & 0x7FFFu], 1u);
+    }
+    __syncthreads();
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_hist(const uint16_t *__restrict__ dig, size_t dig_stride, const uint32_t *__restrict__ n_batch,
+           uint32_t *__restrict__ count /* [batch][NBUCKET] */) {
+    __shared__ uint32_t h[NBUCKET];
+    uint32_t m = blockIdx.z, w = blockIdx.y;
+    uint32_t n = n_batch[m];
+    uint32_t lo = blockIdx.x * SORT_TILE;
+    if (lo >= n) return;
+    uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    const uint16_t *d = dig + (size_t)m * dig_stride + (size_t)w * n;
+    tile_histogram(h, d, lo, hi);
+    uint32_t *cnt = count + (size_t)m * NBUCKET;
+    for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) {
+        uint32_t c = h[b];
+        if (c) atomicAdd(&cnt[b], c);
+    }
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_scatter(const uint16_t *__restrict__ dig, size_t dig_stride, const uint32_t *__restrict__ n_batch,
+              uint32_t *__restrict__ cursor /* [batch][NBUCKET] */, uint32_t *__restrict__ sorted,
+              size_t sorted_stride, uint32_t table_stride) {
+    __shared__ uint32_t h[NBUCKET];
+    uint32_t m = blockIdx.z, w = blockIdx.y;
+    uint32_t n = n_batch[m];
+    uint32_t lo = blockIdx.x * SORT_TILE;
+    if (lo >= n) return;
+    uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    const uint16_t *d = dig + (size_t)m * dig_stride + (size_t)w * n;
+    tile_histogram(h, d, lo, hi);
+    uint32_t *cur = cursor + (size_t)m * NBUCKET;
+    for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) {
+        uint32_t c = h[b];
+        if (c) h[b] = atomicAdd(&cur[b], c);   // reserve [base, base+c) in the bucket's segment
+    }
+    __syncthreads();
+    uint32_t *out = sorted + (size_t)m * sorted_stride;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t code = d[i];
+        if (code != 0xFFFFu) {
+            uint32_t pos = atomicAdd(&h[code & 0x7FFFu], 1u);
+            out[pos] = (w * table_stride + i) | ((code & 0x8000u) << 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. plan: bucket offsets + (bucket, part) -> thread maps for every accumulation level
+// grid = batch, block = PLAN_THREADS.   plan layout per MSM: (1 + nlevels) arrays of NBUCKET+1:
+//   [0] off   : entry offsets of the sorted list            (off[NBUCKET] = #non-zero digits)
+//   [1] tp0   : thread prefix of level 0, parts = max(1, ceil(count / L0))
+//   [l] tp(l-1): thread prefix of level l-1 over the previous level's parts
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t *total) {
+    // Hillis-Steele over blockDim.x values; returns exclusive prefix of v, *total = sum
+    uint32_t t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (uint32_t s = 1; s < blockDim.x; s <<= 1) {
+        uint32_t add = (t >= s) ? lds[t - s] : 0;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    uint32_t incl = lds[t];
+    *total = lds[blockDim.x - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
+    k_plan(const uint32_t *__restrict__ count, uint32_t *__restrict__ cursor, uint32_t *__restrict__ plan,
+           size_t plan_stride, int nlevels, uint32_t l0, uint32_t l1) {
+    __shared__ uint32_t lds[PLAN_THREADS];
+    constexpr uint32_t PER = NBUCKET / PLAN_THREADS;
+    uint32_t m = blockIdx.x;
+    const uint32_t *cnt = count + (size_t)m * NBUCKET;
+    uint32_t *cur = cursor + (size_t)m * NBUCKET;
+    uint32_t *pl = plan + (size_t)m * plan_stride;
+    uint32_t vals[PER];
+    uint32_t base = threadIdx.x * PER;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) vals[j] = cnt[base + j];
+    for (int level = -1; level < nlevels; ++level) {
+        // level -1: scan the raw counts (entry offsets); level >= 0: scan the part counts
+        if (level >= 0) {
+            uint32_t L = level == 0 ? l0 : l1;
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) {
+                uint32_t p = (vals[j] + L - 1) / L;
+                vals[j] = p ? p : 1u;
+            }
+        }
+        uint32_t local = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) local += vals[j];
+        uint32_t total;
+        uint32_t run = block_exclusive_scan(local, lds, &total);
+        uint32_t *o = pl + (size_t)(level + 1) * (NBUCKET + 1);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            o[base + j] = run;
+            if (level < 0) cur[base + j] = run;
+            run += vals[j];
+        }
+        if (threadIdx.x == blockDim.x - 1) o[NBUCKET] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. bucket accumulation
+// level 0: thread t = (bucket, part): <= L0 gathered mixed adds  ->  parts0[t]  (XYZZ)
+// grid = (blocks, batch)
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
+    k_accum0(const uint32_t *__restrict__ sorted, size_t sorted_stride, const uint32_t *__restrict__ plan,
+             size_t plan_stride, const affine_t *__restrict__ table, xyzz_t *__restrict__ parts,
+             size_t parts_stride, uint32_t l0) {
+    using F = typename C::F;
+    uint32_t m = blockIdx.y;
+    const uint32_t *off = plan + (size_t)m * plan_stride;
+    const uint32_t *tp = off + (NBUCKET + 1);
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tp[NBUCKET]) return;
+    uint32_t b = upper_bucket(tp, t);
+    uint32_t part = t - tp[b];
+    uint32_t s = off[b] + part * l0;
+    uint32_t e = off[b + 1];
+    if (e > s + l0) e = s + l0;
+    const uint32_t *src = sorted + (size_t)m * sorted_stride;
+    xyzz_t acc = Ec<C>::identity();
+    if (s < e) {
+        uint32_t v = src[s];
+        affine_t p = table[v & 0x7FFFFFFFu];
+        for (uint32_t j = s; j < e; ++j) {
+            uint32_t vn = 0;
+            affine_t pn = p;
+            if (j + 1 < e) {              // prefetch the next gathered point behind the add
+                vn = src[j + 1];
+                pn = table[vn & 0x7FFFFFFFu];
+            }
+            if (v >> 31) p.y = F::neg(p.y);
+            acc = Ec<C>::madd(acc, p);
+            v = vn;
+            p = pn;
+        }
+    }
+    parts[(size_t)m * parts_stride + t] = acc;
+}
+
+// level >= 1: thread t = (bucket, part) over the previous level's parts, <= L1 full adds
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
+    k_accum1(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
+             size_t plan_stride, int level, xyzz_t *__restrict__ out, size_t out_stride, uint32_t l1) {
+    uint32_t m = blockIdx.y;
+    const uint32_t *tp_prev = plan + (size_t)m * plan_stride + (size_t)level * (NBUCKET + 1);
+    const uint32_t *tp = tp_prev + (NBUCKET + 1);
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tp[NBUCKET]) return;
+    uint32_t b = upper_bucket(tp, t);
+    uint32_t part = t - tp[b];
+    uint32_t s = tp_prev[b] + part * l1;
+    uint32_t e = tp_prev[b + 1];
+    if (e > s + l1) e = s + l1;
+    const xyzz_t *src = in + (size_t)m * in_stride;
+    xyzz_t acc = src[s];
+    for (uint32_t j = s + 1; j < e; ++j) acc = Ec<C>::add(acc, src[j]);
+    out[(size_t)m * out_stride + t] = acc;
+}
+
+// 64-lane exchange of an XYZZ point
+__device__ __forceinline__ xyzz_t shfl_down_point(const xyzz_t &p, unsigned delta) {
+    xyzz_t o;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) d[i] = __shfl_down(s[i], delta, 64);
+    return o;
+}
+
+// final level: one wavefront per bucket; lanes stride over the remaining parts, then a 6-step
+// shuffle tree; lane 0 stores the bucket.   grid = (NBUCKET / waves_per_block, batch)
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
+    k_accum_final(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
+                  size_t plan_stride, int level, xyzz_t *__restrict__ buckets) {
+    uint32_t m = blockIdx.y;
+    const uint32_t *tp = plan + (size_t)m * plan_stride + (size_t)level * (NBUCKET + 1);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t s = tp[b], e = tp[b + 1];
+    const xyzz_t *src = in + (size_t)m * in_stride;
+    xyzz_t *dst = buckets + (size_t)m * NBUCKET;
+    if (e - s == 1) {                       // common case: the bucket is already one part
+        if (lane == 0) dst[b] = src[s];
+        return;
+    }
+    xyzz_t acc = Ec<C>::identity();
+    for (uint32_t j = s + lane; j < e; j += 64) acc = Ec<C>::add(acc, src[j]);
+    for (unsigned d = 32; d >= 1; d >>= 1) {
+        xyzz_t other = shfl_down_point(acc, d);
+        if (lane < d) acc = Ec<C>::add(acc, other);
+    }
+    if (lane == 0) dst[b] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5. bucket reduction  S = sum_b (b+1) B_b,  b = hi * RED_COLS + lo
+//    S = RED_COLS * sum_hi hi * R_hi  +  sum_lo (lo+1) * C_lo
+// k_rowcol: block < RED_ROWS -> row sum R_hi ; else column sum C_lo.   grid = (ROWS + COLS, batch)
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void lds_tree_sum(xyzz_t *v, uint32_t n_pow2) {
+    for (uint32_t s = n_pow2 >> 1; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) v[threadIdx.x] = Ec<C>::add(v[threadIdx.x], v[threadIdx.x + s]);
+        __syncthreads();
+    }
+}
+
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(RED_ROWS, 1)
+    k_rowcol(const xyzz_t *__restrict__ buckets, xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */) {
+    __shared__ xyzz_t v[RED_ROWS];
+    uint32_t m = blockIdx.y;
+    const xyzz_t *B = buckets + (size_t)m * NBUCKET;
+    uint32_t t = threadIdx.x;
+    if (blockIdx.x < RED_ROWS) {
+        uint32_t hi = blockIdx.x;
+        v[t] = (t < RED_COLS) ? B[hi * RED_COLS + t] : Ec<C>::identity();
+    } else {
+        uint32_t lo = blockIdx.x - RED_ROWS;
+        v[t] = B[t * RED_COLS + lo];       // t < RED_ROWS == blockDim.x
+    }
+    __syncthreads();
+    lds_tree_sum<C>(v, RED_ROWS);
+    if (t == 0) rc[(size_t)m * (RED_ROWS + RED_COLS) + blockIdx.x] = v[0];
+}
+
+// sum_j j * X_j  (j = 0..n-1)  = sum_{j>=1} Suffix_j ; inclusive suffix scan then tree sum, in LDS.
+// `plus_one`: weights j+1 instead of j (sum of all suffixes incl. Suffix_0).  n == blockDim.x.
+template <class C>
+__device__ __forceinline__ xyzz_t lds_weighted_sum(xyzz_t *v, xyzz_t x, bool plus_one) {
+    uint32_t t = threadIdx.x, n = blockDim.x;
+    v[t] = x;
+    __syncthreads();
+    for (uint32_t s = 1; s < n; s <<= 1) {           // suffix scan: v[t] = sum_{i >= t} x_i
+        xyzz_t o = (t + s < n) ? v[t + s] : Ec<C>::identity();
+        __syncthreads();
+        v[t] = Ec<C>::add(v[t], o);
+        __syncthreads();
+    }
+    if (!plus_one && t == 0) v[0] = Ec<C>::identity();
+    __syncthreads();
+    lds_tree_sum<C>(v, n);
+    xyzz_t r = v[0];
+    __syncthreads();
+    return r;
+}
+
+// grid = batch, block = RED_ROWS
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(RED_ROWS, 1)
+    k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
+    __shared__ xyzz_t v[RED_ROWS];
+    uint32_t m = blockIdx.x, t = threadIdx.x;
+    const xyzz_t *R = rc + (size_t)m * (RED_ROWS + RED_COLS);
+    const xyzz_t *Cc = R + RED_ROWS;
+    xyzz_t sr = lds_weighted_sum<C>(v, R[t], false);                                   // sum hi * R_hi
+    xyzz_t sc = lds_weighted_sum<C>(v, t < RED_COLS ? Cc[t] : Ec<C>::identity(), true);   // sum (lo+1) C_lo
+    if (t == 0) {
+        for (uint32_t k = 1; k < RED_COLS; k <<= 1) sr = Ec<C>::dbl(sr);               // * RED_COLS
+        out[m] = Ec<C>::add(sr, sc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+template <class C>
+static void build_table_t(Key &k, hipStream_t stream) {
+    const uint32_t n = (uint32_t)k.len;
+    if (n == 0) return;
+    xyzz_t *tmp = nullptr;
+    SRS_HIP_CHECK(hipMalloc((void **)&tmp, (size_t)n * sizeof(xyzz_t)));
+    for (int w = 1; w < NWIN; ++w) {
+        const affine_t *prev = k.table + (size_t)(w - 1) * n;
+        affine_t *cur = k.table + (size_t)w * n;
+        SRS_LAUNCH((k_table_step<C>), (ceil_div(n, 256)), (256), 0, stream, prev, tmp, n);
+        SRS_LAUNCH((k_normalize<C>), (ceil_div(ceil_div(n, NORM_G), 128)), (128), 0, stream, (const xyzz_t *)tmp, cur, n);
+    }
+    SRS_HIP_CHECK(hipStreamSynchronize(stream));
+    SRS_HIP_CHECK(hipFree(tmp));
+}
+
+void build_table(Key &k, hipStream_t stream) {
+    if (k.curve == 0) build_table_t<Bn256>(k, stream); else build_table_t<Grumpkin>(k, stream);
+}
+
+// number of thread-sequential levels after level 0 so that the wavefront-level final pass sees
+// at most ~FINAL_FANIN parts per bucket even if every entry fell into one bucket
+static int levels_for(uint64_t max_entries) {
+    uint64_t parts = (max_entries + ACC_L0 - 1) / ACC_L0;
+    int levels = 1;
+    while (parts > FINAL_FANIN && levels < MAX_LEVELS) {
+        parts = (parts + ACC_L1 - 1) / ACC_L1;
+        ++levels;
+    }
+    return levels;
+}
+
+size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
+    uint64_t M = (uint64_t)n_max * NWIN;
+    int levels = levels_for(M);
+    size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1);
+    uint64_t parts0 = M / ACC_L0 + NBUCKET + 1;
+    uint64_t parts1 = parts0 / ACC_L1 + NBUCKET + 1;
+    size_t per = 0;
+    per += Arena::pad(M * sizeof(uint16_t));                 // digits
+    per += Arena::pad(M * sizeof(uint32_t));                 // sorted
+    per += 2 * Arena::pad(NBUCKET * sizeof(uint32_t));       // count, cursor
+    per += Arena::pad(plan_stride * sizeof(uint32_t));
+    per += Arena::pad(parts0 * sizeof(xyzz_t));              // ping
+    per += Arena::pad(parts1 * sizeof(xyzz_t));              // pong
+    per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
+    per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
+    return per * batch + Arena::pad(batch * sizeof(void *)) + Arena::pad(batch * sizeof(uint32_t)) +
+           Arena::pad(batch * sizeof(xyzz_t)) + 4096;
+}
+
+template <class C>
+static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch,
+                  int is_mont, hipStream_t stream, xyzz_t *result_host) {
+    uint32_t n_max = 0;
+    for (uint32_t m = 0; m < batch; ++m) n_max = std::max(n_max, n_host[m]);
+    if (n_max == 0) {
+        for (uint32_t m = 0; m < batch; ++m) result_host[m] = Ec<C>::identity();
+        return;
+    }
+    const uint64_t M = (uint64_t)n_max * NWIN;
+    const int levels = levels_for(M);
+    const size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1);
+    const uint64_t parts0_cap = M / ACC_L0 + NBUCKET + 1;
+    const uint64_t parts1_cap = parts0_cap / ACC_L1 + NBUCKET + 1;
+
+    Arena &A = k.arena;
+    A.reserve(workspace_bytes(n_max, batch));
+    A.reset();
+    const fe_t **d_ptrs = A.take<const fe_t *>(batch);
+    uint32_t *d_n = A.take<uint32_t>(batch);
+    xyzz_t *d_out = A.take<xyzz_t>(batch);
+    uint16_t *dig = A.take<uint16_t>(M * batch);
+    uint32_t *sorted = A.take<uint32_t>(M * batch);
+    uint32_t *count = A.take<uint32_t>((size_t)NBUCKET * batch);
+    uint32_t *cursor = A.take<uint32_t>((size_t)NBUCKET * batch);
+    uint32_t *plan = A.take<uint32_t>(plan_stride * batch);
+    xyzz_t *ping = A.take<xyzz_t>(parts0_cap * batch);
+    xyzz_t *pong = A.take<xyzz_t>(parts1_cap * batch);
+    xyzz_t *buckets = A.take<xyzz_t>((size_t)NBUCKET * batch);
+    xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
+
+    SRS_HIP_CHECK(hipMemcpyAsync(d_ptrs, scalars_dev, batch * sizeof(void *), hipMemcpyHostToDevice, stream));
+    SRS_HIP_CHECK(hipMemcpyAsync(d_n, n_host, batch * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    SRS_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)NBUCKET * batch * sizeof(uint32_t), stream));
+
+    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, (const fe_t *const *)d_ptrs,
+               (const uint32_t *)d_n, dig, (size_t)M, is_mont, k.rank, k.world);
+    const uint32_t tiles = ceil_div(n_max, SORT_TILE);
+    SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
+               (const uint32_t *)d_n, count);
+    SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
+               levels, (uint32_t)ACC_L0, (uint32_t)ACC_L1);
+    SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
+               (const uint32_t *)d_n, cursor, sorted, (size_t)M, (uint32_t)k.len);
+
+    SRS_LAUNCH((k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+               (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride,
+               (const affine_t *)k.table, ping, (size_t)parts0_cap, (uint32_t)ACC_L0);
+    xyzz_t *cur = ping, *nxt = pong;
+    size_t cur_stride = parts0_cap, nxt_stride = parts1_cap;
+    uint64_t cap = parts0_cap;
+    for (int level = 1; level < levels; ++level) {
+        cap = cap / ACC_L1 + NBUCKET + 1;
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+                   (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, level, nxt, nxt_stride,
+                   (uint32_t)ACC_L1);
+        std::swap(cur, nxt);
+        std::swap(cur_stride, nxt_stride);
+        // both buffers can hold any later level: parts shrink monotonically and pong >= level-1 cap
+    }
+    SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
+               (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, levels, buckets);
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS + RED_COLS, batch), (RED_ROWS), 0, stream, (const xyzz_t *)buckets, rc);
+    SRS_LAUNCH((k_reduce_final<C>), (batch), (RED_ROWS), 0, stream, (const xyzz_t *)rc, d_out);
+    SRS_HIP_CHECK(hipMemcpyAsync(result_host, d_out, batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
+    SRS_HIP_CHECK(hipStreamSynchronize(stream));
+    SRS_HIP_CHECK(hipGetLastError());
+}
+
+void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch, int is_mont,
+         hipStream_t stream, xyzz_t *result_host) {
+    if (k.curve == 0) run_t<Bn256>(k, scalars_dev, n_host, batch, is_mont, stream, result_host);
+    else run_t<Grumpkin>(k, scalars_dev, n_host, batch, is_mont, stream, result_host);
+}
+
+}  // namespace msm
+}  // namespace srs

@@ -1,0 +1,285 @@
+// hipemu.h -- a tiny CPU emulator of the HIP execution model.  TEST INFRASTRUCTURE ONLY.
+//
+// There is no GPU in the development container and GPU minutes are rationed, so the kernel
+// *logic* (indexing, LDS protocols, barriers, wave shuffles, atomics) of sirius_amd/csrc/*.hip is
+// additionally compiled with g++ against this header (-DSRS_EMU) and executed on the host by
+// tests/emu/.  It is never built into, linked with or loaded by the product library:
+// libsirius_amd.so is compiled by hipcc for gfx950 only and has no CPU path.
+//
+// Model: blocks run one after another inside one OS thread; the threads of a block are ucontext
+// fibers, so __syncthreads and wave shuffles have true barrier semantics (a fiber that reaches a
+// barrier yields until every live thread of the block / lane of the wave has arrived);
+// `__shared__` is a plain `static` (one block alive at a time).  Wave = 64 lanes.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __restrict__
+#define __launch_bounds__(...)
+#define __constant__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_ {
+    unsigned x, y, z;
+};
+inline uint3_ threadIdx, blockIdx;
+inline dim3 blockDim, gridDim;
+static constexpr int warpSize = 64;
+
+namespace hipemu {
+enum Wait { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct Fiber {
+    ucontext_t ctx;
+    std::unique_ptr<char[]> stack;
+    int state = RUNNABLE;
+    uint3_ tid;
+};
+struct BlockCtx {
+    std::vector<Fiber> fibers;
+    std::vector<uint64_t> wave_slots;   // 64 x 8-byte exchange slots per wave
+    unsigned nthreads = 0;
+    unsigned cur = 0;                   // running fiber
+    ucontext_t sched;
+    void (*entry)(void *) = nullptr;
+    void *entry_arg = nullptr;
+};
+inline BlockCtx g_ctx;
+inline unsigned t_lin = 0;   // linear thread id of the running fiber
+inline constexpr size_t kStack = 512 * 1024;
+
+inline void yield_as(int wait) {
+    Fiber &f = g_ctx.fibers[g_ctx.cur];
+    f.state = wait;
+    swapcontext(&f.ctx, &g_ctx.sched);
+}
+inline void trampoline() {
+    g_ctx.entry(g_ctx.entry_arg);
+    g_ctx.fibers[g_ctx.cur].state = DONE;
+    swapcontext(&g_ctx.fibers[g_ctx.cur].ctx, &g_ctx.sched);
+}
+// run one block to completion
+inline void run_block() {
+    unsigned n = g_ctx.nthreads;
+    for (unsigned t = 0; t < n; ++t) {
+        Fiber &f = g_ctx.fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.get();
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        f.state = RUNNABLE;
+    }
+    for (;;) {
+        unsigned done = 0, progressed = 0;
+        for (unsigned t = 0; t < n; ++t) {
+            Fiber &f = g_ctx.fibers[t];
+            if (f.state == DONE) { ++done; continue; }
+            if (f.state != RUNNABLE) continue;
+            g_ctx.cur = t;
+            t_lin = t;
+            threadIdx = f.tid;
+            swapcontext(&g_ctx.sched, &f.ctx);
+            ++progressed;
+        }
+        if (done == n) break;
+        // release barriers whose participants have all arrived
+        unsigned live = 0, at_block = 0;
+        for (unsigned t = 0; t < n; ++t) {
+            int s = g_ctx.fibers[t].state;
+            if (s != DONE) ++live;
+            if (s == WAIT_BLOCK) ++at_block;
+        }
+        bool released = false;
+        if (live && at_block == live) {
+            for (unsigned t = 0; t < n; ++t)
+                if (g_ctx.fibers[t].state == WAIT_BLOCK) g_ctx.fibers[t].state = RUNNABLE;
+            released = true;
+        }
+        for (unsigned w = 0; w * 64 < n; ++w) {
+            unsigned lo = w * 64, hi = std::min(n, lo + 64), wl = 0, ww = 0;
+            for (unsigned t = lo; t < hi; ++t) {
+                int s = g_ctx.fibers[t].state;
+                if (s != DONE) ++wl;
+                if (s == WAIT_WAVE) ++ww;
+            }
+            if (wl && ww == wl) {
+                for (unsigned t = lo; t < hi; ++t)
+                    if (g_ctx.fibers[t].state == WAIT_WAVE) g_ctx.fibers[t].state = RUNNABLE;
+                released = true;
+            }
+        }
+        if (!released && !progressed) {
+            std::fprintf(stderr, "hipemu: barrier deadlock (divergent __syncthreads / shuffle)\n");
+            std::abort();
+        }
+    }
+}
+}  // namespace hipemu
+
+inline void __syncthreads() { hipemu::yield_as(hipemu::WAIT_BLOCK); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+template <class T>
+inline T __emu_wave_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "shuffle payload <= 8 bytes");
+    using namespace hipemu;
+    unsigned wave = t_lin / 64, lane = t_lin % 64;
+    uint64_t raw = 0;
+    std::memcpy(&raw, &v, sizeof(T));
+    g_ctx.wave_slots[wave * 64 + lane] = raw;
+    yield_as(WAIT_WAVE);
+    unsigned wave_n = std::min(64u, g_ctx.nthreads - wave * 64);
+    uint64_t got = (src_lane >= 0 && (unsigned)src_lane < wave_n) ? g_ctx.wave_slots[wave * 64 + src_lane] : raw;
+    yield_as(WAIT_WAVE);
+    T o;
+    std::memcpy(&o, &got, sizeof(T));
+    return o;
+}
+template <class T>
+inline T __shfl(T v, int lane, int width = 64) {
+    int self = hipemu::t_lin % 64;
+    return __emu_wave_exchange(v, (self / width) * width + (lane % width));
+}
+template <class T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    (void)width;
+    int self = hipemu::t_lin % 64;
+    return __emu_wave_exchange(v, self ^ mask);
+}
+template <class T>
+inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int self = hipemu::t_lin % 64;
+    int src = self + (int)d;
+    if (src / width != self / width) src = self;
+    return __emu_wave_exchange(v, src);
+}
+template <class T>
+inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int self = hipemu::t_lin % 64;
+    int src = self - (int)d;
+    if (src < 0 || src / width != self / width) src = self;
+    return __emu_wave_exchange(v, src);
+}
+inline unsigned long long __ballot(int pred) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        int p = __emu_wave_exchange(pred ? 1 : 0, l);
+        unsigned wave = hipemu::t_lin / 64;
+        unsigned wave_n = std::min(64u, hipemu::g_ctx.nthreads - wave * 64);
+        if ((unsigned)l < wave_n && p) m |= 1ull << l;
+    }
+    return m;
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+}
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+
+template <class T>
+inline T atomicAdd(T *p, T v) { return ({ T o_ = *p; *p = o_ + v; o_; }); }
+template <class T>
+inline T atomicSub(T *p, T v) { return ({ T o_ = *p; *p = o_ - v; o_; }); }
+template <class T>
+inline T atomicMax(T *p, T v) {
+    T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
+template <class T>
+inline T atomicExch(T *p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+template <class T>
+inline T atomicCAS(T *p, T cmp, T v) {
+    __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return cmp;
+}
+
+// ---------------------------------------------------------------- runtime API subset
+typedef int hipError_t;
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline const char *hipGetErrorString(hipError_t) { return "hipemu error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) {
+    *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <class T>
+inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
+inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+
+namespace hipemu {
+// Run kernel(args...) over grid x block: blocks sequentially, threads of a block as fibers.
+template <class K, class... A>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t dyn_smem, A... args) {
+    (void)dyn_smem;
+    unsigned nthreads = block.x * block.y * block.z;
+    blockDim = block;
+    gridDim = grid;
+    g_ctx.nthreads = nthreads;
+    if (g_ctx.fibers.size() < nthreads) {
+        size_t old = g_ctx.fibers.size();
+        g_ctx.fibers.resize(nthreads);
+        for (size_t t = old; t < nthreads; ++t) g_ctx.fibers[t].stack.reset(new char[kStack]);
+    }
+    for (unsigned t = 0; t < nthreads; ++t) {
+        g_ctx.fibers[t].tid.x = t % block.x;
+        g_ctx.fibers[t].tid.y = (t / block.x) % block.y;
+        g_ctx.fibers[t].tid.z = t / (block.x * block.y);
+    }
+    g_ctx.wave_slots.assign((size_t)((nthreads + 63) / 64) * 64, 0);
+    auto body = [&]() { kernel(args...); };
+    using B = decltype(body);
+    g_ctx.entry = [](void *p) { (*static_cast<B *>(p))(); };
+    g_ctx.entry_arg = &body;
+    size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    for (size_t b = 0; b < nblocks; ++b) {
+        blockIdx.x = (unsigned)(b % grid.x);
+        blockIdx.y = (unsigned)((b / grid.x) % grid.y);
+        blockIdx.z = (unsigned)(b / ((size_t)grid.x * grid.y));
+        run_block();
+    }
+}
+}  // namespace hipemu

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sirius_amd.h declares.
+No compute entry is called here (there is no GPU in this container and no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "sirius_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(srs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sirius_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 10
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_lib._prototypes()) == names, "python prototypes drifted from the header"
+
+
+def test_host_only_entries():
+    """Entry points that are pure host code may be exercised without a device."""
+    import sirius_amd as S
+    from sirius_amd import _lib
+    lib = _lib.load()
+    assert lib.srs_version().startswith(b"sirius_amd")
+    assert lib.srs_scalar_field_of(0) == 0 and lib.srs_scalar_field_of(1) == 1
+    import oracle as O
+    for f in (0, 1):
+        one, two = O.ints_to_mont(f, [1])[0], O.ints_to_mont(f, [2])[0]
+        assert lib.srs_layout_selftest(f, one.ctypes.data, two.ctypes.data) == 0
+        assert lib.srs_layout_selftest(f, two.ctypes.data, one.ctypes.data) == _lib.ERR_LAYOUT
+    # host-side group helpers agree with the oracle
+    for cid in (0, 1):
+        b = O.make_bases(cid, 5, 6)
+        assert np.array_equal(S.point_sum(cid, b[:2]), O.point_add(cid, b[0], b[1]))
+        s = O.ints_to_mont(O.SCALAR_FIELD[cid], [0xDEADBEEF12345])[0]
+        assert np.array_equal(S.point_mul(cid, s, b[3]), O.point_mul(cid, s, b[3]))
+        assert np.array_equal(S.point_sum(cid, np.zeros((0, 8), np.uint64)), np.zeros(8, np.uint64))
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU a compute entry must return SRS_ERR_DEVICE, never a CPU result."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    import sirius_amd as S
+    import oracle as O
+    import pytest
+    with pytest.raises(S.SiriusAmdError) as e:
+        S.CommitmentKey(0, O.make_bases(0, 1, 4))
+    assert e.value.rc == 5

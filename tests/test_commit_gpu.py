@@ -1,0 +1,103 @@
+"""GPU parity: CommitmentKey::commit (src/commitment.rs:81-90) through the C-ABI vs the oracle.
+Bit-exact (integer / group arithmetic)."""
+import numpy as np
+import pytest
+
+from conftest import golden, h2i, seeded_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+def _pts(O, cid, pts):
+    bf = O.BASE_FIELD[cid]
+    return O.ints_to_mont(bf, [h2i(c) for p in pts for c in p]).reshape(-1, 8)
+
+
+@pytest.mark.parametrize("name,cid", [("bn256", 0), ("grumpkin", 1)])
+def test_commit_golden(srs, oracle, name, cid):
+    O = oracle
+    g = golden("curve_msm.json")[name]
+    bases = _pts(O, cid, g["bases"])
+    ck = srs.CommitmentKey(cid, bases)
+    sf = O.SCALAR_FIELD[cid]
+    for rec in g["msm"]:
+        n = rec["n"]
+        sc = O.ints_to_mont(sf, [h2i(s) for s in rec["scalars"]]) if n else np.zeros((0, 4), np.uint64)
+        assert np.array_equal(ck.commit(sc), _pts(O, cid, [rec["out"]])[0]), (n, rec["kind"])
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+@pytest.mark.parametrize("n,kind", [(1, "uniform"), (63, "uniform"), (1000, "uniform"), (1000, "trace"),
+                                    (4097, "uniform"), (1 << 14, "trace"), (1 << 15, "uniform")])
+def test_commit_vs_oracle(srs, oracle, cid, n, kind):
+    O = oracle
+    bases = O.make_bases(cid, 1234 + cid, 1 << 15)
+    ck = srs.CommitmentKey(cid, bases)
+    sc = seeded_scalars(O, cid, n, 77 + n, kind)
+    assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases[:n]))
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_commit_edge_scalars(srs, oracle, cid):
+    """0, 1, q-1, 2^128-1, all-equal scalars, identity bases (SURVEY.md 8c golden list)."""
+    from oracle import pyref as P
+    O = oracle
+    q = P.CURVES[cid].q
+    sf = O.SCALAR_FIELD[cid]
+    n = 2048
+    bases = O.make_bases(cid, 5, n)
+    bases[7] = 0                       # identity point in the key
+    ck = srs.CommitmentKey(cid, bases)
+    for vals in ([0] * n, [1] * n, [q - 1] * n, [(1 << 128) - 1] * n, [0x8000] * n, [0x8001] * n,
+                 [(i % 3) * (q - 1) // 2 for i in range(n)]):
+        sc = O.ints_to_mont(sf, vals)
+        assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases))
+    # canonical-representation entry
+    vals = [(i * 0x9E3779B97F4A7C15) % q for i in range(n)]
+    got = ck.commit(O.ints_to_limbs(vals), repr=1)
+    assert np.array_equal(got, O.msm(cid, O.ints_to_mont(sf, vals), bases))
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_commit_batch_and_errors(srs, oracle, cid):
+    O = oracle
+    bases = O.make_bases(cid, 9, 3000)
+    ck = srs.CommitmentKey(cid, bases)
+    vs = [seeded_scalars(O, cid, n, 10 + i, "trace" if i % 2 else "uniform") for i, n in enumerate((3000, 17, 1024, 2999, 1, 512))]
+    got = ck.commit_batch(vs)
+    for g, v in zip(got, vs):
+        assert np.array_equal(g, O.msm(cid, v, bases[: len(v)]))
+    assert np.array_equal(ck.commit(np.zeros((0, 4), np.uint64)), np.zeros(8, np.uint64))   # n == 0 -> identity
+    with pytest.raises(srs.TooLongInput):                                                    # src/commitment.rs:82-88
+        ck.commit(np.zeros((3001, 4), np.uint64))
+
+
+def test_commit_device_resident_and_homomorphism(srs, oracle):
+    """Witness-sized MSM on device-resident scalars; size-independent check
+    commit(W1 + r W2) = commit(W1) + [r] commit(W2)  (src/nifs/sangria/mod.rs:455-474)."""
+    import torch
+    O = oracle
+    cid = 0
+    n = 12 << 14
+    bases = O.make_bases(cid, 2024, n)
+    ck = srs.CommitmentKey(cid, bases)
+    w1, w2 = seeded_scalars(O, cid, n, 1, "trace"), seeded_scalars(O, cid, n, 2)
+    r = seeded_scalars(O, cid, 1, 3)[0]
+    folded = O.fold_w(O.FR, w1, w2, r)
+    d = lambda a: torch.from_numpy(a.view(np.int64)).cuda()
+    c1, c2, cf = ck.commit(d(w1)), ck.commit(d(w2)), ck.commit(d(folded))
+    assert np.array_equal(cf, srs.point_sum(cid, np.stack([c1, srs.point_mul(cid, r, c2)])))
+    assert np.array_equal(c2, O.msm(cid, w2, bases))
+
+
+def test_commit_sharded_partials(srs, oracle):
+    """Multi-GPU path on one device: each rank's partial over its block-cyclic stripes, summed."""
+    O = oracle
+    cid, n, world = 1, 5000, 4
+    bases = O.make_bases(cid, 11, n)
+    sc = seeded_scalars(O, cid, 4321, 5)
+    parts = []
+    for r in range(world):
+        ck = srs.CommitmentKey(cid, bases, rank=r, world=world)
+        parts.append(ck.commit(sc))
+    assert np.array_equal(srs.point_sum(cid, np.stack(parts)), O.msm(cid, sc, bases[:4321]))
