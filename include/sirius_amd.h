@@ -72,6 +72,13 @@ int srs_layout_selftest(int field, const srs_fe *one, const srs_fe *two);
 int srs_ck_create(int curve, const srs_affine *bases, size_t len, int space, srs_ck **out);
 int srs_ck_create_sharded(int curve, const srs_affine *bases, size_t len, int space,
                           uint32_t rank, uint32_t world, srs_ck **out);
+/* Synthetic key for tests and benches, generated on the device: P_i = [h(seed, i)] G.  This is NOT
+ * CommitmentKey::setup (src/commitment.rs:55-79: SHAKE256 + hash_to_curve, the latter inside the
+ * un-vendored halo2curves); real keys enter through srs_ck_create (e.g. from the reference's cache file). */
+int srs_ck_setup_synthetic(int curve, size_t len, uint64_t seed, uint32_t rank, uint32_t world, srs_ck **out);
+/* Copies this rank's bases (`srs_ck_local_len` points, window 0 of the table) to host memory. */
+int srs_ck_get_bases(const srs_ck *ck, srs_affine *out);
+size_t srs_ck_local_len(const srs_ck *ck);
 void srs_ck_free(srs_ck *ck);
 size_t srs_ck_len(const srs_ck *ck);         /* CommitmentKey::len (src/commitment.rs:47-49) */
 
@@ -87,6 +94,84 @@ int srs_commit_batch(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, 
 int srs_point_sum(int curve, const srs_affine *points, size_t n, srs_affine *out);
 /* out = [scalar] P  (the 1-element best_multiexp of src/nifs/sangria/accumulator.rs:213,243), host. */
 int srs_point_mul(int curve, const srs_fe *scalar, int repr, const srs_affine *p, srs_affine *out);
+/* out = acc + sum_{i<n} scalars[i] * points[i] on the host (acc may be NULL = identity): the group half of
+ * RelaxedPlonkInstance::fold -- W_commitments (n = 1) and E_commitment (n = d) -- src/nifs/sangria/accumulator.rs:201-264. */
+int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n,
+                      int repr, srs_affine *out);
+
+/* ---- per-kernel timing (HIP events on the launch stream), used by bench.py's roofline leg ----
+ * names: "msm_accum0" (units = scalars), "rowprog_cross_terms" (rows), "rowprog_eval" (rows), "ntt_transform" (elements) */
+void srs_profile_enable(int on);
+void srs_profile_reset(void);
+int srs_profile_get(const char *name, double *total_ms, uint64_t *launches, uint64_t *units);
+
+/* ---- fft (src/fft.rs:160-198) ----
+ * In place, natural order in and out, `n` elements of bn256::Fr (the only 2-adic field of the cycle).
+ *   inverse = 0, coset = 0 : fft        (src/fft.rs:160-165)
+ *   inverse = 1, coset = 0 : ifft       (src/fft.rs:168-182)   (includes the * TWO_INV^k)
+ *   inverse = 0, coset = 1 : coset_fft  (src/fft.rs:186-190)
+ *   inverse = 1, coset = 1 : coset_ifft (src/fft.rs:194-198)
+ * n not a power of two -> SRS_ERR_NOT_POW2 (the reference asserts, :161,169; the shim re-panics);
+ * log2(n) > F::S = 28 -> SRS_ERR_K_TOO_LARGE (:13).  field must be SRS_FIELD_FR. */
+int srs_ntt(int field, srs_fe *a, size_t n, int inverse, int coset, int space, void *stream);
+/* `batch` independent transforms of length n, `stride` elements apart (ProtoGalaxy F/G/K vectors). */
+int srs_ntt_batch(int field, srs_fe *a, size_t n, size_t stride, size_t batch, int inverse, int coset,
+                  int space, void *stream);
+/* Tuning knob: bits per Cooley-Tukey digit (4..8, default 8) for n > 2^10; changes the pass
+ * structure (and drops cached twiddle plans), never the result.  Returns the value in effect. */
+int srs_ntt_set_max_radix_bits(int bits);
+
+/* ---- PlonkStructure slice for the row programs (src/plonk/mod.rs:127-157) ----
+ * What the kernels need of `PlonkStructure<F>`: k (rows = 2^k), selectors (bool columns), fixed
+ * columns, num_advice_columns and the gate expressions `S.gates`.  Lookup arguments are not
+ * supported (num_lookups = 0; the Poseidon configurations have none) -- the shim keeps the CPU
+ * path for structures with lookups.
+ *
+ * `gates`: the `Vec<Expression<F>>` (src/polynomial/expression.rs:112-120) serialised as a postfix
+ * stream of u64 words, one SRS_EX_END per gate:
+ *   SRS_EX_CONST c0 c1 c2 c3 | SRS_EX_POLY index rotation(i64) | SRS_EX_CHALLENGE index |
+ *   SRS_EX_NEG | SRS_EX_SUM | SRS_EX_PRODUCT | SRS_EX_SCALED c0 c1 c2 c3 | SRS_EX_END
+ * (constants in the same Montgomery layout as srs_fe).  The library then derives, like
+ * ConstraintSystemMetainfo::build / CompressedGates::new (src/table/constraint_system_metainfo.rs:81-104,
+ * src/plonk/mod.rs:84-107): compress_expression (src/plonk/util.rs:34-56), num_challenges,
+ * Expression::homogeneous (src/polynomial/expression.rs:356-429) and its degree d.
+ * Query indices out of range -> SRS_ERR_EVAL_INDEX (validated once here, not per row). */
+enum { SRS_EX_CONST = 0, SRS_EX_POLY = 1, SRS_EX_CHALLENGE = 2, SRS_EX_NEG = 3, SRS_EX_SUM = 4,
+       SRS_EX_PRODUCT = 5, SRS_EX_SCALED = 6, SRS_EX_END = 7 };
+int srs_structure_create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
+                         const uint8_t *const *selectors, const srs_fe *const *fixed, int space,
+                         const uint64_t *gates, size_t gates_words, size_t num_gates, srs_structure **out);
+void srs_structure_free(srs_structure *S);
+size_t srs_structure_num_cross_terms(const srs_structure *S);   /* d = grouped().len() - 1 */
+size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructure::num_challenges */
+
+/* Evaluation half of VanillaFS::commit_cross_terms (src/nifs/sangria/mod.rs:102-148):
+ *   T_out[k-1][row] = coefficient of X^k in P_homogeneous(fixed, W1 + X*W2, ch1 + X*ch2)[row],  k = 1..d
+ * W1, W2: round-0 witness vectors, column-major num_advice * 2^k (PlonkWitness::W[0]);
+ * challenges = U1.challenges || U1.u || U2.challenges || 1  (src/nifs/sangria/mod.rs:113-118);
+ * a challenge index outside that vector -> SRS_ERR_EVAL_INDEX (ChallengeIndexOutOfBoundary). */
+int srs_cross_terms(srs_structure *S, const srs_fe *W1, const srs_fe *W2, const srs_fe *challenges,
+                    size_t n_challenges, int space, void *stream, srs_fe *const *T_out);
+/* Whole commit_cross_terms: the evaluation above, then commits_out[k-1] = ck.commit(T_k) as one
+ * batched MSM over the shared base prefix (src/nifs/sangria/mod.rs:150-155).  T_out may be NULL
+ * when the caller does not need the vectors themselves (they stay on the device otherwise). */
+int srs_commit_cross_terms(srs_structure *S, srs_ck *ck, const srs_fe *W1, const srs_fe *W2,
+                           const srs_fe *challenges, size_t n_challenges, int space, void *stream,
+                           srs_fe *const *T_out, srs_affine *commits_out);
+/* Per-row gate value used by the deciders: homogeneous = 0 -> compressed gate with challenges =
+ * U.challenges (PlonkStructure::is_sat, src/plonk/mod.rs:304-361); homogeneous = 1 -> homogeneous
+ * gate with challenges = U.challenges || U.u (is_sat_accumulation, src/nifs/sangria/mod.rs:334-383). */
+int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges,
+                   size_t n_challenges, int space, void *stream, srs_fe *out);
+
+/* ---- RelaxedPlonkWitness::fold (src/nifs/sangria/accumulator.rs:364-404) ----
+ * srs_fold_witness: out[i] = w1[i] + r * w2[i]                                   (:366-376)
+ * srs_fold_error  : out[i] = e[i] + sum_{k<n_terms} r^(k+1) * T[k][i]            (:380-398)
+ * out may alias w1 / e. */
+int srs_fold_witness(int field, srs_fe *out, const srs_fe *w1, const srs_fe *w2, const srs_fe *r, size_t n,
+                     int space, void *stream);
+int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const *T, size_t n_terms,
+                   const srs_fe *r, size_t n, int space, void *stream);
 
 #ifdef __cplusplus
 }

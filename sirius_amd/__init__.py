@@ -2,8 +2,32 @@
 
 Host-side mirror of the reference interfaces this library replaces (names follow the reference):
   CommitmentKey.commit           <- src/commitment.rs:81-90
+  fft.{fft,ifft,coset_fft,coset_ifft} <- src/fft.rs:160-198
+  plonk.PlonkStructure / VanillaFS.commit_cross_terms / RelaxedPlonkWitness.fold
+                                 <- src/plonk/mod.rs:127-157, src/nifs/sangria/mod.rs:102-158, accumulator.rs:364-404
 Arrays are numpy uint64 `(n, 4)` field elements / `(n, 8)` affine points (Montgomery, LE limbs)
 or torch uint64/int64 CUDA tensors of the same shape for data already resident in HBM.
 """
+from . import _lib
 from ._lib import (CURVE_BN256, CURVE_GRUMPKIN, FIELD_FQ, FIELD_FR, SiriusAmdError)  # noqa: F401
-from .commitment import CommitmentKey, TooLongInput, point_mul, point_sum  # noqa: F401
+from .commitment import CommitmentKey, TooLongInput, point_lincomb, point_mul, point_sum  # noqa: F401
+from . import fft  # noqa: F401,E402
+from . import expression, field, plonk  # noqa: F401,E402
+from .plonk import PlonkStructure, RelaxedPlonkWitness, VanillaFS  # noqa: F401,E402
+
+
+def profile_enable(on=True):
+    _lib.lib().srs_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    _lib.lib().srs_profile_reset()
+
+
+def profile_get(name):
+    """-> dict(total_ms, launches, units) or None."""
+    import ctypes as _C
+    ms, n, u = _C.c_double(), _C.c_uint64(), _C.c_uint64()
+    if _lib.lib().srs_profile_get(name.encode(), _C.byref(ms), _C.byref(n), _C.byref(u)) != 0:
+        return None
+    return dict(total_ms=ms.value, launches=n.value, units=u.value)

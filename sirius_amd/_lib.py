@@ -34,12 +34,31 @@ def _prototypes():
         "srs_layout_selftest": (i32, [i32, vp, vp]),
         "srs_ck_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "srs_ck_create_sharded": (i32, [i32, vp, sz, i32, u32, u32, C.POINTER(vp)]),
+        "srs_ck_setup_synthetic": (i32, [i32, sz, C.c_uint64, u32, u32, C.POINTER(vp)]),
+        "srs_ck_get_bases": (i32, [vp, vp]),
+        "srs_ck_local_len": (sz, [vp]),
+        "srs_point_lincomb": (i32, [i32, vp, vp, vp, sz, i32, vp]),
+        "srs_profile_enable": (None, [i32]),
+        "srs_profile_reset": (None, []),
+        "srs_profile_get": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "srs_ck_free": (None, [vp]),
         "srs_ck_len": (sz, [vp]),
         "srs_commit": (i32, [vp, vp, sz, i32, i32, vp, vp]),
         "srs_commit_batch": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, i32, i32, vp, vp]),
         "srs_point_sum": (i32, [i32, vp, sz, vp]),
         "srs_point_mul": (i32, [i32, vp, i32, vp, vp]),
+        "srs_structure_create": (i32, [i32, u32, sz, sz, sz, C.POINTER(vp), C.POINTER(vp), i32, vp, sz, sz, C.POINTER(vp)]),
+        "srs_structure_free": (None, [vp]),
+        "srs_structure_num_cross_terms": (sz, [vp]),
+        "srs_structure_num_challenges": (sz, [vp]),
+        "srs_cross_terms": (i32, [vp, vp, vp, vp, sz, i32, vp, C.POINTER(vp)]),
+        "srs_commit_cross_terms": (i32, [vp, vp, vp, vp, vp, sz, i32, vp, C.POINTER(vp), vp]),
+        "srs_eval_gates": (i32, [vp, i32, vp, vp, sz, i32, vp, vp]),
+        "srs_fold_witness": (i32, [i32, vp, vp, vp, vp, sz, i32, vp]),
+        "srs_fold_error": (i32, [i32, vp, vp, C.POINTER(vp), sz, vp, sz, i32, vp]),
+        "srs_ntt": (i32, [i32, vp, sz, i32, i32, i32, vp]),
+        "srs_ntt_set_max_radix_bits": (i32, [i32]),
+        "srs_ntt_batch": (i32, [i32, vp, sz, sz, sz, i32, i32, i32, vp]),
     }
 
 

@@ -50,6 +50,24 @@ class CommitmentKey:
         L.check(L.lib().srs_ck_create_sharded(curve, addr, n, space, rank, world, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def setup_synthetic(cls, curve, n, seed=0, rank=0, world=1):
+        """Device-generated key P_i = [h(seed, i)]G for tests/benches -- NOT CommitmentKey::setup
+        (src/commitment.rs:55-79, hash_to_curve is un-vendored third-party code)."""
+        self = cls.__new__(cls)
+        self.curve, self._len, self.rank, self.world = curve, n, rank, world
+        h = C.c_void_p()
+        L.check(L.lib().srs_ck_setup_synthetic(curve, n, seed, rank, world, C.byref(h)))
+        self._h = h
+        return self
+
+    def bases(self):
+        """This rank's bases as (local_len, 8) uint64."""
+        n = L.lib().srs_ck_local_len(self._h)
+        out = np.zeros((n, 8), dtype=np.uint64)
+        L.check(L.lib().srs_ck_get_bases(self._h, out.ctypes.data))
+        return out
+
     def __len__(self):
         return self._len
 
@@ -94,6 +112,18 @@ def point_sum(curve, points):
     a = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
     out = np.zeros(8, dtype=np.uint64)
     L.check(L.lib().srs_point_sum(curve, a.ctypes.data, a.shape[0], out.ctypes.data))
+    return out
+
+
+def point_lincomb(curve, acc, points, scalars, repr=L.REPR_MONT):
+    """acc + sum scalars[i] * points[i] on the host (RelaxedPlonkInstance::fold, accumulator.rs:201-264)."""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    assert pts.shape[0] == sc.shape[0]
+    a = None if acc is None else np.ascontiguousarray(acc, dtype=np.uint64).reshape(8)
+    out = np.zeros(8, dtype=np.uint64)
+    L.check(L.lib().srs_point_lincomb(curve, None if a is None else a.ctypes.data, pts.ctypes.data, sc.ctypes.data,
+                                      pts.shape[0], repr, out.ctypes.data))
     return out
 
 

@@ -2,12 +2,16 @@
 #include "../../include/sirius_amd.h"
 
 #include <cstring>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "curve.cuh"
 #include "devrt.h"
 #include "msm.h"
+#include "ntt.h"
+#include "prof.h"
+#include "rowprog.h"
 
 namespace srs {
 static thread_local std::string g_err;
@@ -22,6 +26,11 @@ static_assert(sizeof(srs_fe) == sizeof(fe_t) && sizeof(srs_affine) == sizeof(aff
 struct srs_ck {
     msm::Key key;
     Arena staging;      // H2D staging of host scalars
+};
+
+struct srs_structure {
+    rowprog::Structure *s = nullptr;
+    Arena io;           // staged witnesses / cross-term vectors
 };
 
 namespace {
@@ -164,6 +173,42 @@ int srs_ck_create_sharded(int curve, const srs_affine *bases, size_t len, int sp
     });
 }
 
+int srs_ck_setup_synthetic(int curve, size_t len, uint64_t seed, uint32_t rank, uint32_t world, srs_ck **out) {
+    if (!valid_curve(curve) || !out || world == 0 || rank >= world) return fail(SRS_ERR_INVALID, "srs_ck_setup_synthetic: bad argument");
+    if (len > ((size_t)1 << 27)) return fail(SRS_ERR_INVALID, "srs_ck_setup_synthetic: key longer than 2^27 bases");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        srs_ck *ck = new srs_ck();
+        ck->key.curve = curve;
+        ck->key.global_len = len;
+        ck->key.rank = rank;
+        ck->key.world = world;
+        ck->key.len = shard_count(len, rank, world);
+        try {
+            if (ck->key.len) {
+                SRS_HIP_CHECK(hipMalloc((void **)&ck->key.table, ck->key.len * msm::NWIN * sizeof(affine_t)));
+                msm::generate_bases(ck->key, seed, nullptr);
+                msm::build_table(ck->key, nullptr);
+            }
+        } catch (...) {
+            srs_ck_free(ck);
+            throw;
+        }
+        *out = ck;
+        return SRS_OK;
+    });
+}
+
+int srs_ck_get_bases(const srs_ck *ck, srs_affine *out) {
+    if (!ck || (ck->key.len && !out)) return fail(SRS_ERR_INVALID, "srs_ck_get_bases: bad argument");
+    return guarded([&]() -> int {
+        if (ck->key.len) SRS_HIP_CHECK(hipMemcpy(out, ck->key.table, ck->key.len * sizeof(affine_t), hipMemcpyDeviceToHost));
+        return SRS_OK;
+    });
+}
+size_t srs_ck_local_len(const srs_ck *ck) { return ck ? ck->key.len : 0; }
+
 int srs_ck_create(int curve, const srs_affine *bases, size_t len, int space, srs_ck **out) {
     return srs_ck_create_sharded(curve, bases, len, space, 0, 1, out);
 }
@@ -257,6 +302,294 @@ int srs_point_mul(int curve, const srs_fe *scalar, int repr, const srs_affine *p
     };
     if (curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
     return SRS_OK;
+}
+
+int srs_ntt_batch(int field, srs_fe *a, size_t n, size_t stride, size_t batch, int inverse, int coset, int space,
+                  void *stream) {
+    if (!valid_field(field)) return fail(SRS_ERR_INVALID, "srs_ntt: unknown field");
+    if (n == 0 || (n & (n - 1))) return fail(SRS_ERR_NOT_POW2, "srs_ntt: length is not a power of two");
+    uint32_t log_n = 0;
+    while (((size_t)1 << log_n) < n) ++log_n;
+    if (field != SRS_FIELD_FR) return fail(SRS_ERR_INVALID, "srs_ntt: only bn256::Fr is 2-adic enough (Fq has S = 1)");
+    if (log_n > ntt::FR_S)
+        return fail(SRS_ERR_K_TOO_LARGE, "k=" + std::to_string(log_n) + " should no larger than F::S=" + std::to_string(ntt::FR_S));
+    if (batch == 0) return SRS_OK;
+    if (!a || (batch > 1 && stride < n)) return fail(SRS_ERR_INVALID, "srs_ntt: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        if (space == SRS_SPACE_DEVICE) {
+            ntt::run(reinterpret_cast<fe_t *>(a), log_n, stride, (uint32_t)batch, inverse != 0, coset != 0, st);
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            fe_t *d = nullptr;
+            size_t total = (batch - 1) * stride + n;
+            SRS_HIP_CHECK(hipMalloc((void **)&d, total * sizeof(fe_t)));
+            try {
+                SRS_HIP_CHECK(hipMemcpyAsync(d, a, total * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                ntt::run(d, log_n, stride, (uint32_t)batch, inverse != 0, coset != 0, st);
+                SRS_HIP_CHECK(hipMemcpyAsync(a, d, total * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipStreamSynchronize(st));
+            } catch (...) {
+                (void)hipFree(d);
+                throw;
+            }
+            SRS_HIP_CHECK(hipFree(d));
+        }
+        SRS_HIP_CHECK(hipGetLastError());
+        return SRS_OK;
+    });
+}
+
+int srs_ntt_set_max_radix_bits(int bits) {
+    int b = bits < 4 ? 4 : (bits > 8 ? 8 : bits);
+    ntt::set_max_radix_bits((uint32_t)b);
+    return b;
+}
+
+int srs_ntt(int field, srs_fe *a, size_t n, int inverse, int coset, int space, void *stream) {
+    return srs_ntt_batch(field, a, n, n, 1, inverse, coset, space, stream);
+}
+
+int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n, int repr,
+                      srs_affine *out) {
+    if (!valid_curve(curve) || !out || (n && (!points || !scalars))) return fail(SRS_ERR_INVALID, "srs_point_lincomb: bad argument");
+    auto go = [&](auto tag) {
+        using C = decltype(tag);
+        std::vector<xyzz_t> part(n);
+        auto work = [&](size_t i) {
+            fe_t s;
+            affine_t P;
+            std::memcpy(&s, &scalars[i], 32);
+            std::memcpy(&P, &points[i], 64);
+            if (repr == SRS_REPR_MONT) s = C::S::from_mont(s);
+            part[i] = Ec<C>::mul_canon(s.v, P);
+        };
+        if (n > 1) {                                   // the d scalar-muls are independent
+            std::vector<std::thread> th;
+            for (size_t i = 1; i < n; ++i) th.emplace_back(work, i);
+            work(0);
+            for (auto &t : th) t.join();
+        } else if (n == 1) {
+            work(0);
+        }
+        xyzz_t a = Ec<C>::identity();
+        if (acc) {
+            affine_t A;
+            std::memcpy(&A, acc, 64);
+            a = Ec<C>::from_affine(A);
+        }
+        for (size_t i = 0; i < n; ++i) a = Ec<C>::add(a, part[i]);
+        affine_t r = Ec<C>::to_affine(a);
+        std::memcpy(out, &r, sizeof(r));
+    };
+    if (curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
+    return SRS_OK;
+}
+
+void srs_profile_enable(int on) { prof::enable(on != 0); }
+void srs_profile_reset(void) { prof::reset(); }
+int srs_profile_get(const char *name, double *total_ms, uint64_t *launches, uint64_t *units) {
+    prof::Stat st;
+    if (!name || !prof::get(name, st)) return SRS_ERR_INVALID;
+    if (total_ms) *total_ms = st.total_ms;
+    if (launches) *launches = st.launches;
+    if (units) *units = st.units;
+    return SRS_OK;
+}
+
+// ------------------------------------------------------------------ row programs
+int srs_structure_create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
+                         const uint8_t *const *selectors, const srs_fe *const *fixed, int space, const uint64_t *gates,
+                         size_t gates_words, size_t num_gates, srs_structure **out) {
+    if (!valid_field(field) || !out || k > 30 || (num_selectors && !selectors) || (num_fixed && !fixed) || (gates_words && !gates))
+        return fail(SRS_ERR_INVALID, "srs_structure_create: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        std::string err;
+        int crc = 0;
+        rowprog::Structure *s = rowprog::create(field, k, num_selectors, num_fixed, num_advice, selectors,
+                                                reinterpret_cast<const fe_t *const *>(fixed), space == SRS_SPACE_DEVICE, gates,
+                                                gates_words, num_gates, crc, err);
+        if (!s) return fail(crc ? crc : SRS_ERR_INVALID, "srs_structure_create: " + err);
+        srs_structure *S = new srs_structure();
+        S->s = s;
+        *out = S;
+        return SRS_OK;
+    });
+}
+
+void srs_structure_free(srs_structure *S) {
+    if (!S) return;
+    rowprog::destroy(S->s);
+    S->io.release();
+    delete S;
+}
+size_t srs_structure_num_cross_terms(const srs_structure *S) { return S ? rowprog::degree(S->s) : 0; }
+size_t srs_structure_num_challenges(const srs_structure *S) { return S ? rowprog::num_challenges(S->s) : 0; }
+
+static int cross_terms_impl(srs_structure *S, srs_ck *ck, const srs_fe *W1, const srs_fe *W2, const srs_fe *challenges,
+                            size_t n_challenges, int space, void *stream, srs_fe *const *T_out, srs_affine *commits_out) {
+    if (!S || !W1 || !W2 || (n_challenges && !challenges)) return fail(SRS_ERR_INVALID, "srs_cross_terms: bad argument");
+    if (ck && !commits_out) return fail(SRS_ERR_INVALID, "srs_commit_cross_terms: commits_out is NULL");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        rowprog::Structure *s = S->s;
+        const size_t d = rowprog::degree(s), rows = rowprog::rows(s), wlen = rowprog::num_advice(s) * rows;
+        if (d == 0) return SRS_OK;
+        if (ck && rows > ck->key.global_len)
+            return fail(SRS_ERR_TOO_LONG_INPUT, "Can't commit too long input: input len: " + std::to_string(rows) +
+                                                    ", but limit is " + std::to_string(ck->key.global_len));
+        const bool host = space != SRS_SPACE_DEVICE;
+        const bool own_T = host || !T_out;
+        size_t need = 1024;
+        if (host) need += 2 * Arena::pad(wlen * sizeof(fe_t));
+        if (own_T) need += d * Arena::pad(rows * sizeof(fe_t));
+        S->io.reserve(need);
+        S->io.reset();
+        const fe_t *dW1 = reinterpret_cast<const fe_t *>(W1), *dW2 = reinterpret_cast<const fe_t *>(W2);
+        if (host) {
+            fe_t *a = S->io.take<fe_t>(wlen ? wlen : 1), *b = S->io.take<fe_t>(wlen ? wlen : 1);
+            SRS_HIP_CHECK(hipMemcpyAsync(a, W1, wlen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            SRS_HIP_CHECK(hipMemcpyAsync(b, W2, wlen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            dW1 = a;
+            dW2 = b;
+        }
+        std::vector<fe_t *> dT(d);
+        for (size_t k = 0; k < d; ++k) dT[k] = own_T ? S->io.take<fe_t>(rows) : reinterpret_cast<fe_t *>(T_out[k]);
+        std::string err;
+        int erc = rowprog::evaluate(s, 0, dW1, dW2, reinterpret_cast<const fe_t *>(challenges), n_challenges, dT.data(), st, err);
+        if (erc) return fail(erc, "srs_cross_terms: " + err);
+        if (ck) {
+            std::vector<const srs_fe *> v(d);
+            std::vector<size_t> nn(d, rows);
+            for (size_t k = 0; k < d; ++k) v[k] = reinterpret_cast<const srs_fe *>(dT[k]);
+            int crc = srs_commit_batch(ck, v.data(), nn.data(), d, SRS_SPACE_DEVICE, SRS_REPR_MONT, stream, commits_out);
+            if (crc) return crc;
+        }
+        if (host && T_out) {
+            for (size_t k = 0; k < d; ++k) SRS_HIP_CHECK(hipMemcpyAsync(T_out[k], dT[k], rows * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        return SRS_OK;
+    });
+}
+
+int srs_cross_terms(srs_structure *S, const srs_fe *W1, const srs_fe *W2, const srs_fe *challenges, size_t n_challenges,
+                    int space, void *stream, srs_fe *const *T_out) {
+    if (!T_out) return fail(SRS_ERR_INVALID, "srs_cross_terms: T_out is NULL");
+    return cross_terms_impl(S, nullptr, W1, W2, challenges, n_challenges, space, stream, T_out, nullptr);
+}
+int srs_commit_cross_terms(srs_structure *S, srs_ck *ck, const srs_fe *W1, const srs_fe *W2, const srs_fe *challenges,
+                           size_t n_challenges, int space, void *stream, srs_fe *const *T_out, srs_affine *commits_out) {
+    if (!ck) return fail(SRS_ERR_INVALID, "srs_commit_cross_terms: ck is NULL");
+    return cross_terms_impl(S, ck, W1, W2, challenges, n_challenges, space, stream, T_out, commits_out);
+}
+
+int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges, size_t n_challenges,
+                   int space, void *stream, srs_fe *out) {
+    if (!S || !W || !out || (n_challenges && !challenges)) return fail(SRS_ERR_INVALID, "srs_eval_gates: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        rowprog::Structure *s = S->s;
+        const size_t rows = rowprog::rows(s), wlen = rowprog::num_advice(s) * rows;
+        const bool host = space != SRS_SPACE_DEVICE;
+        const fe_t *dW = reinterpret_cast<const fe_t *>(W);
+        fe_t *dO = reinterpret_cast<fe_t *>(out);
+        if (host) {
+            S->io.reserve(Arena::pad(wlen * sizeof(fe_t)) + Arena::pad(rows * sizeof(fe_t)) + 1024);
+            S->io.reset();
+            fe_t *a = S->io.take<fe_t>(wlen ? wlen : 1);
+            SRS_HIP_CHECK(hipMemcpyAsync(a, W, wlen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            dW = a;
+            dO = S->io.take<fe_t>(rows);
+        }
+        std::string err;
+        fe_t *outs[1] = {dO};
+        int erc = rowprog::evaluate(s, homogeneous ? 2 : 1, dW, nullptr, reinterpret_cast<const fe_t *>(challenges), n_challenges, outs, st, err);
+        if (erc) return fail(erc, "srs_eval_gates: " + err);
+        if (host) {
+            SRS_HIP_CHECK(hipMemcpyAsync(out, dO, rows * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        return SRS_OK;
+    });
+}
+
+// ------------------------------------------------------------------ folds
+int srs_fold_witness(int field, srs_fe *out, const srs_fe *w1, const srs_fe *w2, const srs_fe *r, size_t n, int space, void *stream) {
+    if (!valid_field(field) || !r || (n && (!out || !w1 || !w2))) return fail(SRS_ERR_INVALID, "srs_fold_witness: bad argument");
+    if (n == 0) return SRS_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        fe_t rr;
+        std::memcpy(&rr, r, 32);
+        if (space == SRS_SPACE_DEVICE) {
+            rowprog::fold_w(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *>(w1), reinterpret_cast<const fe_t *>(w2), rr, n, st);
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            fe_t *a = nullptr, *b = nullptr;
+            SRS_HIP_CHECK(hipMalloc((void **)&a, n * sizeof(fe_t)));
+            if (hipMalloc((void **)&b, n * sizeof(fe_t)) != hipSuccess) { (void)hipFree(a); return fail(SRS_ERR_DEVICE, "hipMalloc failed"); }
+            try {
+                SRS_HIP_CHECK(hipMemcpyAsync(a, w1, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                SRS_HIP_CHECK(hipMemcpyAsync(b, w2, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                rowprog::fold_w(field, a, a, b, rr, n, st);
+                SRS_HIP_CHECK(hipMemcpyAsync(out, a, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipStreamSynchronize(st));
+            } catch (...) { (void)hipFree(a); (void)hipFree(b); throw; }
+            (void)hipFree(a);
+            (void)hipFree(b);
+        }
+        SRS_HIP_CHECK(hipGetLastError());
+        return SRS_OK;
+    });
+}
+
+int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const *T, size_t n_terms, const srs_fe *r, size_t n,
+                   int space, void *stream) {
+    if (!valid_field(field) || !r || (n && (!out || !e)) || (n_terms && !T)) return fail(SRS_ERR_INVALID, "srs_fold_error: bad argument");
+    if (n == 0) return SRS_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        fe_t rr;
+        std::memcpy(&rr, r, 32);
+        std::string err;
+        if (space == SRS_SPACE_DEVICE) {
+            int erc = rowprog::fold_e(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *>(e),
+                                      reinterpret_cast<const fe_t *const *>(T), n_terms, rr, n, st, err);
+            if (erc) return fail(erc, "srs_fold_error: " + err);
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            fe_t *buf = nullptr;
+            SRS_HIP_CHECK(hipMalloc((void **)&buf, (n_terms + 1) * n * sizeof(fe_t)));
+            try {
+                SRS_HIP_CHECK(hipMemcpyAsync(buf, e, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                std::vector<const fe_t *> tp(n_terms);
+                for (size_t k = 0; k < n_terms; ++k) {
+                    SRS_HIP_CHECK(hipMemcpyAsync(buf + (k + 1) * n, T[k], n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                    tp[k] = buf + (k + 1) * n;
+                }
+                int erc = rowprog::fold_e(field, buf, buf, tp.data(), n_terms, rr, n, st, err);
+                if (erc) { (void)hipFree(buf); return fail(erc, "srs_fold_error: " + err); }
+                SRS_HIP_CHECK(hipMemcpyAsync(out, buf, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipStreamSynchronize(st));
+            } catch (...) { (void)hipFree(buf); throw; }
+            (void)hipFree(buf);
+        }
+        SRS_HIP_CHECK(hipGetLastError());
+        return SRS_OK;
+    });
 }
 
 }  // extern "C"

@@ -39,6 +39,8 @@ struct Key {
 
 // fills table[len .. 16*len) from table[0 .. len)
 void build_table(Key &k, hipStream_t stream);
+// fills table[0 .. len) with the synthetic key (see k_gen_bases)
+void generate_bases(Key &k, uint64_t seed, hipStream_t stream);
 
 size_t workspace_bytes(uint32_t n_max, uint32_t batch);
 

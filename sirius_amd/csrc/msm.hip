@@ -23,6 +23,7 @@
 // Batched entry: the d-1 cross-term commitments share one base prefix and run
 // as one set of launches (grid.y / grid.z = batch index).
 #include "msm.h"
+#include "prof.h"
 
 #include <algorithm>
 #include <vector>
@@ -98,6 +99,44 @@ __global__ void k_normalize(const xyzz_t *__restrict__ in, affine_t *__restrict_
         }
         out[lo + j] = o;
     }
+}
+
+// synthetic key: P_i = [h(seed, g)] G with g the GLOBAL index of local base i  (NOT the reference's
+// SHAKE256 + hash_to_curve key, src/commitment.rs:55-79 -- hash_to_curve is [3P]; any valid points
+// with no known small relation serve parity and timing)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+template <class C>
+__global__ void k_gen_bases(xyzz_t *__restrict__ tmp, uint32_t n, uint64_t seed, uint32_t rank, uint32_t world) {
+    using F = typename C::F;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t g = shard_global_index(i, rank, world);
+    uint64_t st = seed ^ (g * 0x100000001b3ull + 0xcbf29ce484222325ull);
+    uint32_t k[8];
+    for (int j = 0; j < 4; ++j) {
+        uint64_t v = splitmix64(st);
+        k[2 * j] = (uint32_t)v;
+        k[2 * j + 1] = (uint32_t)(v >> 32);
+    }
+    k[7] &= 0x0FFFFFFFu;   // < 2^252 < group order
+    k[0] |= 1u;
+    affine_t gen;
+    gen.x = F::one();
+    if (C::ID == 0) {
+        gen.y = F::dbl(F::one());                                  // bn256 G1 generator (1, 2)
+    } else {
+        // grumpkin generator (1, sqrt(-16)) = 17631683881184975370165255887551781615748388533673675138860
+        fe_t y;
+        const uint32_t yc[8] = {0x823f272cu, 0x833fc48du, 0xf1181294u, 0x2d270d45u, 0x06a45d63u, 0xcf135e75u, 0x00000002u, 0u};
+        for (int j = 0; j < 8; ++j) y.v[j] = yc[j];
+        gen.y = F::to_mont(y);
+    }
+    tmp[i] = Ec<C>::mul_canon(k, gen);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -444,6 +483,21 @@ static void build_table_t(Key &k, hipStream_t stream) {
     SRS_HIP_CHECK(hipFree(tmp));
 }
 
+template <class C>
+static void generate_t(Key &k, uint64_t seed, hipStream_t stream) {
+    const uint32_t n = (uint32_t)k.len;
+    if (n == 0) return;
+    xyzz_t *tmp = nullptr;
+    SRS_HIP_CHECK(hipMalloc((void **)&tmp, (size_t)n * sizeof(xyzz_t)));
+    SRS_LAUNCH((k_gen_bases<C>), (ceil_div(n, 128)), (128), 0, stream, tmp, n, seed, k.rank, k.world);
+    SRS_LAUNCH((k_normalize<C>), (ceil_div(ceil_div(n, NORM_G), 128)), (128), 0, stream, (const xyzz_t *)tmp, k.table, n);
+    SRS_HIP_CHECK(hipStreamSynchronize(stream));
+    SRS_HIP_CHECK(hipFree(tmp));
+}
+void generate_bases(Key &k, uint64_t seed, hipStream_t stream) {
+    if (k.curve == 0) generate_t<Bn256>(k, seed, stream); else generate_t<Grumpkin>(k, seed, stream);
+}
+
 void build_table(Key &k, hipStream_t stream) {
     if (k.curve == 0) build_table_t<Bn256>(k, stream); else build_table_t<Grumpkin>(k, stream);
 }
@@ -524,9 +578,14 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                (const uint32_t *)d_n, cursor, sorted, (size_t)M, (uint32_t)k.len);
 
-    SRS_LAUNCH((k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
-               (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride,
-               (const affine_t *)k.table, ping, (size_t)parts0_cap, (uint32_t)ACC_L0);
+    uint64_t units = 0;
+    for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
+    {
+        prof::Scope ps("msm_accum0", stream, units);
+        SRS_LAUNCH((k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+                   (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride,
+                   (const affine_t *)k.table, ping, (size_t)parts0_cap, (uint32_t)ACC_L0);
+    }
     xyzz_t *cur = ping, *nxt = pong;
     size_t cur_stride = parts0_cap, nxt_stride = parts1_cap;
     uint64_t cap = parts0_cap;
@@ -546,6 +605,7 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     SRS_HIP_CHECK(hipMemcpyAsync(result_host, d_out, batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
     SRS_HIP_CHECK(hipGetLastError());
+    prof::collect();
 }
 
 void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch, int is_mont,

@@ -1,0 +1,404 @@
+// ntt.hip -- radix-2 NTT over bn256::Fr on gfx950: fft / ifft / coset_fft / coset_ifft.
+//
+// Replaces the bodies of reference src/fft.rs:160-198 (`fft`, `ifft`, `coset_fft`, `coset_ifft`
+// over `best_fft`, :61-115).  Same contract: in place, natural order in AND out,
+//   fft : a_i <- sum_j a_j w^(ij),  w = ROOT_OF_UNITY^(2^(S-k))            (:12-23)
+//   ifft: same with w^-1, then * TWO_INV^k                                  (:168-182)
+//   coset_fft : a_i *= ZETA^(i mod 3) first; coset_ifft: a_i *= ZETA^-(i mod 3) last (:186-228)
+// Field arithmetic is exact, so any butterfly schedule reproduces the reference bit for bit.
+//
+// MI355X-first schedule (not the reference's bit-reverse + recursive rayon::join):
+//   * n <= 2^10: one workgroup, whole vector in LDS, bit-reversed load + DIT stages.
+//   * larger n: Cooley-Tukey over p = ceil(k/8) digits of <= 8 bits.  Pass j transforms digit j
+//     for a tile of 16 neighbouring columns (512 B contiguous per row -> coalesced HBM traffic),
+//     all 2^r x 16 elements staged in LDS (up to 128 KiB of the CU's 160 KiB), butterflies from an
+//     LDS-resident w_(2^r) table, then ONE multiply by a precomputed inter-digit twiddle that is
+//     read coalesced (same index pattern as the data).  The last pass writes through the digit
+//     reversal so the result lands in natural order; ifft's n^-1 is folded into the first table.
+//     Physical traffic = P x 64 B/element (+32 B for the first-pass table), P = number of passes.
+#include "ntt.h"
+#include "prof.h"
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace srs {
+namespace ntt {
+
+constexpr uint32_t COLS = 16;      // neighbouring columns per tile (512 B rows)
+constexpr uint32_t SMALL_LOG = 10; // single-workgroup path up to 2^10 points
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// T[i] = scale * base^(e(i)),  e(i) = (i >> lo_bits) * (i & (2^lo_bits - 1)) mod 2^m   (m = log2 of table)
+// lo_bits == 0 : plain powers base^i.
+__global__ void k_fill_table(fe_t *__restrict__ T, uint32_t log_entries, uint32_t lo_bits, fe_t base, fe_t scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << log_entries)) return;
+    uint64_t e;
+    if (lo_bits == 0) {
+        e = i;
+    } else {
+        uint64_t k = i >> lo_bits, rest = i & (((uint64_t)1 << lo_bits) - 1);
+        e = (k * rest) & (((uint64_t)1 << log_entries) - 1);
+    }
+    fe_t acc = scale;
+    fe_t b = base;
+    while (e) {
+        if (e & 1) acc = Fr::mul(acc, b);
+        b = Fr::sqr(b);
+        e >>= 1;
+    }
+    T[i] = acc;
+}
+
+struct Scale3 {   // multiply element with global index i by z[i % 3] (z[0] unused = 1)
+    fe_t z1, z2;
+    int on;
+};
+__device__ __forceinline__ fe_t apply_scale3(const Scale3 &s, fe_t v, size_t idx) {
+    uint32_t r = (uint32_t)(idx % 3);
+    if (r == 1) return Fr::mul(v, s.z1);
+    if (r == 2) return Fr::mul(v, s.z2);
+    return v;
+}
+
+// one DIT butterfly stage over an LDS tile laid out [row][col], rows = 2^rbits
+template <uint32_t NCOLS>
+__device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rbits, uint32_t s) {
+    const uint32_t half = 1u << s;
+    const uint32_t pairs = (1u << (rbits - 1)) * NCOLS;
+    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
+        uint32_t c = p % NCOLS, q = p / NCOLS;
+        uint32_t j = q & (half - 1);
+        uint32_t lo = ((q >> s) << (s + 1)) | j;
+        uint32_t hi = lo + half;
+        fe_t a = tile[lo * NCOLS + c];
+        fe_t b = tile[hi * NCOLS + c];
+        if (j) b = Fr::mul(b, W[j << (rbits - 1 - s)]);
+        tile[lo * NCOLS + c] = Fr::add(a, b);
+        tile[hi * NCOLS + c] = Fr::sub(a, b);
+    }
+}
+
+// ---- single-workgroup transform, n = 2^k <= 2^SMALL_LOG; grid.x = batch of independent vectors
+__global__ void SRS_KERNEL_BOUNDS(512, 1)
+    k_ntt_small(fe_t *__restrict__ a, size_t stride, uint32_t k, const fe_t *__restrict__ Wg, fe_t post, int has_post,
+                Scale3 pre, Scale3 fin) {
+    __shared__ fe_t tile[1u << SMALL_LOG];
+    __shared__ fe_t W[1u << (SMALL_LOG - 1)];
+    const uint32_t n = 1u << k;
+    fe_t *v = a + (size_t)blockIdx.x * stride;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        fe_t x = v[i];
+        if (pre.on) x = apply_scale3(pre, x, i);
+        tile[bitrev(i, k)] = x;
+    }
+    for (uint32_t i = threadIdx.x; i < (n >> 1); i += blockDim.x) W[i] = Wg[i];
+    __syncthreads();
+    for (uint32_t s = 0; s < k; ++s) {
+        lds_stage<1>(tile, W, k, s);
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        fe_t x = tile[i];
+        if (has_post) x = Fr::mul(x, post);
+        if (fin.on) x = apply_scale3(fin, x, i);
+        v[i] = x;
+    }
+}
+
+// ---- one digit of the multi-pass transform
+struct PassArgs {
+    uint32_t log_n;
+    uint32_t rbits;      // this digit's width
+    uint32_t lbits;      // bits below this digit (0 for the last pass)
+    uint32_t npass, pass;
+    uint32_t radix_bits[4];   // widths of digit 1..p (digit 1 = most significant input bits)
+};
+
+// non-final pass: tile = (hi, 16 consecutive `rest`), in place, times inter-digit twiddle T
+template <uint32_t RBITS>
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_ntt_pass(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg,
+               const fe_t *__restrict__ T, Scale3 pre) {
+    __shared__ fe_t tile[(1u << RBITS) * COLS];
+    __shared__ fe_t W[1u << (RBITS - 1)];
+    const uint32_t rows = 1u << RBITS;
+    const uint32_t tiles_per_hi = 1u << (pa.lbits - 4);           // lbits >= 4
+    const size_t hi = blockIdx.x / tiles_per_hi;
+    const uint32_t rest0 = (blockIdx.x % tiles_per_hi) * COLS;
+    const size_t base = (hi << (RBITS + pa.lbits)) + rest0;
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t d = e / COLS, c = e % COLS;
+        size_t idx = base + ((size_t)d << pa.lbits) + c;
+        fe_t x = src[idx];
+        if (pre.on) x = apply_scale3(pre, x, idx);
+        tile[bitrev(d, RBITS) * COLS + c] = x;
+    }
+    for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
+    __syncthreads();
+    for (uint32_t s = 0; s < RBITS; ++s) {
+        lds_stage<COLS>(tile, W, RBITS, s);
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t kd = e / COLS, c = e % COLS;
+        size_t tidx = ((size_t)kd << pa.lbits) + rest0 + c;      // T[k_j][rest]
+        fe_t x = Fr::mul(tile[e], T[tidx]);
+        dst[base + ((size_t)kd << pa.lbits) + c] = x;
+    }
+}
+
+// final pass: tile = 16 consecutive k1 (most significant memory digit) x one contiguous run;
+// output index = digit reversal  k1 + N1*(k2 + N2*(...)) + (N1..N_{p-1}) * k_p
+template <uint32_t RBITS>
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_ntt_last(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg, Scale3 fin) {
+    __shared__ fe_t tile[(1u << RBITS) * COLS];
+    __shared__ fe_t W[1u << (RBITS - 1)];
+    const uint32_t rows = 1u << RBITS;
+    const uint32_t r1 = pa.radix_bits[0];
+    const uint32_t mid_bits = pa.log_n - r1 - RBITS;              // digits 2..p-1
+    const uint32_t mid = blockIdx.x & ((1u << mid_bits) - 1);
+    const uint32_t k1_0 = (blockIdx.x >> mid_bits) * COLS;
+    // digit-reverse `mid` (memory order: digit 2 most significant) into output order (digit 2 least)
+    uint32_t out_mid = 0;
+    {
+        uint32_t m = mid, shift_out = 0;
+        // peel digits from the least significant memory digit (p-1) down to digit 2
+        uint32_t widths[2], nd = 0;
+        for (uint32_t j = pa.npass - 1; j >= 2; --j) widths[nd++] = pa.radix_bits[j - 1];   // digit j width
+        // total output offset of digit j = sum of widths of digits 2..j-1
+        uint32_t off_of[2];
+        for (uint32_t t = 0; t < nd; ++t) {
+            uint32_t j = pa.npass - 1 - t, off = 0;
+            for (uint32_t q = 2; q < j; ++q) off += pa.radix_bits[q - 1];
+            off_of[t] = off;
+        }
+        for (uint32_t t = 0; t < nd; ++t) {
+            uint32_t dg = m & ((1u << widths[t]) - 1);
+            m >>= widths[t];
+            out_mid |= dg << off_of[t];
+        }
+        (void)shift_out;
+    }
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t c = e / rows, i = e % rows;
+        size_t idx = ((size_t)(k1_0 + c) << (pa.log_n - r1)) + ((size_t)mid << RBITS) + i;
+        tile[bitrev(i, RBITS) * COLS + c] = src[idx];
+    }
+    for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
+    __syncthreads();
+    for (uint32_t s = 0; s < RBITS; ++s) {
+        lds_stage<COLS>(tile, W, RBITS, s);
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t kp = e / COLS, c = e % COLS;
+        size_t oidx = (size_t)(k1_0 + c) + ((size_t)out_mid << r1) + ((size_t)kp << (pa.log_n - RBITS));
+        fe_t x = tile[e];
+        if (fin.on) x = apply_scale3(fin, x, oidx);
+        dst[oidx] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: constants, plans
+// ---------------------------------------------------------------------------------------------
+struct Consts {
+    fe_t root, root_inv, two_inv, zeta, zeta2;
+};
+static const Consts &consts() {
+    static Consts c = [] {
+        Consts k;
+        // ROOT_OF_UNITY = 7^((r-1) / 2^28)  [3P halo2curves bn256::Fr, pinned by src/fft.rs:241-260]
+        uint32_t e[8];
+        for (int i = 0; i < 8; ++i) e[i] = FrP::p(i);
+        e[0] -= 1;
+        for (int s = 0; s < 28; ++s) {
+            for (int i = 0; i < 8; ++i) e[i] = (e[i] >> 1) | (i < 7 ? (e[i + 1] << 31) : 0);
+        }
+        k.root = Fr::pow(Fr::from_u64(7), e);
+        k.root_inv = Fr::inv(k.root);
+        k.two_inv = Fr::inv(Fr::from_u64(2));
+        // ZETA (WithSmallOrderMulGroup<3>) [3P halo2curves], canonical value:
+        fe_t z;
+        const uint32_t zc[8] = {0x36636f23u, 0xb8ca0b2du, 0xec2bc5e9u, 0xcc37a73fu, 0x3fd84104u, 0x048b6e19u, 0xe131a029u, 0x30644e72u};
+        for (int i = 0; i < 8; ++i) z.v[i] = zc[i];
+        k.zeta = Fr::to_mont(z);
+        k.zeta2 = Fr::sqr(k.zeta);
+        return k;
+    }();
+    return c;
+}
+static fe_t omega_for(uint32_t k, bool inverse) {      // src/fft.rs:12-23
+    fe_t w = inverse ? consts().root_inv : consts().root;
+    for (uint32_t i = k; i < FR_S; ++i) w = Fr::sqr(w);
+    return w;
+}
+
+struct Plan {
+    uint32_t log_n = 0;
+    bool inverse = false;
+    uint32_t npass = 0;
+    uint32_t radix_bits[4] = {0, 0, 0, 0};
+    fe_t *W[4] = {nullptr, nullptr, nullptr, nullptr};   // w_(2^r)^e tables per pass (small path: W[0] = w_n^e)
+    fe_t *T[4] = {nullptr, nullptr, nullptr, nullptr};   // inter-digit twiddles after pass j (j < npass-1)
+    fe_t scale;                                          // n^-1 for ifft (small path only)
+    fe_t *scratch = nullptr;                             // n elements (multi-pass ping buffer)
+};
+
+static std::mutex g_mu;
+static uint32_t g_max_radix = 8;   // tuning knob (4..8): digits per pass; never changes results
+static std::map<std::pair<uint32_t, bool>, Plan> g_plans;
+
+static void fill(fe_t *T, uint32_t log_entries, uint32_t lo_bits, const fe_t &base, const fe_t &scale, hipStream_t st) {
+    size_t n = (size_t)1 << log_entries;
+    SRS_LAUNCH(k_fill_table, ((uint32_t)((n + 255) / 256)), (256), 0, st, T, log_entries, lo_bits, base, scale);
+}
+
+static Plan &get_plan(uint32_t log_n, bool inverse, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(log_n, inverse);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    Plan p;
+    p.log_n = log_n;
+    p.inverse = inverse;
+    fe_t ninv = Fr::one();
+    if (inverse)
+        for (uint32_t i = 0; i < log_n; ++i) ninv = Fr::mul(ninv, consts().two_inv);   // TWO_INV^k, src/fft.rs:25-27
+    p.scale = ninv;
+    if (log_n <= SMALL_LOG) {
+        p.npass = 1;
+        p.radix_bits[0] = log_n;
+        if (log_n >= 1) {
+            SRS_HIP_CHECK(hipMalloc((void **)&p.W[0], sizeof(fe_t) << (log_n - 1)));
+            fill(p.W[0], log_n - 1, 0, omega_for(log_n, inverse), Fr::one(), st);
+        }
+    } else {
+        p.npass = (log_n + g_max_radix - 1) / g_max_radix;
+        if (p.npass > 4) { set_error("ntt: max radix too small for this length"); throw DeviceError{4}; }
+        uint32_t left = log_n;
+        for (uint32_t j = 0; j < p.npass; ++j) {
+            uint32_t r = (left + (p.npass - j) - 1) / (p.npass - j);
+            p.radix_bits[j] = r;
+            left -= r;
+            if (r < 4) { set_error("ntt: digit narrower than 4 bits (raise max radix)"); throw DeviceError{4}; }
+        }
+        uint32_t below = log_n;
+        for (uint32_t j = 0; j < p.npass; ++j) {
+            uint32_t r = p.radix_bits[j];
+            below -= r;
+            SRS_HIP_CHECK(hipMalloc((void **)&p.W[j], sizeof(fe_t) << (r - 1)));
+            fill(p.W[j], r - 1, 0, omega_for(r, inverse), Fr::one(), st);
+            if (j + 1 < p.npass) {
+                uint32_t m = r + below;     // M_j = 2^m entries: T[k][rest] = w_M^(k*rest), k < 2^r, rest < 2^below
+                SRS_HIP_CHECK(hipMalloc((void **)&p.T[j], sizeof(fe_t) << m));
+                fill(p.T[j], m, below, omega_for(m, inverse), j == 0 ? ninv : Fr::one(), st);
+            }
+        }
+        SRS_HIP_CHECK(hipMalloc((void **)&p.scratch, sizeof(fe_t) << log_n));
+    }
+    SRS_HIP_CHECK(hipStreamSynchronize(st));
+    return g_plans.emplace(key, p).first->second;
+}
+
+void set_max_radix_bits(uint32_t bits) {
+    release_plans();
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_max_radix = bits < 4 ? 4 : (bits > 8 ? 8 : bits);
+}
+
+void release_plans() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_plans) {
+        for (int j = 0; j < 4; ++j) {
+            if (kv.second.W[j]) (void)hipFree(kv.second.W[j]);
+            if (kv.second.T[j]) (void)hipFree(kv.second.T[j]);
+        }
+        if (kv.second.scratch) (void)hipFree(kv.second.scratch);
+    }
+    g_plans.clear();
+}
+
+template <uint32_t R>
+static void launch_pass(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &pre,
+                        hipStream_t st) {
+    uint32_t blocks = 1u << (pa.log_n - R - 4);
+    uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
+    SRS_LAUNCH((k_ntt_pass<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
+}
+template <uint32_t R>
+static void launch_last(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &fin,
+                        hipStream_t st) {
+    uint32_t blocks = 1u << (pa.log_n - R - 4);
+    uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
+    SRS_LAUNCH((k_ntt_last<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
+}
+#define DISPATCH_R(fn, r, ...)                          \
+    switch (r) {                                        \
+    case 4: fn<4>(__VA_ARGS__); break;                  \
+    case 5: fn<5>(__VA_ARGS__); break;                  \
+    case 6: fn<6>(__VA_ARGS__); break;                  \
+    case 7: fn<7>(__VA_ARGS__); break;                  \
+    default: fn<8>(__VA_ARGS__); break;                 \
+    }
+
+// a: device pointer to `batch` vectors of 2^log_n elements, `stride` apart.  In place.
+void run(fe_t *a, uint32_t log_n, size_t stride, uint32_t batch, bool inverse, bool coset, hipStream_t st) {
+    Plan &p = get_plan(log_n, inverse, st);
+    prof::Scope ps("ntt_transform", st, (uint64_t)batch << log_n);
+    Scale3 none;
+    none.z1 = none.z2 = Fr::one();
+    none.on = 0;
+    Scale3 pre = none, fin = none;
+    if (coset && !inverse) {        // distribute_powers_zeta(into_coset = true): [zeta, zeta^2]
+        pre.z1 = consts().zeta;
+        pre.z2 = consts().zeta2;
+        pre.on = 1;
+    }
+    if (coset && inverse) {         // moving out of the coset: [zeta^2, zeta]
+        fin.z1 = consts().zeta2;
+        fin.z2 = consts().zeta;
+        fin.on = 1;
+    }
+    if (p.npass == 1) {
+        uint32_t n = 1u << log_n;
+        uint32_t threads = n >= 1024 ? 512 : (n >= 128 ? n / 2 : 64);
+        SRS_LAUNCH(k_ntt_small, (batch), (threads), 0, st, a, stride, log_n, (const fe_t *)p.W[0], p.scale,
+                   (int)(inverse ? 1 : 0), pre, fin);
+        return;
+    }
+    for (uint32_t b = 0; b < batch; ++b) {
+        fe_t *v = a + (size_t)b * stride;
+        PassArgs pa;
+        pa.log_n = log_n;
+        pa.npass = p.npass;
+        for (int j = 0; j < 4; ++j) pa.radix_bits[j] = p.radix_bits[j];
+        // ping-pong so that the last (out-of-place) pass lands in v:
+        //   npass odd : v -> scratch (pass 1), scratch in place ..., scratch -> v (last)
+        //   the first pass may be out of place because it keeps positions; middle passes are in place.
+        uint32_t below = log_n;
+        const fe_t *src = v;
+        for (uint32_t j = 0; j + 1 < p.npass; ++j) {
+            uint32_t r = p.radix_bits[j];
+            below -= r;
+            pa.rbits = r;
+            pa.lbits = below;
+            pa.pass = j;
+            DISPATCH_R(launch_pass, r, src, p.scratch, pa, p, j, (j == 0 ? pre : none), st);
+            src = p.scratch;
+        }
+        uint32_t r = p.radix_bits[p.npass - 1];
+        pa.rbits = r;
+        pa.lbits = 0;
+        pa.pass = p.npass - 1;
+        DISPATCH_R(launch_last, r, (const fe_t *)p.scratch, v, pa, p, p.npass - 1, fin, st);
+    }
+}
+
+}  // namespace ntt
+}  // namespace srs

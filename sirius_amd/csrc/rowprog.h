@@ -1,0 +1,42 @@
+// rowprog.h -- internal interface of the row-program engine (see rowprog.hip).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "devrt.h"
+#include "field.cuh"
+
+namespace srs {
+namespace rowprog {
+
+struct Insn {   // 16 bytes, read wave-uniformly
+    uint32_t op, dst, a, b;
+};
+
+struct Structure;
+
+// rc: 0 ok, 4 invalid, 5 device, 7 index out of range
+Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
+                  const uint8_t *const *selectors, const fe_t *const *fixed, int space_device,
+                  const uint64_t *gates, size_t gates_words, size_t num_gates, int &rc, std::string &err);
+void destroy(Structure *S);
+size_t degree(const Structure *S);            // homogeneous degree d = number of cross terms
+size_t num_challenges(const Structure *S);    // PlonkStructure::num_challenges
+size_t num_advice(const Structure *S);
+size_t rows(const Structure *S);
+int field(const Structure *S);
+
+// mode 0: cross terms T_1..T_d (W1, W2, challenges = U1.ch || U1.u || U2.ch || 1)
+// mode 1: compressed gate value per row on W1   (challenges = U.ch)
+// mode 2: homogeneous gate value per row on W1  (challenges = U.ch || U.u)
+// W*, outputs: DEVICE pointers (out_dev_ptrs_host = host array of device pointers).
+int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host, size_t n_ch,
+             fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err);
+
+void fold_w(int field, fe_t *out, const fe_t *w1, const fe_t *w2, const fe_t &r, size_t n, hipStream_t st);
+int fold_e(int field, fe_t *out, const fe_t *e, const fe_t *const *t_dev_ptrs_host, size_t n_terms, const fe_t &r, size_t n,
+           hipStream_t st, std::string &err);
+
+}  // namespace rowprog
+}  // namespace srs

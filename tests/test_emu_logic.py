@@ -1,0 +1,73 @@
+"""CPU: runs the product kernels' *logic* (sort, segmented accumulation, bucket reduction, NTT passes,
+row programs) on the host through tests/emu/hipemu.h and checks them against the oracle.
+This is a development aid for a GPU-less container -- the emulated build is a separate test
+library (tests/emu/libsirius_emu.so), never the product."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, seeded_scalars
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libsirius_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    import sirius_amd as S
+    from sirius_amd import _lib
+    _lib.load(EMU_LIB)
+    yield S
+    _lib._lib = None          # the real library is (re)loaded lazily by later tests
+
+
+def test_emu_commit(emu, oracle):
+    O = oracle
+    for cid, n, kind in ((0, 300, "uniform"), (1, 300, "trace"), (0, 1, "uniform")):
+        bases = O.make_bases(cid, 7 + cid, 300)
+        ck = emu.CommitmentKey(cid, bases)
+        sc = seeded_scalars(O, cid, n, 5, kind)
+        assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases[:n]))
+        ck.close()
+
+
+def test_emu_ntt(emu, oracle):
+    O = oracle
+    rng = np.random.default_rng(1)
+    for k in (0, 3, 7, 11, 13):
+        raw = rng.integers(0, 1 << 63, size=(1 << k, 4), dtype=np.uint64)
+        raw[:, 3] &= np.uint64((1 << 60) - 1)
+        a = O.to_mont(O.FR, raw)
+        for fn in ("fft", "ifft", "coset_fft", "coset_ifft"):
+            assert np.array_equal(getattr(emu.fft, fn)(a.copy()), getattr(O, fn)(a)), (k, fn)
+
+
+def test_emu_cross_terms(emu, oracle):
+    O = oracle
+    from oracle import expr as OE
+    from workloads import gates_for, rand_fe
+    for field, k, gate_T in ((0, 4, [5, 3]), (1, 3, [5])):
+        rows = 1 << k
+        gates, nfix, nadv = gates_for(gate_T)
+        og, fo, ao = [], 0, 0
+        for T in gate_T:
+            og.append(OE.main_gate_expression(T, 0, fo, ao, nfix)); fo += 2 * T + 5; ao += T + 2
+        rng = np.random.default_rng(k)
+        fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
+        W1, W2 = rand_fe(rng, nadv * rows), rand_fe(rng, nadv * rows)
+        S = emu.PlonkStructure(field, k, [], fixed, nadv, gates)
+        nch = S.num_challenges
+        u1c, u1u, u2c = rand_fe(rng, nch), rand_fe(rng, 1)[0], rand_fe(rng, nch)
+        terms, _ = emu.VanillaFS.commit_cross_terms(None, S, u1c, u1u, W1, u2c, W2)
+        ch = emu.VanillaFS.cross_term_challenges(u1c, u1u, u2c, field)
+        cg, exp = OE.cross_terms_oracle(O, field, og, 0, nfix, nadv, [], fixed, W1, W2, ch)
+        assert len(terms) == cg.degree
+        for a, b in zip(terms, exp):
+            assert np.array_equal(a, b)
+        r, E = rand_fe(rng, 1)[0], rand_fe(rng, rows)
+        acc = emu.RelaxedPlonkWitness(field, [W1], E).fold([W2], terms, r)
+        assert np.array_equal(acc.W[0], O.fold_w(field, W1, W2, r)) and np.array_equal(acc.E, O.fold_e(field, E, exp, r))
+        S.close()
