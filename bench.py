@@ -83,14 +83,8 @@ def combine(S, side, partial, dist, world, dev):
     """all-gather the per-rank partial commitments (RCCL) and sum them on the host."""
     if world == 1:
         return partial
-    import torch
-    p = np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1, 8)
-    t = torch.from_numpy(p.view(np.int64)).to(dev)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=dev)
-    dist.all_gather_into_tensor(out, t)
-    g = out.cpu().numpy().view(np.uint64)                       # (world, m, 8)
-    res = np.stack([S.point_sum(side.curve, g[:, j, :]) for j in range(p.shape[0])])
-    return res if partial.ndim == 2 else res[0]
+    from sirius_amd.distributed import all_gather_commitments
+    return all_gather_commitments(side.curve, partial, device=dev)
 
 
 def prove(S, side, dist, world, dev):
