@@ -141,16 +141,60 @@ struct Fp {
     SRS_HD static fe_t neg(const fe_t &a) { return sub(zero(), a); }
     SRS_HD static fe_t dbl(const fe_t &a) { return add(a, a); }
 
-    // Montgomery product a*b/R mod p, CIOS over 32-bit limbs; every step is one
-    // 32x32+64 multiply-add (v_mad_u64_u32) plus a carry add.
-    SRS_HD static fe_t mul(const fe_t &a, const fe_t &b) {
+    // Montgomery product a*b/R mod p.
+    //
+    // Device: finely-integrated product scanning (FIPS).  Column k accumulates sum a_i*b_(k-i) and
+    // sum m_i*p_(k-i) in a 96-bit accumulator; every term is ONE v_mad_u64_u32 whose carry-out
+    // (vcc) is folded into the third limb by ONE v_addc_co_u32 -- 2 half-rate VALU ops per 32x32
+    // product, no zero-extension moves (the C/CIOS form below compiles to 575 instructions, 250
+    // of them v_mov; this form to ~330).  Measured rates: profiles/r01_ubench_gfx950.txt.
+    // Host (and the CPU logic emulator): portable CIOS, identical results.
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (hi:acc) += a * b      acc: 64-bit VGPR pair, hi: 32-bit
+    static __device__ __forceinline__ void mac_vv(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b) {
+        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(acc), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+    }
+    // same with a wave-uniform multiplier (modulus limb) in an SGPR
+    static __device__ __forceinline__ void mac_vs(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b) {
+        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(acc), "+v"(hi) : "v"(a), "s"(b) : "vcc");
+    }
+    static __device__ __forceinline__ fe_t mul(const fe_t &a, const fe_t &b) {
+        uint64_t acc = 0;
+        uint32_t hi = 0;
+        uint32_t m[8];
+        fe_t o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) mac_vv(acc, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+            for (int i = 0; i < k; ++i) mac_vs(acc, hi, m[i], P::p(k - i));
+            m[k] = (uint32_t)acc * P::INV;
+            mac_vs(acc, hi, m[k], P::p(0));                 // low word becomes 0
+            acc = (acc >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+#pragma unroll
+        for (int k = 8; k < 15; ++k) {
+#pragma unroll
+            for (int i = k - 7; i < 8; ++i) mac_vv(acc, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+            for (int i = k - 7; i < 8; ++i) mac_vs(acc, hi, m[i], P::p(k - i));
+            o.v[k - 8] = (uint32_t)acc;
+            acc = (acc >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+        o.v[7] = (uint32_t)acc;                               // result < 2p < 2^255: nothing above
+        return reduce_once(o);
+    }
+#else
+    static inline fe_t mul(const fe_t &a, const fe_t &b) {
         uint32_t t[8];
-#pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = 0;
-#pragma unroll
         for (int i = 0; i < 8; ++i) {
             uint64_t c = 0;
-#pragma unroll
             for (int j = 0; j < 8; ++j) {
                 c += (uint64_t)a.v[j] * b.v[i] + t[j];
                 t[j] = (uint32_t)c;
@@ -160,7 +204,6 @@ struct Fp {
             uint32_t m = t[0] * P::INV;
             uint64_t d = (uint64_t)m * P::p(0) + t[0];
             d >>= 32;
-#pragma unroll
             for (int j = 1; j < 8; ++j) {
                 d += (uint64_t)m * P::p(j) + t[j];
                 t[j - 1] = (uint32_t)d;
@@ -170,10 +213,10 @@ struct Fp {
             t[7] = (uint32_t)d;            // (t + a*b_i + m*p) / 2^32 < 2p < 2^255: no ninth limb
         }
         fe_t o;
-#pragma unroll
         for (int i = 0; i < 8; ++i) o.v[i] = t[i];
         return reduce_once(o);
     }
+#endif
     SRS_HD static fe_t sqr(const fe_t &a) { return mul(a, a); }
 
     SRS_HD static fe_t from_mont(const fe_t &a) {

@@ -15,8 +15,8 @@ constexpr uint32_t SORT_THREADS = 1024;   // one workgroup per CU: 128 KiB LDS h
 constexpr uint32_t SORT_TILE = 16384;     // digits per workgroup
 constexpr uint32_t PLAN_THREADS = 1024;
 constexpr uint32_t ACC_THREADS = 128;
-constexpr uint32_t ACC_L0 = 16;           // gathered mixed adds per level-0 thread
-constexpr uint32_t ACC_L1 = 8;            // full adds per thread on later levels
+constexpr uint32_t ACC_L0_LOG = 4, ACC_L0 = 1u << ACC_L0_LOG;   // gathered mixed adds per level-0 thread
+constexpr uint32_t ACC_L1_LOG = 3, ACC_L1 = 1u << ACC_L1_LOG;   // full adds per thread on later levels
 constexpr uint32_t FINAL_THREADS = 256;   // 4 wavefronts = 4 buckets per workgroup
 constexpr uint32_t FINAL_FANIN = 512;     // worst-case parts per bucket left for the wave-level pass
 constexpr int MAX_LEVELS = 8;

@@ -239,26 +239,55 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
 //   [l] tp(l-1): thread prefix of level l-1 over the previous level's parts
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t *total) {
-    // Hillis-Steele over blockDim.x values; returns exclusive prefix of v, *total = sum
-    uint32_t t = threadIdx.x;
-    lds[t] = v;
-    __syncthreads();
-    for (uint32_t s = 1; s < blockDim.x; s <<= 1) {
-        uint32_t add = (t >= s) ? lds[t - s] : 0;
-        __syncthreads();
-        lds[t] += add;
-        __syncthreads();
+    // wave-level inclusive scan by shuffles, then one wave scans the per-wave totals (<= 16 waves)
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, nwaves = blockDim.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
     }
-    uint32_t incl = lds[t];
-    *total = lds[blockDim.x - 1];
+    if (lane == 63) lds[wave] = x;
     __syncthreads();
-    return incl - v;
+    if (wave == 0) {
+        uint32_t w = lane < nwaves ? lds[lane] : 0;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(w, d, 64);
+            if (lane >= d) w += y;
+        }
+        if (lane < nwaves) lds[lane] = w;      // inclusive prefix of wave totals
+    }
+    __syncthreads();
+    uint32_t base = wave ? lds[wave - 1] : 0;
+    *total = lds[nwaves - 1];
+    __syncthreads();
+    return base + x - v;
 }
 
+__device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t *lds) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        uint32_t y = __shfl_xor(v, d, 64);
+        v = y > v ? y : v;
+    }
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) m = lds[w] > m ? lds[w] : m;
+    __syncthreads();
+    return m;
+}
+
+// plan[level] arrays as described above; the last 4 words of the plan hold
+//   [0] levels_needed : number of thread-sequential levels (>= 1) before the wavefront-level pass --
+//       decided HERE from the actual heaviest bucket, so the common (balanced) case runs level 0 only
+//       and later k_accum1 launches exit immediately.
 __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     k_plan(const uint32_t *__restrict__ count, uint32_t *__restrict__ cursor, uint32_t *__restrict__ plan,
-           size_t plan_stride, int nlevels, uint32_t l0, uint32_t l1) {
-    __shared__ uint32_t lds[PLAN_THREADS];
+           size_t plan_stride, int nlevels, uint32_t l0_log, uint32_t l1_log) {
+    __shared__ uint32_t lds[64];
     constexpr uint32_t PER = NBUCKET / PLAN_THREADS;
     uint32_t m = blockIdx.x;
     const uint32_t *cnt = count + (size_t)m * NBUCKET;
@@ -268,14 +297,38 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     uint32_t base = threadIdx.x * PER;
 #pragma unroll
     for (uint32_t j = 0; j < PER; ++j) vals[j] = cnt[base + j];
-    for (int level = -1; level < nlevels; ++level) {
+    int needed = nlevels;
+    uint32_t total_entries = 0;
+    for (int level = -1; level < needed; ++level) {
         // level -1: scan the raw counts (entry offsets); level >= 0: scan the part counts
         if (level >= 0) {
-            uint32_t L = level == 0 ? l0 : l1;
+            uint32_t lg = level == 0 ? l0_log : l1_log;
+            uint32_t mx = 0;
 #pragma unroll
             for (uint32_t j = 0; j < PER; ++j) {
-                uint32_t p = (vals[j] + L - 1) / L;
+                uint32_t p = (vals[j] + (1u << lg) - 1) >> lg;
                 vals[j] = p ? p : 1u;
+                mx = vals[j] > mx ? vals[j] : mx;
+            }
+            if (level == 0) {
+                // (a) the heaviest bucket must be down to <= FINAL_FANIN parts for the wave-level pass;
+                // (b) the TYPICAL bucket (2x the mean load) must be down to one part: the wave-level pass
+                //     spends a whole wavefront per bucket, so it must find real work only in outliers.
+                uint32_t p = block_max(mx, lds);
+                needed = 1;
+                while (p > FINAL_FANIN && needed < nlevels) {
+                    p = (p + (1u << l1_log) - 1) >> l1_log;
+                    ++needed;
+                }
+                uint32_t typical = (2u * total_entries + NBUCKET - 1) / NBUCKET;
+                uint32_t x = (typical + (1u << l0_log) - 1) >> l0_log;
+                int by_mean = 1;
+                while (x > 1 && by_mean < nlevels) {
+                    x = (x + (1u << l1_log) - 1) >> l1_log;
+                    ++by_mean;
+                }
+                needed = by_mean > needed ? by_mean : needed;
+                if (threadIdx.x == 0) pl[plan_stride - 4] = (uint32_t)needed;
             }
         }
         uint32_t local = 0;
@@ -283,6 +336,7 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
         for (uint32_t j = 0; j < PER; ++j) local += vals[j];
         uint32_t total;
         uint32_t run = block_exclusive_scan(local, lds, &total);
+        if (level < 0) total_entries = total;
         uint32_t *o = pl + (size_t)(level + 1) * (NBUCKET + 1);
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
@@ -342,6 +396,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum1(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
              size_t plan_stride, int level, xyzz_t *__restrict__ out, size_t out_stride, uint32_t l1) {
     uint32_t m = blockIdx.y;
+    if ((uint32_t)level >= plan[(size_t)m * plan_stride + plan_stride - 4]) return;   // level not needed (k_plan)
     const uint32_t *tp_prev = plan + (size_t)m * plan_stride + (size_t)level * (NBUCKET + 1);
     const uint32_t *tp = tp_prev + (NBUCKET + 1);
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -371,9 +426,13 @@ __device__ __forceinline__ xyzz_t shfl_down_point(const xyzz_t &p, unsigned delt
 // shuffle tree; lane 0 stores the bucket.   grid = (NBUCKET / waves_per_block, batch)
 template <class C>
 __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
-    k_accum_final(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
-                  size_t plan_stride, int level, xyzz_t *__restrict__ buckets) {
+    k_accum_final(const xyzz_t *__restrict__ ping, size_t ping_stride, const xyzz_t *__restrict__ pong,
+                  size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride,
+                  xyzz_t *__restrict__ buckets) {
     uint32_t m = blockIdx.y;
+    const uint32_t level = plan[(size_t)m * plan_stride + plan_stride - 4];   // levels actually run
+    const xyzz_t *in = (level & 1u) ? ping : pong;     // level 0 -> ping, level 1 -> pong, ...
+    const size_t in_stride = (level & 1u) ? ping_stride : pong_stride;
     const uint32_t *tp = plan + (size_t)m * plan_stride + (size_t)level * (NBUCKET + 1);
     uint32_t lane = threadIdx.x & 63u;
     uint32_t b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -425,40 +484,38 @@ __global__ void SRS_KERNEL_BOUNDS(RED_ROWS, 1)
     if (t == 0) rc[(size_t)m * (RED_ROWS + RED_COLS) + blockIdx.x] = v[0];
 }
 
-// sum_j j * X_j  (j = 0..n-1)  = sum_{j>=1} Suffix_j ; inclusive suffix scan then tree sum, in LDS.
-// `plus_one`: weights j+1 instead of j (sum of all suffixes incl. Suffix_0).  n == blockDim.x.
+// sum_j j * X_j = sum_{j>=1} Suffix_j with Suffix_j = sum_{i>=j} X_i: an inclusive suffix scan and a
+// tree sum, both log-depth in LDS.  The two weighted sums of the 2-D split run side by side:
+// segment A = v[0,256)  : R_hi, weights hi          (drop Suffix_0)
+// segment B = v[256,512): C_lo (128 real), weights lo+1 (keep Suffix_0)
+// grid = batch, block = RED_ROWS + RED_COLS (384) threads
 template <class C>
-__device__ __forceinline__ xyzz_t lds_weighted_sum(xyzz_t *v, xyzz_t x, bool plus_one) {
-    uint32_t t = threadIdx.x, n = blockDim.x;
-    v[t] = x;
+__global__ void SRS_KERNEL_BOUNDS(RED_ROWS + RED_COLS, 1)
+    k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
+    constexpr uint32_t SEG = RED_ROWS;                 // 256
+    __shared__ xyzz_t v[2 * SEG];
+    uint32_t m = blockIdx.x, t = threadIdx.x;
+    const xyzz_t *R = rc + (size_t)m * (RED_ROWS + RED_COLS);
+    v[t] = R[t];                                        // t < 256: R_t ; 256 <= t < 384: C_(t-256)
+    if (t < SEG - RED_COLS) v[SEG + RED_COLS + t] = Ec<C>::identity();
     __syncthreads();
-    for (uint32_t s = 1; s < n; s <<= 1) {           // suffix scan: v[t] = sum_{i >= t} x_i
-        xyzz_t o = (t + s < n) ? v[t + s] : Ec<C>::identity();
+    const uint32_t seg_end = t < SEG ? SEG : 2 * SEG;
+    for (uint32_t s = 1; s < SEG; s <<= 1) {           // suffix scan inside each segment
+        xyzz_t o = (t + s < seg_end) ? v[t + s] : Ec<C>::identity();
         __syncthreads();
         v[t] = Ec<C>::add(v[t], o);
         __syncthreads();
     }
-    if (!plus_one && t == 0) v[0] = Ec<C>::identity();
+    if (t == 0) v[0] = Ec<C>::identity();
     __syncthreads();
-    lds_tree_sum<C>(v, n);
-    xyzz_t r = v[0];
-    __syncthreads();
-    return r;
-}
-
-// grid = batch, block = RED_ROWS
-template <class C>
-__global__ void SRS_KERNEL_BOUNDS(RED_ROWS, 1)
-    k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
-    __shared__ xyzz_t v[RED_ROWS];
-    uint32_t m = blockIdx.x, t = threadIdx.x;
-    const xyzz_t *R = rc + (size_t)m * (RED_ROWS + RED_COLS);
-    const xyzz_t *Cc = R + RED_ROWS;
-    xyzz_t sr = lds_weighted_sum<C>(v, R[t], false);                                   // sum hi * R_hi
-    xyzz_t sc = lds_weighted_sum<C>(v, t < RED_COLS ? Cc[t] : Ec<C>::identity(), true);   // sum (lo+1) C_lo
+    for (uint32_t s = SEG >> 1; s >= 1; s >>= 1) {     // tree sum inside each segment
+        if ((t & (SEG - 1)) < s) v[t] = Ec<C>::add(v[t], v[t + s]);
+        __syncthreads();
+    }
     if (t == 0) {
+        xyzz_t sr = v[0];
         for (uint32_t k = 1; k < RED_COLS; k <<= 1) sr = Ec<C>::dbl(sr);               // * RED_COLS
-        out[m] = Ec<C>::add(sr, sc);
+        out[m] = Ec<C>::add(sr, v[SEG]);
     }
 }
 
@@ -517,7 +574,7 @@ static int levels_for(uint64_t max_entries) {
 size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     uint64_t M = (uint64_t)n_max * NWIN;
     int levels = levels_for(M);
-    size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1);
+    size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1) + 4;
     uint64_t parts0 = M / ACC_L0 + NBUCKET + 1;
     uint64_t parts1 = parts0 / ACC_L1 + NBUCKET + 1;
     size_t per = 0;
@@ -544,7 +601,7 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     }
     const uint64_t M = (uint64_t)n_max * NWIN;
     const int levels = levels_for(M);
-    const size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1);
+    const size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1) + 4;
     const uint64_t parts0_cap = M / ACC_L0 + NBUCKET + 1;
     const uint64_t parts1_cap = parts0_cap / ACC_L1 + NBUCKET + 1;
 
@@ -574,7 +631,7 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                (const uint32_t *)d_n, count);
     SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
-               levels, (uint32_t)ACC_L0, (uint32_t)ACC_L1);
+               levels, (uint32_t)ACC_L0_LOG, (uint32_t)ACC_L1_LOG);
     SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                (const uint32_t *)d_n, cursor, sorted, (size_t)M, (uint32_t)k.len);
 
@@ -598,10 +655,13 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
         std::swap(cur_stride, nxt_stride);
         // both buffers can hold any later level: parts shrink monotonically and pong >= level-1 cap
     }
+    (void)cur;
+    (void)cur_stride;
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
-               (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, levels, buckets);
+               (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap,
+               (const uint32_t *)plan, plan_stride, buckets);
     SRS_LAUNCH((k_rowcol<C>), (RED_ROWS + RED_COLS, batch), (RED_ROWS), 0, stream, (const xyzz_t *)buckets, rc);
-    SRS_LAUNCH((k_reduce_final<C>), (batch), (RED_ROWS), 0, stream, (const xyzz_t *)rc, d_out);
+    SRS_LAUNCH((k_reduce_final<C>), (batch), (RED_ROWS + RED_COLS), 0, stream, (const xyzz_t *)rc, d_out);
     SRS_HIP_CHECK(hipMemcpyAsync(result_host, d_out, batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
     SRS_HIP_CHECK(hipGetLastError());
