@@ -173,6 +173,51 @@ int srs_fold_witness(int field, srs_fe *out, const srs_fe *w1, const srs_fe *w2,
 int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const *T, size_t n_terms,
                    const srs_fe *r, size_t n, int space, void *stream);
 
+/* ---- ProtoGalaxy NIFS polynomials (src/nifs/protogalaxy/poly/mod.rs), bn256::Fr structures only ----
+ * Leaves f_i = S.gates[i / 2^k] at row(i) (get_evaluate_witness_fn, src/plonk/mod.rs:683-718), i < n =
+ * (gates * 2^k).next_power_of_two(), zero beyond gates * 2^k; pow_i(c) = prod_{b in bits(i)} c_b.
+ * `reference_compat` != 0 reproduces the reference bit for bit INCLUDING its row-index quirk
+ * `row_index = index & total_row` (src/plonk/mod.rs:714), i.e. every leaf is evaluated at row 0;
+ * 0 evaluates the mathematically intended row `index % 2^k`.  Callers that must match the
+ * reference (proof transcripts!) pass 1.
+ * Witnesses W are round-0 vectors (num_advice * 2^k, column-major); `challenges` the trace's challenges. */
+typedef struct {                       /* PolyContext (poly/mod.rs:205-269) */
+    size_t count_of_evaluation_with_padding;
+    size_t betas_count;                /* log2 of the above */
+    size_t fft_points_count_F;         /* (betas_count + 1).next_power_of_two() */
+    size_t fft_points_count_G;         /* (traces_len * max_gate_degree + 1).next_power_of_two() */
+    size_t instances_to_fold;          /* traces_len + 1 */
+    size_t lagrange_domain;            /* log2(instances_to_fold) */
+    uint32_t fft_log_domain_size_K;    /* (points_G + 1 - instances_to_fold).next_power_of_two() -- a count used as a log (:263-268) */
+} srs_pg_context;
+int srs_pg_context_new(const srs_structure *S, size_t traces_len, srs_pg_context *out);
+/* compute_F (:68-203): poly_F[fft_points_count_F] = ifft_X( sum_i pow_i(betas + X*deltas) f_i(w) ), deltas_b = delta^(2^b) */
+int srs_pg_compute_F(srs_structure *S, const srs_fe *betas, size_t n_betas, const srs_fe *delta, const srs_fe *W,
+                     const srs_fe *challenges, size_t n_challenges, int space, int reference_compat, void *stream,
+                     srs_fe *poly_F);
+/* compute_G (:308-425) with FoldedWitness (folded_witness.rs:20-180) fused (never materialised):
+ * poly_G[fft_points_count_G] = ifft_X( sum_i pow_i(betas_stroke) f_i( sum_j L_j(X) w_j ) ); W[0] / challenges[0] = accumulator,
+ * W[1..] = incoming traces; n_instances = L + 1 (a power of two, <= 4). */
+int srs_pg_compute_G(srs_structure *S, const srs_fe *betas_stroke, size_t n_betas, const srs_fe *const *W,
+                     const srs_fe *const *challenges, size_t n_challenges, size_t n_instances, int space,
+                     int reference_compat, void *stream, srs_fe *poly_G);
+/* compute_K_from_G (:475-509): K = (G - F(alpha) L_0) / Z evaluated on ZETA * <w> of size 2^fft_log_domain_size_K, then coset_ifft */
+int srs_pg_compute_K_from_G(const srs_fe *poly_G, size_t n_G, const srs_fe *poly_F_in_alpha, size_t instances_to_fold,
+                            uint32_t fft_log_domain_size_K, void *stream, srs_fe *poly_K);
+/* evaluate_e_from_trace (src/nifs/protogalaxy/mod.rs:571-640): e = sum_i pow_i(betas) f_i(w) */
+int srs_pg_evaluate_e(srs_structure *S, const srs_fe *betas, size_t n_betas, const srs_fe *W, const srs_fe *challenges,
+                      size_t n_challenges, int space, int reference_compat, void *stream, srs_fe *e);
+/* calculate_e (protogalaxy/mod.rs:748-764): F(alpha) * L_0(gamma) + Z(gamma) * K(gamma); host */
+int srs_pg_calculate_e(const srs_fe *poly_F, size_t n_F, const srs_fe *poly_K, size_t n_K, const srs_fe *gamma,
+                       const srs_fe *alpha, uint32_t log_n, srs_fe *out);
+/* iter_eval_lagrange_poly_for_cyclic_group (src/polynomial/lagrange.rs:50-75): out[i] = L_i(X), i < 2^log_n; host */
+int srs_lagrange_eval(const srs_fe *X, uint32_t log_n, srs_fe *out);
+/* UnivariatePoly::eval (src/polynomial/univariate.rs:67-75); host */
+int srs_poly_eval(const srs_fe *coeffs, size_t n, const srs_fe *x, srs_fe *out);
+/* ProtoGalaxy::fold_witness (protogalaxy/mod.rs:176-210): out[i] = sum_{j<J} coefs[j] * W[j][i]  (J <= 4) */
+int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n,
+                     int space, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (CURVE_BN256, CURVE_GRUMPKIN, FIELD_FQ, FIELD_FR, SiriusAmdError)  # noqa: F401
 from .commitment import CommitmentKey, TooLongInput, point_lincomb, point_mul, point_sum  # noqa: F401
 from . import fft  # noqa: F401,E402
-from . import distributed, expression, field, plonk  # noqa: F401,E402
+from . import distributed, expression, field, plonk, protogalaxy  # noqa: F401,E402
 from .plonk import PlonkStructure, RelaxedPlonkWitness, VanillaFS  # noqa: F401,E402
 
 

@@ -56,6 +56,15 @@ def _prototypes():
         "srs_eval_gates": (i32, [vp, i32, vp, vp, sz, i32, vp, vp]),
         "srs_fold_witness": (i32, [i32, vp, vp, vp, vp, sz, i32, vp]),
         "srs_fold_error": (i32, [i32, vp, vp, C.POINTER(vp), sz, vp, sz, i32, vp]),
+        "srs_pg_context_new": (i32, [vp, sz, vp]),
+        "srs_pg_compute_F": (i32, [vp, vp, sz, vp, vp, vp, sz, i32, i32, vp, vp]),
+        "srs_pg_compute_G": (i32, [vp, vp, sz, C.POINTER(vp), C.POINTER(vp), sz, sz, i32, i32, vp, vp]),
+        "srs_pg_compute_K_from_G": (i32, [vp, sz, vp, sz, u32, vp, vp]),
+        "srs_pg_evaluate_e": (i32, [vp, vp, sz, vp, vp, sz, i32, i32, vp, vp]),
+        "srs_pg_calculate_e": (i32, [vp, sz, vp, sz, vp, vp, u32, vp]),
+        "srs_lagrange_eval": (i32, [vp, u32, vp]),
+        "srs_poly_eval": (i32, [vp, sz, vp, vp]),
+        "srs_fold_lincomb": (i32, [i32, vp, C.POINTER(vp), vp, sz, sz, i32, vp]),
         "srs_ntt": (i32, [i32, vp, sz, i32, i32, i32, vp]),
         "srs_ntt_set_max_radix_bits": (i32, [i32]),
         "srs_ntt_batch": (i32, [i32, vp, sz, sz, sz, i32, i32, i32, vp]),

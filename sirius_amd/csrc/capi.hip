@@ -592,4 +592,154 @@ int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const 
     });
 }
 
+// ------------------------------------------------------------------ ProtoGalaxy
+int srs_pg_context_new(const srs_structure *S, size_t traces_len, srs_pg_context *out) {
+    if (!S || !out) return fail(SRS_ERR_INVALID, "srs_pg_context_new: bad argument");
+    if (((traces_len + 1) & traces_len) != 0) return fail(SRS_ERR_INVALID, "instances_to_fold must be a power of two");   // poly/mod.rs:225
+    rowprog::PgSizes z;
+    if (!rowprog::pg_sizes(S->s, traces_len, z)) return fail(SRS_ERR_INVALID, "structure has no gates");
+    out->count_of_evaluation_with_padding = z.count_with_padding;
+    out->betas_count = z.betas_count;
+    out->fft_points_count_F = z.points_F;
+    out->fft_points_count_G = z.points_G;
+    out->instances_to_fold = z.instances_to_fold;
+    out->lagrange_domain = z.lagrange_domain;
+    out->fft_log_domain_size_K = z.log_domain_K;
+    return SRS_OK;
+}
+
+static int pg_impl(srs_structure *S, int mode, const srs_fe *weights, size_t n_weights, const srs_fe *delta, const srs_fe *const *W,
+                   const srs_fe *const *challenges, size_t n_challenges, size_t J, int space, int compat, void *stream, srs_fe *out) {
+    if (!S || !weights || !W || !out || (n_challenges && !challenges)) return fail(SRS_ERR_INVALID, "srs_pg_*: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        rowprog::Structure *s = S->s;
+        const size_t wlen = rowprog::num_advice(s) * rowprog::rows(s);
+        std::vector<const fe_t *> dW(J);
+        if (space == SRS_SPACE_DEVICE) {
+            for (size_t j = 0; j < J; ++j) dW[j] = reinterpret_cast<const fe_t *>(W[j]);
+        } else {
+            S->io.reserve(J * Arena::pad((wlen + 1) * sizeof(fe_t)) + 1024);
+            S->io.reset();
+            for (size_t j = 0; j < J; ++j) {
+                fe_t *d = S->io.take<fe_t>(wlen + 1);
+                SRS_HIP_CHECK(hipMemcpyAsync(d, W[j], wlen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                dW[j] = d;
+            }
+        }
+        std::vector<const fe_t *> ch(J);
+        for (size_t j = 0; j < J; ++j) ch[j] = n_challenges ? reinterpret_cast<const fe_t *>(challenges[j]) : nullptr;
+        std::string err;
+        size_t n_out = 0;
+        int erc = rowprog::pg_sum(s, mode, dW.data(), ch.data(), n_challenges, J, reinterpret_cast<const fe_t *>(weights), n_weights,
+                                  reinterpret_cast<const fe_t *>(delta), compat, st, reinterpret_cast<fe_t *>(out), &n_out, err);
+        if (erc) return fail(erc, "srs_pg: " + err);
+        return SRS_OK;
+    });
+}
+
+int srs_pg_compute_F(srs_structure *S, const srs_fe *betas, size_t n_betas, const srs_fe *delta, const srs_fe *W,
+                     const srs_fe *challenges, size_t n_challenges, int space, int reference_compat, void *stream, srs_fe *poly_F) {
+    if (!delta) return fail(SRS_ERR_INVALID, "srs_pg_compute_F: delta is NULL");
+    const srs_fe *Ws[1] = {W};
+    const srs_fe *chs[1] = {challenges};
+    return pg_impl(S, 0, betas, n_betas, delta, Ws, chs, n_challenges, 1, space, reference_compat, stream, poly_F);
+}
+int srs_pg_compute_G(srs_structure *S, const srs_fe *betas_stroke, size_t n_betas, const srs_fe *const *W,
+                     const srs_fe *const *challenges, size_t n_challenges, size_t n_instances, int space, int reference_compat,
+                     void *stream, srs_fe *poly_G) {
+    if (n_instances < 2) return fail(SRS_ERR_INVALID, "You can't fold 0 traces");                // poly/mod.rs:27
+    if (n_instances & (n_instances - 1)) return fail(SRS_ERR_INVALID, "instances_to_fold must be a power of two");
+    return pg_impl(S, 1, betas_stroke, n_betas, nullptr, W, challenges, n_challenges, n_instances, space, reference_compat, stream, poly_G);
+}
+int srs_pg_evaluate_e(srs_structure *S, const srs_fe *betas, size_t n_betas, const srs_fe *W, const srs_fe *challenges,
+                      size_t n_challenges, int space, int reference_compat, void *stream, srs_fe *e) {
+    const srs_fe *Ws[1] = {W};
+    const srs_fe *chs[1] = {challenges};
+    return pg_impl(S, 2, betas, n_betas, nullptr, Ws, chs, n_challenges, 1, space, reference_compat, stream, e);
+}
+
+int srs_pg_compute_K_from_G(const srs_fe *poly_G, size_t n_G, const srs_fe *poly_F_in_alpha, size_t instances_to_fold,
+                            uint32_t fft_log_domain_size_K, void *stream, srs_fe *poly_K) {
+    if (!poly_G || !poly_F_in_alpha || !poly_K || instances_to_fold == 0) return fail(SRS_ERR_INVALID, "srs_pg_compute_K_from_G: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        fe_t fa;
+        std::memcpy(&fa, poly_F_in_alpha, 32);
+        std::string err;
+        int erc = rowprog::pg_K_from_G(reinterpret_cast<const fe_t *>(poly_G), n_G, fa, instances_to_fold, fft_log_domain_size_K,
+                                       (hipStream_t)stream, reinterpret_cast<fe_t *>(poly_K), err);
+        if (erc) return fail(erc, "srs_pg_compute_K_from_G: " + err);
+        return SRS_OK;
+    });
+}
+
+int srs_lagrange_eval(const srs_fe *X, uint32_t log_n, srs_fe *out) {
+    if (!X || !out || log_n > ntt::FR_S) return fail(SRS_ERR_INVALID, "srs_lagrange_eval: bad argument");
+    fe_t x;
+    std::memcpy(&x, X, 32);
+    std::vector<fe_t> v = rowprog::lagrange_eval(x, log_n);
+    std::memcpy(out, v.data(), v.size() * sizeof(fe_t));
+    return SRS_OK;
+}
+int srs_poly_eval(const srs_fe *coeffs, size_t n, const srs_fe *x, srs_fe *out) {
+    if ((n && !coeffs) || !x || !out) return fail(SRS_ERR_INVALID, "srs_poly_eval: bad argument");
+    fe_t xx;
+    std::memcpy(&xx, x, 32);
+    fe_t r = rowprog::poly_eval(reinterpret_cast<const fe_t *>(coeffs), n, xx);
+    std::memcpy(out, &r, 32);
+    return SRS_OK;
+}
+int srs_pg_calculate_e(const srs_fe *poly_F, size_t n_F, const srs_fe *poly_K, size_t n_K, const srs_fe *gamma,
+                       const srs_fe *alpha, uint32_t log_n, srs_fe *out) {
+    if (!poly_F || !poly_K || !gamma || !alpha || !out) return fail(SRS_ERR_INVALID, "srs_pg_calculate_e: bad argument");
+    fe_t g, a;
+    std::memcpy(&g, gamma, 32);
+    std::memcpy(&a, alpha, 32);
+    fe_t l0 = rowprog::lagrange_eval(g, log_n)[0];
+    fe_t fa = rowprog::poly_eval(reinterpret_cast<const fe_t *>(poly_F), n_F, a);
+    fe_t z = Fr::sub(Fr::pow_u64(g, (uint64_t)1 << log_n), Fr::one());      // eval_vanish_polynomial, lagrange.rs:83-85
+    fe_t kg = rowprog::poly_eval(reinterpret_cast<const fe_t *>(poly_K), n_K, g);
+    fe_t r = Fr::add(Fr::mul(fa, l0), Fr::mul(z, kg));
+    std::memcpy(out, &r, 32);
+    return SRS_OK;
+}
+
+int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n, int space, void *stream) {
+    if (!valid_field(field) || !coefs || !W || (n && !out) || J == 0) return fail(SRS_ERR_INVALID, "srs_fold_lincomb: bad argument");
+    if (n == 0) return SRS_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        std::string err;
+        if (space == SRS_SPACE_DEVICE) {
+            int erc = rowprog::lincomb(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *const *>(W),
+                                       reinterpret_cast<const fe_t *>(coefs), J, n, st, err);
+            if (erc) return fail(erc, "srs_fold_lincomb: " + err);
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            fe_t *buf = nullptr;
+            SRS_HIP_CHECK(hipMalloc((void **)&buf, J * n * sizeof(fe_t)));
+            try {
+                std::vector<const fe_t *> wp(J);
+                for (size_t j = 0; j < J; ++j) {
+                    SRS_HIP_CHECK(hipMemcpyAsync(buf + j * n, W[j], n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                    wp[j] = buf + j * n;
+                }
+                int erc = rowprog::lincomb(field, buf, wp.data(), reinterpret_cast<const fe_t *>(coefs), J, n, st, err);
+                if (erc) { (void)hipFree(buf); return fail(erc, "srs_fold_lincomb: " + err); }
+                SRS_HIP_CHECK(hipMemcpyAsync(out, buf, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipStreamSynchronize(st));
+            } catch (...) { (void)hipFree(buf); throw; }
+            (void)hipFree(buf);
+        }
+        SRS_HIP_CHECK(hipGetLastError());
+        return SRS_OK;
+    });
+}
+
 }  // extern "C"

@@ -239,6 +239,9 @@ static fe_t omega_for(uint32_t k, bool inverse) {      // src/fft.rs:12-23
     return w;
 }
 
+fe_t omega(uint32_t k, bool inverse) { return omega_for(k, inverse); }
+fe_t zeta() { return consts().zeta; }
+
 struct Plan {
     uint32_t log_n = 0;
     bool inverse = false;

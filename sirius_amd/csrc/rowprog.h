@@ -34,6 +34,21 @@ int field(const Structure *S);
 int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host, size_t n_ch,
              fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err);
 
+// ---- ProtoGalaxy (Fr only) ----
+struct PgSizes {   // PolyContext, src/nifs/protogalaxy/poly/mod.rs:205-269
+    size_t count_with_padding = 0, betas_count = 0, points_F = 0, points_G = 0, instances_to_fold = 0, lagrange_domain = 0;
+    uint32_t log_domain_K = 0;
+};
+bool pg_sizes(const Structure *S, size_t traces_len, PgSizes &out);
+std::vector<fe_t> lagrange_eval(const fe_t &X, uint32_t log_n);
+fe_t poly_eval(const fe_t *coeffs, size_t n, const fe_t &x);
+int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
+           const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
+           size_t *n_out, std::string &err);
+int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t instances_to_fold, uint32_t log_domain_K,
+                hipStream_t st, fe_t *out_host, std::string &err);
+int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err);
+
 void fold_w(int field, fe_t *out, const fe_t *w1, const fe_t *w2, const fe_t &r, size_t n, hipStream_t st);
 int fold_e(int field, fe_t *out, const fe_t *e, const fe_t *const *t_dev_ptrs_host, size_t n_terms, const fe_t &r, size_t n,
            hipStream_t st, std::string &err);

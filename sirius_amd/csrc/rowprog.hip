@@ -18,9 +18,12 @@
 // Row registers live in LDS as [slot][thread] (conflict-free 32-byte lanes); the d accumulators
 // T_k live in VGPRs.  Columns are read coalesced (column-major, consecutive rows per lane).
 #include "rowprog.h"
+#include "ntt.h"
 #include "prof.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -36,14 +39,24 @@ constexpr uint32_t UNIFORM_BIT = 0x80000000u;
 constexpr uint32_t RP_THREADS = 128;
 constexpr uint32_t DMAX = 8;   // cross terms kept in VGPRs; larger degrees are rejected at create time
 
+constexpr uint32_t JMAX = 4;   // witnesses combined by one advice load (cross terms: 2; ProtoGalaxy G: L + 1 <= 4)
+
+// everything a row needs besides the program
+struct RowCtx {
+    uint32_t rows;
+    const uint8_t *const *sel;
+    const fe_t *const *fix;
+    const fe_t *W[JMAX];      // column-major [num_advice][rows] each
+    uint32_t J;               // number of witnesses
+    const fe_t *wcoef;        // [npts][J] combination coefficients, or nullptr:
+                              //   J == 1: W[0];  J == 2: W[0] + pt * W[1]  (cross-term points X = pt)
+};
+
 struct DevArgs {
     const Insn *prog;
     uint32_t n_insn;
     uint32_t result;          // operand code of the expression value
-    uint32_t rows, log_rows;
-    const uint8_t *const *sel;
-    const fe_t *const *fix;
-    const fe_t *W1, *W2;      // column-major [num_advice][rows]
+    RowCtx ctx;
     const fe_t *utab;         // [npts][n_uniform]
     uint32_t n_uniform;
     uint32_t npts;            // d + 1 (interpolate) or 1 (plain evaluation)
@@ -66,49 +79,60 @@ __device__ __forceinline__ fe_t small_times(const fe_t &x, uint32_t j) {   // j 
     return acc;
 }
 
+// interpret one row program at evaluation point `pt`; registers = LDS slots [slot][thread]
+template <class F>
+__device__ __forceinline__ fe_t interp(fe_t *slots, const Insn *__restrict__ prog, uint32_t n_insn, uint32_t result,
+                                       const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *__restrict__ U) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x, mask = C.rows - 1;
+    for (uint32_t ip = 0; ip < n_insn; ++ip) {
+        const Insn in = prog[ip];
+        fe_t r;
+        if (in.op <= I_LD_ADV) {
+            uint32_t rr = (row + (uint32_t)(int32_t)in.b) & mask;     // (row + rot) rem_euclid 2^k
+            if (in.op == I_LD_SEL) {
+                r = C.sel[in.a][rr] ? F::one() : F::zero();
+            } else if (in.op == I_LD_FIX) {
+                r = C.fix[in.a][rr];
+            } else {
+                size_t idx = (size_t)in.a * C.rows + rr;
+                if (C.wcoef == nullptr) {
+                    r = C.W[0][idx];
+                    if (C.J == 2 && pt) r = F::add(r, small_times<F>(C.W[1][idx], pt));
+                } else {
+                    const fe_t *cf = C.wcoef + (size_t)pt * C.J;
+                    r = F::mul(cf[0], C.W[0][idx]);
+                    for (uint32_t j = 1; j < C.J; ++j) r = F::add(r, F::mul(cf[j], C.W[j][idx]));
+                }
+            }
+        } else {
+            fe_t a = (in.a & UNIFORM_BIT) ? U[in.a & ~UNIFORM_BIT] : slots[in.a * nthr + tid];
+            if (in.op <= I_MUL) {
+                fe_t b = (in.b & UNIFORM_BIT) ? U[in.b & ~UNIFORM_BIT] : slots[in.b * nthr + tid];
+                r = in.op == I_ADD ? F::add(a, b) : (in.op == I_SUB ? F::sub(a, b) : F::mul(a, b));
+            } else if (in.op == I_SQR) {
+                r = F::sqr(a);
+            } else if (in.op == I_DBL) {
+                r = F::dbl(a);
+            } else {
+                r = F::neg(a);
+            }
+        }
+        slots[in.dst * nthr + tid] = r;
+    }
+    return (result & UNIFORM_BIT) ? U[result & ~UNIFORM_BIT] : slots[result * nthr + tid];
+}
+
 template <class F, uint32_t NSLOT>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
     __shared__ fe_t slots[NSLOT * RP_THREADS];
-    const uint32_t tid = threadIdx.x;
-    uint32_t row = blockIdx.x * RP_THREADS + tid;
-    const bool live = row < A.rows;
-    if (!live) row = A.rows - 1;
-    const uint32_t mask = A.rows - 1;
+    uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
+    const bool live = row < A.ctx.rows;
+    if (!live) row = A.ctx.rows - 1;
     fe_t T[DMAX];
 #pragma unroll
     for (uint32_t k = 0; k < DMAX; ++k) T[k] = F::zero();
     for (uint32_t pt = 0; pt < A.npts; ++pt) {
-        const fe_t *U = A.utab + (size_t)pt * A.n_uniform;
-        for (uint32_t ip = 0; ip < A.n_insn; ++ip) {
-            const Insn in = A.prog[ip];
-            fe_t r;
-            if (in.op <= I_LD_ADV) {
-                uint32_t rr = (row + (uint32_t)(int32_t)in.b) & mask;     // (row + rot) rem_euclid 2^k
-                if (in.op == I_LD_SEL) {
-                    r = A.sel[in.a][rr] ? F::one() : F::zero();
-                } else if (in.op == I_LD_FIX) {
-                    r = A.fix[in.a][rr];
-                } else {
-                    size_t idx = (size_t)in.a * A.rows + rr;
-                    r = A.W1[idx];
-                    if (pt) r = F::add(r, small_times<F>(A.W2[idx], pt));
-                }
-            } else {
-                fe_t a = (in.a & UNIFORM_BIT) ? U[in.a & ~UNIFORM_BIT] : slots[in.a * RP_THREADS + tid];
-                if (in.op <= I_MUL) {
-                    fe_t b = (in.b & UNIFORM_BIT) ? U[in.b & ~UNIFORM_BIT] : slots[in.b * RP_THREADS + tid];
-                    r = in.op == I_ADD ? F::add(a, b) : (in.op == I_SUB ? F::sub(a, b) : F::mul(a, b));
-                } else if (in.op == I_SQR) {
-                    r = F::sqr(a);
-                } else if (in.op == I_DBL) {
-                    r = F::dbl(a);
-                } else {
-                    r = F::neg(a);
-                }
-            }
-            slots[in.dst * RP_THREADS + tid] = r;
-        }
-        fe_t P = (A.result & UNIFORM_BIT) ? U[A.result & ~UNIFORM_BIT] : slots[A.result * RP_THREADS + tid];
+        fe_t P = interp<F>(slots, A.prog, A.n_insn, A.result, A.ctx, row, pt, A.utab + (size_t)pt * A.n_uniform);
         if (A.d == 0) {
             if (live) A.out[0][row] = P;
         } else {
@@ -122,6 +146,121 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
 #pragma unroll
         for (uint32_t k = 0; k < DMAX; ++k)
             if (k < A.d) A.out[k][row] = T[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ProtoGalaxy: pow-weighted sums of gate evaluations (reference src/nifs/protogalaxy/poly/mod.rs)
+//   Out[p] = sum_{i < n} pow_i(c^(p)) * f_i^(p),   pow_i(c) = prod_{b in bits(i)} c_b
+//   f_i = gates[i / 2^k] evaluated at row(i)  (get_evaluate_witness_fn, src/plonk/mod.rs:683-718)
+// compute_F : one leaf value, P weight vectors c^(p) = beta + X_p * delta          (:68-203)
+// compute_G : P leaf values (witness folded with L_j(X_p) on the fly -- FoldedWitness is never
+//             materialised), one weight vector beta'                                (:308-425)
+// evaluate_e: P = 1                                                   (protogalaxy/mod.rs:571-640)
+// The reference reduces with a binary tree where the right child is scaled by c_height; the same
+// tree is evaluated here level by level (LDS inside a workgroup, then across workgroups).
+// ---------------------------------------------------------------------------------------------
+struct GateProg {
+    const Insn *prog;
+    uint32_t n_insn, result, n_uniform, utab_off;   // utab_off: offset (in fe) of this gate's table in PgArgs.utab
+};
+struct PgArgs {
+    const GateProg *gates;
+    uint32_t n_gates, log_rows;
+    RowCtx ctx;
+    int compat;               // Q1: row_index = index & 2^k  ==> every leaf is evaluated at row 0
+    uint32_t leaf_pts;        // 1 (F, e) or P (G)
+    uint32_t P;
+    const fe_t *utab;         // per gate: [leaf_pts][n_uniform]
+    const fe_t *weights;      // [levels][wpts]
+    uint32_t wpts;            // P (F) or 1 (G, e)
+    uint32_t tile_log;        // leaves per workgroup = 2^tile_log (<= 7)
+    fe_t *partial;            // [n_gates * tiles_per_gate][P]
+};
+
+// binary-tree combine of blockDim.x values: v[2t] + v[2t+1] * w[level]; result in red[0]
+template <class F>
+__device__ __forceinline__ void weighted_tree(fe_t *red, fe_t x, const fe_t *__restrict__ w, uint32_t wstride, uint32_t levels) {
+    const uint32_t tid = threadIdx.x;
+    red[tid] = x;
+    __syncthreads();
+    for (uint32_t l = 0; l < levels; ++l) {
+        uint32_t stride = 1u << l;
+        if ((tid & (2 * stride - 1)) == 0) red[tid] = F::add(red[tid], F::mul(red[tid + stride], w[(size_t)l * wstride]));
+        __syncthreads();
+    }
+}
+
+// grid = (tiles_per_gate, n_gates), block = 2^tile_log threads
+template <class F, uint32_t NSLOT>
+__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_leaves(PgArgs A) {
+    __shared__ fe_t slots[NSLOT * RP_THREADS];
+    __shared__ fe_t red[RP_THREADS];
+    const uint32_t gate = blockIdx.y, tile = blockIdx.x;
+    const GateProg G = A.gates[gate];
+    const uint32_t row = tile * blockDim.x + threadIdx.x;            // < rows (rows is a multiple of the tile)
+    const uint32_t erow = A.compat ? 0u : row;
+    fe_t v = F::zero();
+    for (uint32_t p = 0; p < A.P; ++p) {
+        if (A.leaf_pts > 1 || p == 0)
+            v = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, erow, p, A.utab + G.utab_off + (size_t)p * G.n_uniform);
+        weighted_tree<F>(red, v, A.weights + (A.wpts > 1 ? p : 0), A.wpts, A.tile_log);
+        if (threadIdx.x == 0) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = red[0];
+        __syncthreads();
+    }
+}
+
+// continues the tree over the per-tile partials: in[m_valid][P] (zero beyond m_valid) -> out[ceil(m / 2^lv)][P]
+// grid = number of output nodes, block = 2^lv threads
+template <class F>
+__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1)
+    k_pg_reduce(const fe_t *__restrict__ in, uint32_t m_valid, uint32_t P, const fe_t *__restrict__ weights, uint32_t wpts,
+                uint32_t level0, uint32_t lv, fe_t *__restrict__ out) {
+    __shared__ fe_t red[RP_THREADS];
+    const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t p = 0; p < P; ++p) {
+        fe_t x = node < m_valid ? in[(size_t)node * P + p] : F::zero();
+        weighted_tree<F>(red, x, weights + (size_t)level0 * wpts + (wpts > 1 ? p : 0), wpts, lv);
+        if (threadIdx.x == 0) out[(size_t)blockIdx.x * P + p] = red[0];
+        __syncthreads();
+    }
+}
+
+// K(X) on the coset (compute_K_from_G, poly/mod.rs:475-509): thread i: X = ZETA * w^i,
+//   K(X) = (G(X) - F(alpha) * L0(X)) / Z(X),  L0(X) = (1/n)(X^n - 1)/(X - 1),  Z(X) = X^n - 1,  n = instances_to_fold
+__global__ void k_pg_K_points(const fe_t *__restrict__ polyG, uint32_t nG, fe_t f_alpha, fe_t zeta, fe_t omega, fe_t inv_n,
+                              uint32_t n_fold, uint32_t count, fe_t *__restrict__ out, int *__restrict__ err) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    fe_t X = Fr::mul(zeta, Fr::pow_u64(omega, i));
+    fe_t g = Fr::zero(), xp = Fr::one();
+    for (uint32_t k = 0; k < nG; ++k) {            // UnivariatePoly::eval (univariate.rs:67-75)
+        g = Fr::add(g, Fr::mul(xp, polyG[k]));
+        xp = Fr::mul(xp, X);
+    }
+    fe_t xn1 = Fr::sub(Fr::pow_u64(X, n_fold), Fr::one());
+    fe_t xm1 = Fr::sub(X, Fr::one());
+    fe_t l0;
+    if (Fr::is_zero(xn1) && Fr::is_zero(xm1)) l0 = Fr::one();   // lagrange.rs:67-69
+    else l0 = Fr::mul(inv_n, Fr::mul(xn1, Fr::inv(xm1)));
+    if (Fr::is_zero(xn1)) { *err = 1; return; }                 // "Z(X) must be not equal to 0"
+    out[i] = Fr::mul(Fr::sub(g, Fr::mul(f_alpha, l0)), Fr::inv(xn1));
+}
+
+// out[i] = sum_j coef[j] * W[j][i]   (ProtoGalaxy::fold_witness, protogalaxy/mod.rs:176-210)
+struct LincombArgs {
+    const fe_t *w[JMAX];
+    fe_t coef[JMAX];
+    uint32_t J;
+};
+template <class F>
+__global__ void k_lincomb(fe_t *__restrict__ out, LincombArgs a, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        fe_t acc = F::mul(a.coef[0], a.w[0][i]);
+        for (uint32_t j = 1; j < a.J; ++j) acc = F::add(acc, F::mul(a.coef[j], a.w[j][i]));
+        out[i] = acc;
     }
 }
 
@@ -344,6 +483,23 @@ static bool homogeneous(Ast &ast, int r, const Ctx &ctx, int &out, size_t &degre
     }
 }
 
+// Expression::degree (src/polynomial/expression.rs:431-447)
+static size_t expr_degree(const Ast &ast, int r, const Ctx &ctx) {
+    const Node &x = ast.n[r];
+    switch (x.kind) {
+    case N_CONST: return 0;
+    case N_POLY: {
+        size_t i = (size_t)x.index;
+        return (i >= ctx.num_selectors + ctx.num_fixed) ? 1 : 0;
+    }
+    case N_CHAL: return 1;
+    case N_NEG:
+    case N_SCALED: return expr_degree(ast, x.a, ctx);
+    case N_SUM: return std::max(expr_degree(ast, x.a, ctx), expr_degree(ast, x.b, ctx));
+    default: return expr_degree(ast, x.a, ctx) + expr_degree(ast, x.b, ctx);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host: compile an expression into (uniform program, row program)
 // ---------------------------------------------------------------------------------------------
@@ -550,6 +706,9 @@ struct Structure {
     Program cross;                 // homogeneous expression, fold mode
     Program plain_compressed;      // compressed expression, single witness (decider, plonk/mod.rs:328)
     Program plain_homogeneous;     // homogeneous expression, single witness (decider, sangria/mod.rs:351)
+    std::vector<Program> gate_progs;   // S.gates one by one (ProtoGalaxy leaves, plonk/mod.rs:697-701)
+    size_t max_gate_degree = 0;    // max_i gates[i].degree()  (get_points_count, poly/mod.rs:535-545)
+    GateProg *d_gate_progs = nullptr;
     std::vector<fe_t> vinv;        // [degree][degree+1]
     // device data
     uint8_t **d_sel_ptrs = nullptr;
@@ -570,6 +729,12 @@ static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx
     p.uops = c.uops;
     allocate(c.vins, c.nvreg, result_vreg, p.insns, p.result, p.nslots);
     if (result_vreg < 0) p.result = result_uniform;
+    if (std::getenv("SRS_DEBUG_ROWPROG")) {
+        int cnt[9] = {0};
+        for (auto &in : p.insns) cnt[in.op]++;
+        std::fprintf(stderr, "rowprog: %zu insns (ld sel/fix/adv %d/%d/%d add %d sub %d mul %d sqr %d dbl %d neg %d), %u slots, %zu uniforms\n",
+                     p.insns.size(), cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], p.nslots, p.uops.size());
+    }
     return true;
 }
 
@@ -639,11 +804,17 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         return nullptr;
     }
     if (degree) S->vinv = inverse_vandermonde(f, degree);
+    S->gate_progs.resize(roots.size());
+    for (size_t g = 0; g < roots.size(); ++g) {
+        if (!build_program(ast, roots[g], f, ctx, false, S->gate_progs[g], err)) { rc = 7; return nullptr; }
+        S->max_gate_degree = std::max(S->max_gate_degree, expr_degree(ast, roots[g], ctx));
+    }
     // ---- device residency: programs, fixed columns, selectors
     rc = 5;
     upload_program(S->cross, *S);
     upload_program(S->plain_compressed, *S);
     upload_program(S->plain_homogeneous, *S);
+    for (auto &gp : S->gate_progs) upload_program(gp, *S);
     if (!S->vinv.empty()) {
         SRS_HIP_CHECK(hipMalloc((void **)&S->d_vinv, S->vinv.size() * sizeof(fe_t)));
         S->owned.push_back(S->d_vinv);
@@ -715,8 +886,10 @@ static bool eval_uniform(const Program &p, const FieldOps &f, const fe_t *ch, si
 
 template <class F>
 static void launch_rowprog(const DevArgs &A, uint32_t nslots, hipStream_t st) {
-    uint32_t blocks = (A.rows + RP_THREADS - 1) / RP_THREADS;
+    uint32_t blocks = (A.ctx.rows + RP_THREADS - 1) / RP_THREADS;
     if (nslots <= 8) SRS_LAUNCH((k_rowprog<F, 8>), (blocks), (RP_THREADS), 0, st, A);
+    else if (nslots <= 10) SRS_LAUNCH((k_rowprog<F, 10>), (blocks), (RP_THREADS), 0, st, A);
+    else if (nslots <= 12) SRS_LAUNCH((k_rowprog<F, 12>), (blocks), (RP_THREADS), 0, st, A);
     else if (nslots <= 16) SRS_LAUNCH((k_rowprog<F, 16>), (blocks), (RP_THREADS), 0, st, A);
     else if (nslots <= 24) SRS_LAUNCH((k_rowprog<F, 24>), (blocks), (RP_THREADS), 0, st, A);
     else SRS_LAUNCH((k_rowprog<F, 32>), (blocks), (RP_THREADS), 0, st, A);
@@ -748,12 +921,14 @@ int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, con
     a.prog = p.d_insns;
     a.n_insn = (uint32_t)p.insns.size();
     a.result = p.result;
-    a.rows = (uint32_t)S->rows;
-    a.log_rows = S->k;
-    a.sel = S->d_sel_ptrs;
-    a.fix = S->d_fix_ptrs;
-    a.W1 = W1_dev;
-    a.W2 = W2_dev ? W2_dev : W1_dev;
+    a.ctx.rows = (uint32_t)S->rows;
+    a.ctx.sel = S->d_sel_ptrs;
+    a.ctx.fix = S->d_fix_ptrs;
+    for (uint32_t j = 0; j < JMAX; ++j) a.ctx.W[j] = nullptr;
+    a.ctx.W[0] = W1_dev;
+    a.ctx.W[1] = W2_dev;
+    a.ctx.J = mode == 0 ? 2 : 1;
+    a.ctx.wcoef = nullptr;
     a.utab = d_utab;
     a.n_uniform = (uint32_t)nu;
     a.npts = npts;
@@ -793,6 +968,241 @@ int fold_e(int field, fe_t *out, const fe_t *e, const fe_t *const *t_dev_ptrs_ho
     uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, 256 * 16);
     if (field == 0) SRS_LAUNCH((k_fold_e<Fr>), (blocks), (256), 0, st, out, e, fa, n);
     else SRS_LAUNCH((k_fold_e<Fq>), (blocks), (256), 0, st, out, e, fa, n);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ProtoGalaxy host side
+// ---------------------------------------------------------------------------------------------
+static size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+static uint32_t ilog2(size_t v) { uint32_t l = 0; while (((size_t)1 << (l + 1)) <= v) ++l; return l; }
+
+// PolyContext (src/nifs/protogalaxy/poly/mod.rs:205-269)
+bool pg_sizes(const Structure *S, size_t traces_len, PgSizes &o) {
+    size_t count = S->rows * S->gate_progs.size();           // get_count_of_valuation :511-516
+    if (count == 0) return false;
+    o.count_with_padding = next_pow2(count);                   // :518-533
+    o.betas_count = ilog2(o.count_with_padding);               // :237-239
+    o.points_F = next_pow2(o.betas_count + 1);                 // :241-243
+    o.instances_to_fold = traces_len + 1;
+    o.points_G = next_pow2(traces_len * S->max_gate_degree + 1);   // get_points_count :535-545
+    o.lagrange_domain = ilog2(o.instances_to_fold);            // :253-255
+    // Q2: fft_log_domain_size_K returns a COUNT that is then used as a LOG (:263-268, :481)
+    size_t c = o.points_G + 1;
+    c = c > o.instances_to_fold ? c - o.instances_to_fold : 0;
+    o.log_domain_K = (uint32_t)next_pow2(c);
+    return true;
+}
+
+// iter_eval_lagrange_poly_for_cyclic_group (src/polynomial/lagrange.rs:50-75), Fr, host
+std::vector<fe_t> lagrange_eval(const fe_t &X, uint32_t log_n) {
+    const size_t n = (size_t)1 << log_n;
+    fe_t inv_n = Fr::inv(Fr::from_u64(n));
+    fe_t w = ntt::omega(log_n, false);
+    fe_t xn1 = Fr::sub(Fr::pow_u64(X, n), Fr::one());
+    std::vector<fe_t> out(n);
+    fe_t value = Fr::one();
+    for (size_t i = 0; i < n; ++i) {
+        fe_t d = Fr::sub(X, value);
+        if (Fr::is_zero(xn1) && Fr::is_zero(d)) out[i] = Fr::one();
+        else out[i] = Fr::mul(Fr::mul(value, inv_n), Fr::mul(xn1, Fr::inv(d)));
+        value = Fr::mul(value, w);
+    }
+    return out;
+}
+
+fe_t poly_eval(const fe_t *c, size_t n, const fe_t &x) {       // UnivariatePoly::eval (univariate.rs:67-75)
+    fe_t acc = Fr::zero(), xp = Fr::one();
+    for (size_t i = 0; i < n; ++i) {
+        acc = Fr::add(acc, Fr::mul(xp, c[i]));
+        xp = Fr::mul(xp, x);
+    }
+    return acc;
+}
+
+template <uint32_t NS>
+static void launch_pg_leaves(const PgArgs &A, uint32_t tiles, uint32_t gates, uint32_t threads, hipStream_t st) {
+    SRS_LAUNCH((k_pg_leaves<Fr, NS>), (tiles, gates), (threads), 0, st, A);
+}
+
+// mode 0: compute_F, 1: compute_G, 2: evaluate_e.  W_dev: J device witness pointers (J = 1 for F / e).
+// challenges_host: J arrays of n_ch challenges.  weights_in: betas (F, e) / betas_stroke (G), betas_count values.
+// out_host: points_F / points_G coefficients (after ifft) or the single value e.
+int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
+           const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
+           size_t *n_out, std::string &err) {
+    if (S->field != 0) { err = "ProtoGalaxy polynomials need the 2-adic field bn256::Fr"; return 4; }
+    if (J == 0 || J > JMAX) { err = "unsupported number of traces"; return 4; }
+    PgSizes sz;
+    if (!pg_sizes(S, mode == 1 ? J - 1 : 1, sz)) { *n_out = 0; return 0; }
+    if (n_weights < sz.betas_count) { err = "not enough betas"; return 4; }
+    FieldOps f{0};
+    const uint32_t P = mode == 0 ? (uint32_t)sz.points_F : (mode == 1 ? (uint32_t)sz.points_G : 1u);
+    const uint32_t leaf_pts = mode == 1 ? P : 1u;
+    const uint32_t wpts = mode == 0 ? P : 1u;
+    const uint32_t levels = (uint32_t)sz.betas_count;
+    const uint32_t n_gates = (uint32_t)S->gate_progs.size();
+    // ---- weights [levels][wpts]
+    std::vector<fe_t> weights((size_t)levels * wpts);
+    std::vector<fe_t> pts;                                     // evaluation points X_p (F: w_t'^p ; G: w_G^p)
+    if (mode != 2) {
+        fe_t w = ntt::omega(ilog2(P), false), x = Fr::one();
+        for (uint32_t p = 0; p < P; ++p) { pts.push_back(x); x = Fr::mul(x, w); }     // iter_cyclic_subgroup
+    }
+    if (mode == 0) {
+        fe_t d = *delta;                                       // deltas: delta^(2^b)  (:97-99)
+        for (uint32_t b = 0; b < levels; ++b) {
+            for (uint32_t p = 0; p < P; ++p) weights[(size_t)b * P + p] = Fr::add(weights_in[b], Fr::mul(pts[p], d));   // :102-111
+            d = Fr::sqr(d);
+        }
+    } else {
+        for (uint32_t b = 0; b < levels; ++b) weights[b] = weights_in[b];
+    }
+    // ---- witness combination coefficients and per-point challenges
+    std::vector<fe_t> wcoef;                                   // [P][J] = L_j(X_p)   (FoldedWitness::new, folded_witness.rs:20-47)
+    std::vector<std::vector<fe_t>> ch_pt(leaf_pts, std::vector<fe_t>(n_ch ? n_ch : 1, Fr::zero()));
+    if (mode == 1) {
+        wcoef.resize((size_t)P * J);
+        for (uint32_t p = 0; p < P; ++p) {
+            std::vector<fe_t> L = lagrange_eval(pts[p], (uint32_t)sz.lagrange_domain);
+            for (size_t j = 0; j < J; ++j) {
+                wcoef[(size_t)p * J + j] = L[j];
+                for (size_t c = 0; c < n_ch; ++c)             // fold_plonk_challenges :142-180
+                    ch_pt[p][c] = Fr::add(ch_pt[p][c], Fr::mul(challenges_host[j][c], L[j]));
+            }
+        }
+    } else {
+        for (size_t c = 0; c < n_ch; ++c) ch_pt[0][c] = challenges_host[0][c];
+    }
+    // ---- uniform tables per gate / leaf point
+    uint32_t max_slots = 1;
+    std::vector<GateProg> gp(n_gates);
+    std::vector<fe_t> utab;
+    for (uint32_t g = 0; g < n_gates; ++g) {
+        Program &p = S->gate_progs[g];
+        max_slots = std::max(max_slots, p.nslots);
+        const size_t nu = p.uops.size() ? p.uops.size() : 1;
+        gp[g].prog = p.d_insns;
+        gp[g].n_insn = (uint32_t)p.insns.size();
+        gp[g].result = p.result;
+        gp[g].n_uniform = (uint32_t)nu;
+        gp[g].utab_off = (uint32_t)utab.size();
+        utab.resize(utab.size() + nu * leaf_pts);
+        for (uint32_t lp = 0; lp < leaf_pts; ++lp)
+            if (!eval_uniform(p, f, ch_pt[lp].data(), n_ch, 0, false, 0, utab.data() + gp[g].utab_off + (size_t)lp * nu, err)) return 7;
+    }
+    if (max_slots > 32) { err = "row program needs more than 32 live registers"; return 4; }
+    const uint32_t tile_log = std::min<uint32_t>(7, S->k);
+    const uint32_t tile = 1u << tile_log, tiles_per_gate = (uint32_t)(S->rows >> tile_log);
+    const size_t n_tiles_valid = (size_t)n_gates * tiles_per_gate;
+    const size_t n_tiles_padded = sz.count_with_padding >> tile_log;
+    // ---- device staging
+    Arena &A = S->arena;
+    size_t need = Arena::pad(weights.size() * sizeof(fe_t)) + Arena::pad((wcoef.size() + 1) * sizeof(fe_t)) +
+                  Arena::pad((utab.size() + 1) * sizeof(fe_t)) + Arena::pad(gp.size() * sizeof(GateProg)) +
+                  2 * Arena::pad((n_tiles_padded + 1) * P * sizeof(fe_t)) + Arena::pad(sizeof(fe_t) * P) + 4096;
+    A.reserve(need);
+    A.reset();
+    fe_t *d_w = A.take<fe_t>(weights.size());
+    fe_t *d_coef = A.take<fe_t>(wcoef.size() + 1);
+    fe_t *d_utab = A.take<fe_t>(utab.size() + 1);
+    GateProg *d_gp = A.take<GateProg>(gp.size());
+    fe_t *buf0 = A.take<fe_t>((n_tiles_padded + 1) * P);
+    fe_t *buf1 = A.take<fe_t>((n_tiles_padded + 1) * P);
+    SRS_HIP_CHECK(hipMemcpyAsync(d_w, weights.data(), weights.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    if (!wcoef.empty()) SRS_HIP_CHECK(hipMemcpyAsync(d_coef, wcoef.data(), wcoef.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    SRS_HIP_CHECK(hipMemcpyAsync(d_utab, utab.data(), utab.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    SRS_HIP_CHECK(hipMemcpyAsync(d_gp, gp.data(), gp.size() * sizeof(GateProg), hipMemcpyHostToDevice, st));
+    PgArgs a;
+    a.gates = d_gp;
+    a.n_gates = n_gates;
+    a.log_rows = S->k;
+    a.ctx.rows = (uint32_t)S->rows;
+    a.ctx.sel = S->d_sel_ptrs;
+    a.ctx.fix = S->d_fix_ptrs;
+    for (uint32_t j = 0; j < JMAX; ++j) a.ctx.W[j] = j < J ? W_dev[j] : nullptr;
+    a.ctx.J = (uint32_t)(mode == 1 ? J : 1);
+    a.ctx.wcoef = mode == 1 ? d_coef : nullptr;
+    a.compat = compat;
+    a.leaf_pts = leaf_pts;
+    a.P = P;
+    a.utab = d_utab;
+    a.weights = d_w;
+    a.wpts = wpts;
+    a.tile_log = tile_log;
+    a.partial = buf0;
+    {
+        prof::Scope ps(mode == 0 ? "pg_F_leaves" : (mode == 1 ? "pg_G_leaves" : "pg_e_leaves"), st, S->rows * n_gates);
+        if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, st);
+        else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, st);
+        else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, st);
+        else launch_pg_leaves<32>(a, tiles_per_gate, n_gates, tile, st);
+    }
+    // ---- upper levels of the tree over the tile partials (zero padding beyond the real gates)
+    size_t m_valid = n_tiles_valid, m = n_tiles_padded;
+    uint32_t level0 = tile_log;
+    fe_t *cur = buf0, *nxt = buf1;
+    while (m > 1) {
+        uint32_t lv = std::min<uint32_t>(7, ilog2(m));
+        uint32_t outs = (uint32_t)(m >> lv);
+        SRS_LAUNCH((k_pg_reduce<Fr>), (outs), (1u << lv), 0, st, (const fe_t *)cur, (uint32_t)m_valid, P, (const fe_t *)d_w, wpts,
+                   level0, lv, nxt);
+        level0 += lv;
+        m = outs;
+        m_valid = outs;
+        std::swap(cur, nxt);
+    }
+    if (mode != 2 && P > 1) ntt::run(cur, ilog2(P), P, 1, true, false, st);      // fft::ifft(&mut points)  (:197, :419)
+    SRS_HIP_CHECK(hipMemcpyAsync(out_host, cur, (size_t)P * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+    SRS_HIP_CHECK(hipStreamSynchronize(st));
+    SRS_HIP_CHECK(hipGetLastError());
+    prof::collect();
+    *n_out = P;
+    return 0;
+}
+
+// compute_K_from_G (src/nifs/protogalaxy/poly/mod.rs:475-509)
+int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t instances_to_fold, uint32_t log_domain_K,
+                hipStream_t st, fe_t *out_host, std::string &err) {
+    if (log_domain_K > ntt::FR_S) { err = "k=" + std::to_string(log_domain_K) + " should no larger than F::S=28"; return 3; }   // fft.rs:13
+    const size_t count = (size_t)1 << log_domain_K;
+    fe_t *d_g = nullptr, *d_out = nullptr;
+    int *d_err = nullptr;
+    SRS_HIP_CHECK(hipMalloc((void **)&d_g, (nG + 1) * sizeof(fe_t)));
+    SRS_HIP_CHECK(hipMalloc((void **)&d_out, count * sizeof(fe_t)));
+    SRS_HIP_CHECK(hipMalloc((void **)&d_err, sizeof(int)));
+    int herr = 0;
+    try {
+        SRS_HIP_CHECK(hipMemcpyAsync(d_g, polyG_host, nG * sizeof(fe_t), hipMemcpyHostToDevice, st));
+        SRS_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int), st));
+        fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
+        SRS_LAUNCH(k_pg_K_points, ((uint32_t)((count + 63) / 64)), (64), 0, st, (const fe_t *)d_g, (uint32_t)nG, f_alpha,
+                   ntt::zeta(), ntt::omega(log_domain_K, false), inv_n, (uint32_t)instances_to_fold, (uint32_t)count, d_out, d_err);
+        ntt::run(d_out, log_domain_K, count, 1, true, true, st);     // UnivariatePoly::coset_ifft
+        SRS_HIP_CHECK(hipMemcpyAsync(out_host, d_out, count * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+        SRS_HIP_CHECK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+        SRS_HIP_CHECK(hipStreamSynchronize(st));
+    } catch (...) {
+        (void)hipFree(d_g); (void)hipFree(d_out); (void)hipFree(d_err);
+        throw;
+    }
+    (void)hipFree(d_g); (void)hipFree(d_out); (void)hipFree(d_err);
+    if (herr) { err = "Z(X) must be not equal to 0"; return 4; }
+    return 0;
+}
+
+int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err) {
+    if (J == 0 || J > JMAX) { err = "unsupported number of witnesses"; return 4; }
+    if (!n) return 0;
+    LincombArgs a;
+    a.J = (uint32_t)J;
+    for (uint32_t j = 0; j < JMAX; ++j) {
+        a.w[j] = j < J ? w_dev[j] : nullptr;
+        a.coef[j] = j < J ? coefs[j] : Fr::zero();
+    }
+    uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, 256 * 16);
+    if (field == 0) SRS_LAUNCH((k_lincomb<Fr>), (blocks), (256), 0, st, out, a, n);
+    else SRS_LAUNCH((k_lincomb<Fq>), (blocks), (256), 0, st, out, a, n);
     return 0;
 }
 

@@ -1,0 +1,57 @@
+"""Shared ProtoGalaxy parity case (product vs the oracle's literal restatement)."""
+import random
+
+import numpy as np
+
+
+def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
+    from oracle import expr as OE
+    from oracle import protogalaxy as OPG
+    from oracle import pyref as P
+    from sirius_amd import protogalaxy as PG
+    from workloads import gates_for, rand_fe
+    rnd = random.Random(seed)
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(gate_T)
+    og, fo, ao = [], 0, 0
+    for T in gate_T:
+        og.append(OE.main_gate_expression(T, 0, fo, ao, nfix)); fo += 2 * T + 5; ao += T + 2
+    rng = np.random.default_rng(k * 7 + len(gate_T) + seed)
+    fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
+    Ws = [rand_fe(rng, nadv * rows) for _ in range(L_traces + 1)]
+    St = S.PlonkStructure(0, k, [], fixed, nadv, gates)
+    ctx = PG.PolyContext(St, L_traces)
+    oS = OPG.Structure(O, og, k, [], fixed, nadv, 0)
+    octx = oS.context(L_traces)
+    # PolyContext sizes incl. Q2 (K "log" domain)  -- poly/mod.rs:205-269
+    assert (ctx.count_of_evaluation_with_padding, ctx.betas_count, ctx.fft_points_count_F, ctx.fft_points_count_G,
+            ctx.fft_log_domain_size_K, ctx.lagrange_domain) == \
+        (octx.count_with_padding, octx.betas_count(), octx.fft_points_count_F(), octx.fft_points_count_G,
+         octx.fft_log_domain_size_K(), octx.lagrange_domain())
+    t = ctx.betas_count
+    beta = rnd.randrange(P.FR)
+    betas = OPG.new_accumulator_betas(beta, t)                 # Q3
+    delta, alpha, gamma = (rnd.randrange(P.FR) for _ in range(3))
+    m = lambda v: O.ints_to_mont(O.FR, list(v))
+    pF = PG.compute_F(ctx, m(betas), m([delta])[0], Ws[0], reference_compat=compat)
+    eF = OPG.compute_F(oS, octx, betas, delta, Ws[0], [], compat)
+    assert O.mont_to_ints(O.FR, pF) == eF, "compute_F"
+    bs = OPG.beta_stroke(betas, alpha, delta)
+    pG = PG.compute_G(ctx, m(bs), Ws, reference_compat=compat)
+    eG = OPG.compute_G(oS, octx, bs, Ws, [[] for _ in Ws], compat)
+    assert O.mont_to_ints(O.FR, pG) == eG, "compute_G"
+    Fa = OPG.poly_eval(eF, alpha)
+    assert O.mont_to_ints(O.FR, PG.poly_eval(pF, m([alpha])[0])) == [Fa]
+    if octx.fft_log_domain_size_K() <= 8:
+        pK = PG.compute_K_from_G(ctx, pG, m([Fa])[0])
+        eK = OPG.compute_K_from_G(octx, eG, Fa)
+        assert O.mont_to_ints(O.FR, pK) == eK, "compute_K_from_G"
+        got = PG.calculate_e(pF, pK, m([gamma])[0], m([alpha])[0], ctx.lagrange_domain)
+        assert O.mont_to_ints(O.FR, got) == [OPG.calculate_e(eF, eK, gamma, alpha, octx.lagrange_domain())]
+    pe = PG.evaluate_e_from_trace(ctx, m(betas), Ws[0], reference_compat=compat)
+    assert O.mont_to_ints(O.FR, pe) == [OPG.evaluate_e_from_trace(oS, octx, betas, Ws[0], [], compat)], "evaluate_e"
+    Lg = P.eval_lagrange_poly_for_cyclic_group(gamma, octx.lagrange_domain())
+    assert O.mont_to_ints(O.FR, PG.eval_lagrange_poly_for_cyclic_group(m([gamma])[0], ctx.lagrange_domain)) == Lg
+    assert np.array_equal(PG.fold_witness(0, Ws, m(Lg)), OPG.fold_witness(O, Ws, Lg)), "fold_witness"
+    St.close()
+    return ctx

@@ -12,7 +12,7 @@ from conftest import ROOT
 def _declared():
     text = open(os.path.join(ROOT, "include", "sirius_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(srs_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(srs_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -71,3 +71,11 @@ def test_emu_cross_terms(emu, oracle):
         acc = emu.RelaxedPlonkWitness(field, [W1], E).fold([W2], terms, r)
         assert np.array_equal(acc.W[0], O.fold_w(field, W1, W2, r)) and np.array_equal(acc.E, O.fold_e(field, E, exp, r))
         S.close()
+
+
+def test_emu_protogalaxy(emu, oracle):
+    from pg_cases import run_pg_case
+    run_pg_case(emu, oracle, 4, [2], 1, True)
+    run_pg_case(emu, oracle, 3, [5, 3, 2], 1, False)
+    run_pg_case(emu, oracle, 8, [5, 3], 1, True)
+    run_pg_case(emu, oracle, 4, [2], 3, False)
