@@ -34,10 +34,9 @@ def test_lagrange_kats(srs, oracle):
 
 def test_cyclefold_shape_k17_properties(srs, oracle):
     """CycleFold-shaped primary structure at k = 17 (2 gates -> n = 2^18 leaves): size-independent checks.
-    compat mode: every leaf equals gate_j(row 0), so F(X) has the closed form  sum_j g_j * prod-structure;
-    we check (a) poly_F evaluated at the FFT points equals the direct weighted sum computed from the two
-    row-0 gate values, (b) G(w^0) point consistency: G evaluated at X=1 folds to the accumulator alone,
-    so it must equal evaluate_e with betas_stroke."""
+    (a) F(0) = sum_i pow_i(beta) f_i = evaluate_e(betas);  (b) G(1) = sum of G's coefficients: at X = w^0 = 1
+    the folded witness is the accumulator alone (L_0(1) = 1, L_1(1) = 0), so G(1) = evaluate_e(betas_stroke);
+    both in reference-compat mode and with true per-row leaves (which must differ from each other)."""
     import torch
     from oracle import pyref as P
     from sirius_amd import protogalaxy as PG
@@ -56,9 +55,6 @@ def test_cyclefold_shape_k17_properties(srs, oracle):
     delta, alpha = rnd.randrange(P.FR), rnd.randrange(P.FR)
     m = lambda v: O.ints_to_mont(O.FR, list(v))
     pF = O.mont_to_ints(O.FR, PG.compute_F(ctx, m(betas), m([delta])[0], W0))
-    # (a) closed form in compat mode: leaves of gate j all equal g_j (row 0)
-    g = [O.mont_to_ints(O.FR, S.eval_gates(W0, np.zeros((0, 4), np.uint64)))[0]]   # compressed gate is not per-gate; use F at beta-only instead
-    del g
     # evaluate_e with betas_stroke == G at X = w^0 = 1 (L_0(1) = 1, L_1(1) = 0)
     bs = [(b + alpha * pow(delta, 1 << i, P.FR)) % P.FR for i, b in enumerate(betas)]
     pG = O.mont_to_ints(O.FR, PG.compute_G(ctx, m(bs), [W0, W1]))
