@@ -37,12 +37,12 @@ def build(force=False, verbose=False):
         s_inc = os.path.join(snap, "include")
         os.makedirs(s_csrc)
         os.makedirs(s_inc)
-        for f in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cuh")):
+        for f in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.inc")):
             shutil.copy2(f, s_csrc)
         for f in glob.glob(os.path.join(INCLUDE, "*.h")):
             shutil.copy2(f, s_inc)
         srcs = sorted(glob.glob(os.path.join(s_csrc, "*.hip")))
-        hdrs = glob.glob(os.path.join(s_csrc, "*.h")) + glob.glob(os.path.join(s_csrc, "*.cuh")) + glob.glob(os.path.join(s_inc, "*.h"))
+        hdrs = glob.glob(os.path.join(s_csrc, "*.h")) + glob.glob(os.path.join(s_csrc, "*.cuh")) + glob.glob(os.path.join(s_csrc, "*.inc")) + glob.glob(os.path.join(s_inc, "*.h"))
         objs, jobs = [], []
         for s in srcs:
             name = os.path.basename(s)[:-4]

@@ -141,7 +141,8 @@ struct Fp {
     SRS_HD static fe_t neg(const fe_t &a) { return sub(zero(), a); }
     SRS_HD static fe_t dbl(const fe_t &a) { return add(a, a); }
 
-    // Montgomery product a*b/R mod p.
+    // Montgomery product a*b/R mod p.  (device body generated by tools/gen_field_fips.py: one asm
+    // statement per column, because hipcc pads every asm statement with an s_nop)
     //
     // Device: finely-integrated product scanning (FIPS).  Column k accumulates sum a_i*b_(k-i) and
     // sum m_i*p_(k-i) in a 96-bit accumulator; every term is ONE v_mad_u64_u32 whose carry-out
@@ -161,33 +162,7 @@ struct Fp {
             : "+v"(acc), "+v"(hi) : "v"(a), "s"(b) : "vcc");
     }
     static __device__ __forceinline__ fe_t mul(const fe_t &a, const fe_t &b) {
-        uint64_t acc = 0;
-        uint32_t hi = 0;
-        uint32_t m[8];
-        fe_t o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-            for (int i = 0; i <= k; ++i) mac_vv(acc, hi, a.v[i], b.v[k - i]);
-#pragma unroll
-            for (int i = 0; i < k; ++i) mac_vs(acc, hi, m[i], P::p(k - i));
-            m[k] = (uint32_t)acc * P::INV;
-            mac_vs(acc, hi, m[k], P::p(0));                 // low word becomes 0
-            acc = (acc >> 32) | ((uint64_t)hi << 32);
-            hi = 0;
-        }
-#pragma unroll
-        for (int k = 8; k < 15; ++k) {
-#pragma unroll
-            for (int i = k - 7; i < 8; ++i) mac_vv(acc, hi, a.v[i], b.v[k - i]);
-#pragma unroll
-            for (int i = k - 7; i < 8; ++i) mac_vs(acc, hi, m[i], P::p(k - i));
-            o.v[k - 8] = (uint32_t)acc;
-            acc = (acc >> 32) | ((uint64_t)hi << 32);
-            hi = 0;
-        }
-        o.v[7] = (uint32_t)acc;                               // result < 2p < 2^255: nothing above
-        return reduce_once(o);
+#include "field_fips.inc"
     }
 #else
     static inline fe_t mul(const fe_t &a, const fe_t &b) {

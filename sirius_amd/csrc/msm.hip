@@ -465,58 +465,51 @@ __device__ __forceinline__ void lds_tree_sum(xyzz_t *v, uint32_t n_pow2) {
     }
 }
 
+// grid = (ROWS + COLS, batch), block = RED_COLS (128) threads = 2 wavefronts: with <= 2 workgroups per CU
+// every wavefront has a SIMD to itself, so a tree level costs one add latency.
 template <class C>
-__global__ void SRS_KERNEL_BOUNDS(RED_ROWS, 1)
+__global__ void SRS_KERNEL_BOUNDS(RED_COLS, 1)
     k_rowcol(const xyzz_t *__restrict__ buckets, xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */) {
-    __shared__ xyzz_t v[RED_ROWS];
+    __shared__ xyzz_t v[RED_COLS];
     uint32_t m = blockIdx.y;
     const xyzz_t *B = buckets + (size_t)m * NBUCKET;
     uint32_t t = threadIdx.x;
     if (blockIdx.x < RED_ROWS) {
         uint32_t hi = blockIdx.x;
-        v[t] = (t < RED_COLS) ? B[hi * RED_COLS + t] : Ec<C>::identity();
+        v[t] = B[hi * RED_COLS + t];
     } else {
-        uint32_t lo = blockIdx.x - RED_ROWS;
-        v[t] = B[t * RED_COLS + lo];       // t < RED_ROWS == blockDim.x
+        uint32_t lo = blockIdx.x - RED_ROWS;       // 256 elements per column: two per thread
+        v[t] = Ec<C>::add(B[(size_t)t * RED_COLS + lo], B[(size_t)(t + RED_ROWS / 2) * RED_COLS + lo]);
     }
     __syncthreads();
-    lds_tree_sum<C>(v, RED_ROWS);
+    lds_tree_sum<C>(v, RED_COLS);
     if (t == 0) rc[(size_t)m * (RED_ROWS + RED_COLS) + blockIdx.x] = v[0];
 }
 
 // sum_j j * X_j = sum_{j>=1} Suffix_j with Suffix_j = sum_{i>=j} X_i: an inclusive suffix scan and a
-// tree sum, both log-depth in LDS.  The two weighted sums of the 2-D split run side by side:
-// segment A = v[0,256)  : R_hi, weights hi          (drop Suffix_0)
-// segment B = v[256,512): C_lo (128 real), weights lo+1 (keep Suffix_0)
-// grid = batch, block = RED_ROWS + RED_COLS (384) threads
+// tree sum, both log-depth in LDS.  grid = (2, batch), block = RED_ROWS (256) threads:
+//   block 0: A = sum_hi hi * R_hi        (drop Suffix_0)
+//   block 1: B = sum_lo (lo+1) * C_lo    (keep Suffix_0; 128 real elements)
+// out[2m] = A, out[2m+1] = B;  the host finishes  S = RED_COLS * A + B  (7 doublings + 1 add).
 template <class C>
-__global__ void SRS_KERNEL_BOUNDS(RED_ROWS + RED_COLS, 1)
+__global__ void SRS_KERNEL_BOUNDS(RED_ROWS, 1)
     k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
-    constexpr uint32_t SEG = RED_ROWS;                 // 256
-    __shared__ xyzz_t v[2 * SEG];
-    uint32_t m = blockIdx.x, t = threadIdx.x;
-    const xyzz_t *R = rc + (size_t)m * (RED_ROWS + RED_COLS);
-    v[t] = R[t];                                        // t < 256: R_t ; 256 <= t < 384: C_(t-256)
-    if (t < SEG - RED_COLS) v[SEG + RED_COLS + t] = Ec<C>::identity();
+    __shared__ xyzz_t v[RED_ROWS];
+    const uint32_t m = blockIdx.y, t = threadIdx.x, which = blockIdx.x;
+    const xyzz_t *src = rc + (size_t)m * (RED_ROWS + RED_COLS) + (which ? RED_ROWS : 0);
+    const uint32_t n = which ? RED_COLS : RED_ROWS;
+    v[t] = t < n ? src[t] : Ec<C>::identity();
     __syncthreads();
-    const uint32_t seg_end = t < SEG ? SEG : 2 * SEG;
-    for (uint32_t s = 1; s < SEG; s <<= 1) {           // suffix scan inside each segment
-        xyzz_t o = (t + s < seg_end) ? v[t + s] : Ec<C>::identity();
+    for (uint32_t s = 1; s < n; s <<= 1) {             // suffix scan
+        xyzz_t o = (t + s < n) ? v[t + s] : Ec<C>::identity();
         __syncthreads();
-        v[t] = Ec<C>::add(v[t], o);
+        if (t < n) v[t] = Ec<C>::add(v[t], o);
         __syncthreads();
     }
-    if (t == 0) v[0] = Ec<C>::identity();
+    if (which == 0 && t == 0) v[0] = Ec<C>::identity();
     __syncthreads();
-    for (uint32_t s = SEG >> 1; s >= 1; s >>= 1) {     // tree sum inside each segment
-        if ((t & (SEG - 1)) < s) v[t] = Ec<C>::add(v[t], v[t + s]);
-        __syncthreads();
-    }
-    if (t == 0) {
-        xyzz_t sr = v[0];
-        for (uint32_t k = 1; k < RED_COLS; k <<= 1) sr = Ec<C>::dbl(sr);               // * RED_COLS
-        out[m] = Ec<C>::add(sr, v[SEG]);
-    }
+    lds_tree_sum<C>(v, RED_ROWS);
+    if (t == 0) out[(size_t)m * 2 + which] = v[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -587,7 +580,7 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
     return per * batch + Arena::pad(batch * sizeof(void *)) + Arena::pad(batch * sizeof(uint32_t)) +
-           Arena::pad(batch * sizeof(xyzz_t)) + 4096;
+           Arena::pad(2 * batch * sizeof(xyzz_t)) + 4096;
 }
 
 template <class C>
@@ -610,7 +603,7 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     A.reset();
     const fe_t **d_ptrs = A.take<const fe_t *>(batch);
     uint32_t *d_n = A.take<uint32_t>(batch);
-    xyzz_t *d_out = A.take<xyzz_t>(batch);
+    xyzz_t *d_out = A.take<xyzz_t>(2 * (size_t)batch);
     uint16_t *dig = A.take<uint16_t>(M * batch);
     uint32_t *sorted = A.take<uint32_t>(M * batch);
     uint32_t *count = A.take<uint32_t>((size_t)NBUCKET * batch);
@@ -660,11 +653,17 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap,
                (const uint32_t *)plan, plan_stride, buckets);
-    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS + RED_COLS, batch), (RED_ROWS), 0, stream, (const xyzz_t *)buckets, rc);
-    SRS_LAUNCH((k_reduce_final<C>), (batch), (RED_ROWS + RED_COLS), 0, stream, (const xyzz_t *)rc, d_out);
-    SRS_HIP_CHECK(hipMemcpyAsync(result_host, d_out, batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS + RED_COLS, batch), (RED_COLS), 0, stream, (const xyzz_t *)buckets, rc);
+    SRS_LAUNCH((k_reduce_final<C>), (2, batch), (RED_ROWS), 0, stream, (const xyzz_t *)rc, d_out);
+    std::vector<xyzz_t> two(2 * (size_t)batch);
+    SRS_HIP_CHECK(hipMemcpyAsync(two.data(), d_out, two.size() * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
     SRS_HIP_CHECK(hipGetLastError());
+    for (uint32_t m = 0; m < batch; ++m) {             // S = RED_COLS * A + B on the host (8 group ops)
+        xyzz_t a = two[2 * m];
+        for (uint32_t k = 1; k < RED_COLS; k <<= 1) a = Ec<C>::dbl(a);
+        result_host[m] = Ec<C>::add(a, two[2 * m + 1]);
+    }
     prof::collect();
 }
 
