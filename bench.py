@@ -36,6 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+from concurrent.futures import ThreadPoolExecutor
+
+POOL = ThreadPoolExecutor(max_workers=2)     # host-side instance folds overlap the GPU witness fold
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 MSM_BYTES_PER_SCALAR = 96.0    # 64 B base + 32 B scalar, each read once
 
@@ -91,12 +94,14 @@ def prove(S, side, dist, world, dev):
     """VanillaFS::prove hot path (src/nifs/sangria/mod.rs:253-277)."""
     terms, commits = S.VanillaFS.commit_cross_terms(side.ck, side.S, side.u1c, side.u1u, side.accW, side.u2c, side.inW)
     commits = combine(S, side, commits, dist, world, dev)
-    # generate_challenge: Poseidon RO on the CPU in the reference -> seeded constant r here
-    # RelaxedPlonkInstance::fold group part (accumulator.rs:201-264): W' = W1 + r*W2 ; E' = E + sum r^k T_k
-    side.accCW = S.point_lincomb(side.curve, side.accCW, side.inC.reshape(1, 8), side.r.reshape(1, 4))
-    side.accCE = S.point_lincomb(side.curve, side.accCE, commits, side.rpows)
+    # generate_challenge: Poseidon RO on the CPU in the reference -> seeded constant r here.
+    # Both folds depend only on r: the instance fold (host scalar-muls, accumulator.rs:201-264:
+    # W' = W1 + r*W2 ; E' = E + sum r^k T_k) runs on host threads while the GPU folds the witness.
+    fW = POOL.submit(S.point_lincomb, side.curve, side.accCW, side.inC.reshape(1, 8), side.r.reshape(1, 4))
+    fE = POOL.submit(S.point_lincomb, side.curve, side.accCE, commits, side.rpows)
     acc = S.RelaxedPlonkWitness(side.field, [side.accW], side.accE).fold([side.inW], terms, side.r)
     side.accW, side.accE = acc.W[0], acc.E
+    side.accCW, side.accCE = fW.result(), fE.result()
     return commits
 
 

@@ -165,31 +165,44 @@ struct Fp {
 #include "field_fips.inc"
     }
 #else
+    // host: 4 x 64-bit limbs with 128-bit products (same CIOS, 4x fewer steps than the 32-bit form)
     static inline fe_t mul(const fe_t &a, const fe_t &b) {
-        uint32_t t[8];
-        for (int i = 0; i < 8; ++i) t[i] = 0;
-        for (int i = 0; i < 8; ++i) {
-            uint64_t c = 0;
-            for (int j = 0; j < 8; ++j) {
-                c += (uint64_t)a.v[j] * b.v[i] + t[j];
-                t[j] = (uint32_t)c;
-                c >>= 32;
+        typedef unsigned __int128 u128;
+        uint64_t A[4], B[4], Pm[4], t[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) {
+            A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+            B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+            Pm[i] = (uint64_t)P::p(2 * i) | ((uint64_t)P::p(2 * i + 1) << 32);
+        }
+        // -p^-1 mod 2^64 from the 32-bit constant by one Newton step
+        uint64_t inv = (uint64_t)P::INV;                 // -p^-1 mod 2^32
+        inv = inv * (2 + Pm[0] * inv);                   // x' = x (2 + p x) for x = -p^-1
+        for (int i = 0; i < 4; ++i) {
+            u128 c = 0;
+            for (int j = 0; j < 4; ++j) {
+                c += (u128)A[j] * B[i] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
             }
-            uint32_t hi = (uint32_t)c;     // t + a*b_i < 2^32 * 2p: exactly one extra limb
-            uint32_t m = t[0] * P::INV;
-            uint64_t d = (uint64_t)m * P::p(0) + t[0];
-            d >>= 32;
-            for (int j = 1; j < 8; ++j) {
-                d += (uint64_t)m * P::p(j) + t[j];
-                t[j - 1] = (uint32_t)d;
-                d >>= 32;
+            uint64_t hi = (uint64_t)c + t[4];
+            uint64_t m = t[0] * inv;
+            c = (u128)m * Pm[0] + t[0];
+            c >>= 64;
+            for (int j = 1; j < 4; ++j) {
+                c += (u128)m * Pm[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
             }
-            d += hi;
-            t[7] = (uint32_t)d;            // (t + a*b_i + m*p) / 2^32 < 2p < 2^255: no ninth limb
+            c += hi;
+            t[3] = (uint64_t)c;
+            t[4] = (uint64_t)(c >> 64);
         }
         fe_t o;
-        for (int i = 0; i < 8; ++i) o.v[i] = t[i];
-        return reduce_once(o);
+        for (int i = 0; i < 4; ++i) {
+            o.v[2 * i] = (uint32_t)t[i];
+            o.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+        }
+        return reduce_once(o);                           // t < 2p < 2^255, t[4] == 0
     }
 #endif
     SRS_HD static fe_t sqr(const fe_t &a) { return mul(a, a); }

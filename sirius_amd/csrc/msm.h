@@ -24,7 +24,7 @@ constexpr uint32_t RED_ROWS = 256;        // bucket index = hi * RED_COLS + lo
 constexpr uint32_t RED_COLS = NBUCKET / RED_ROWS;
 constexpr uint32_t NORM_G = 16;           // points per inversion in the key-expansion normalise
 
-static_assert(RED_ROWS == 2 * RED_COLS, "k_rowcol: two column elements per thread");
+static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
 static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
 
 // Device-resident commitment key: window-expanded table T[w * len + i] = 2^(16 w) P_i.

@@ -465,25 +465,47 @@ __device__ __forceinline__ void lds_tree_sum(xyzz_t *v, uint32_t n_pow2) {
     }
 }
 
-// grid = (ROWS + COLS, batch), block = RED_COLS (128) threads = 2 wavefronts: with <= 2 workgroups per CU
-// every wavefront has a SIMD to itself, so a tree level costs one add latency.
+// 64-lane exchange of an XYZZ point inside groups of `width` lanes
+__device__ __forceinline__ xyzz_t shfl_down_point_w(const xyzz_t &p, unsigned delta, int width) {
+    xyzz_t o;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) d[i] = __shfl_down(s[i], delta, width);
+    return o;
+}
+
+// Row / column sums with full lanes: every lane first adds RC_SERIAL consecutive elements serially,
+// then the lanes of a group (16 for a 128-element row, 32 for a 256-element column) combine by a
+// shuffle tree.  One wavefront = 4 row sums or 2 column sums; 128 wavefronts per MSM.
+// grid = (RED_ROWS / 4 + RED_COLS / 2, batch), block = 64
 template <class C>
-__global__ void SRS_KERNEL_BOUNDS(RED_COLS, 1)
+__global__ void SRS_KERNEL_BOUNDS(64, 1)
     k_rowcol(const xyzz_t *__restrict__ buckets, xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */) {
-    __shared__ xyzz_t v[RED_COLS];
-    uint32_t m = blockIdx.y;
+    constexpr uint32_t SER = 8;
+    const uint32_t m = blockIdx.y, lane = threadIdx.x;
     const xyzz_t *B = buckets + (size_t)m * NBUCKET;
-    uint32_t t = threadIdx.x;
-    if (blockIdx.x < RED_ROWS) {
-        uint32_t hi = blockIdx.x;
-        v[t] = B[hi * RED_COLS + t];
+    xyzz_t *out = rc + (size_t)m * (RED_ROWS + RED_COLS);
+    if (blockIdx.x < RED_ROWS / 4) {
+        const uint32_t hi = blockIdx.x * 4 + (lane >> 4), sub = lane & 15u;     // 16 lanes x 8 = 128 = RED_COLS
+        const xyzz_t *src = B + (size_t)hi * RED_COLS + sub * SER;
+        xyzz_t acc = src[0];
+        for (uint32_t j = 1; j < SER; ++j) acc = Ec<C>::add(acc, src[j]);
+        for (unsigned d = 8; d >= 1; d >>= 1) {
+            xyzz_t o = shfl_down_point_w(acc, d, 16);
+            if (sub < d) acc = Ec<C>::add(acc, o);
+        }
+        if (sub == 0) out[hi] = acc;
     } else {
-        uint32_t lo = blockIdx.x - RED_ROWS;       // 256 elements per column: two per thread
-        v[t] = Ec<C>::add(B[(size_t)t * RED_COLS + lo], B[(size_t)(t + RED_ROWS / 2) * RED_COLS + lo]);
+        const uint32_t lo = (blockIdx.x - RED_ROWS / 4) * 2 + (lane >> 5), sub = lane & 31u;   // 32 lanes x 8 = 256 = RED_ROWS
+        xyzz_t acc = B[(size_t)(sub * SER) * RED_COLS + lo];
+        for (uint32_t j = 1; j < SER; ++j) acc = Ec<C>::add(acc, B[(size_t)(sub * SER + j) * RED_COLS + lo]);
+        for (unsigned d = 16; d >= 1; d >>= 1) {
+            xyzz_t o = shfl_down_point_w(acc, d, 32);
+            if (sub < d) acc = Ec<C>::add(acc, o);
+        }
+        if (sub == 0) out[RED_ROWS + lo] = acc;
     }
-    __syncthreads();
-    lds_tree_sum<C>(v, RED_COLS);
-    if (t == 0) rc[(size_t)m * (RED_ROWS + RED_COLS) + blockIdx.x] = v[0];
 }
 
 // sum_j j * X_j = sum_{j>=1} Suffix_j with Suffix_j = sum_{i>=j} X_i: an inclusive suffix scan and a
@@ -653,7 +675,7 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap,
                (const uint32_t *)plan, plan_stride, buckets);
-    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS + RED_COLS, batch), (RED_COLS), 0, stream, (const xyzz_t *)buckets, rc);
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 4 + RED_COLS / 2, batch), (64), 0, stream, (const xyzz_t *)buckets, rc);
     SRS_LAUNCH((k_reduce_final<C>), (2, batch), (RED_ROWS), 0, stream, (const xyzz_t *)rc, d_out);
     std::vector<xyzz_t> two(2 * (size_t)batch);
     SRS_HIP_CHECK(hipMemcpyAsync(two.data(), d_out, two.size() * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
