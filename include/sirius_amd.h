@@ -144,6 +144,10 @@ int srs_structure_create(int field, uint32_t k, size_t num_selectors, size_t num
 void srs_structure_free(srs_structure *S);
 size_t srs_structure_num_cross_terms(const srs_structure *S);   /* d = grouped().len() - 1 */
 size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructure::num_challenges */
+/* Developer hook: the straight-line C++ of a compiled row program (which: 0 cross terms, 1 compressed,
+ * 2 homogeneous), its fingerprint and the ahead-of-time specialised kernel it maps to (-1 = interpreter).
+ * Returns the source length (truncated to cap-1).  Used by tools/gen_rowprog_spec.py. */
+size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id);
 
 /* Evaluation half of VanillaFS::commit_cross_terms (src/nifs/sangria/mod.rs:102-148):
  *   T_out[k-1][row] = coefficient of X^k in P_homogeneous(fixed, W1 + X*W2, ch1 + X*ch2)[row],  k = 1..d

@@ -51,6 +51,7 @@ def _prototypes():
         "srs_structure_free": (None, [vp]),
         "srs_structure_num_cross_terms": (sz, [vp]),
         "srs_structure_num_challenges": (sz, [vp]),
+        "srs_structure_program_source": (sz, [vp, i32, vp, sz, C.POINTER(C.c_uint64), C.POINTER(i32)]),
         "srs_cross_terms": (i32, [vp, vp, vp, vp, sz, i32, vp, C.POINTER(vp)]),
         "srs_commit_cross_terms": (i32, [vp, vp, vp, vp, vp, sz, i32, vp, C.POINTER(vp), vp]),
         "srs_eval_gates": (i32, [vp, i32, vp, vp, sz, i32, vp, vp]),

@@ -429,6 +429,17 @@ void srs_structure_free(srs_structure *S) {
 }
 size_t srs_structure_num_cross_terms(const srs_structure *S) { return S ? rowprog::degree(S->s) : 0; }
 size_t srs_structure_num_challenges(const srs_structure *S) { return S ? rowprog::num_challenges(S->s) : 0; }
+size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id) {
+    if (!S) return 0;
+    std::string src;
+    rowprog::spec_source(S->s, which, fingerprint, spec_id, src);
+    if (buf && cap) {
+        size_t n = std::min(src.size(), cap - 1);
+        std::memcpy(buf, src.data(), n);
+        buf[n] = 0;
+    }
+    return src.size();
+}
 
 static int cross_terms_impl(srs_structure *S, srs_ck *ck, const srs_fe *W1, const srs_fe *W2, const srs_fe *challenges,
                             size_t n_challenges, int space, void *stream, srs_fe *const *T_out, srs_affine *commits_out) {

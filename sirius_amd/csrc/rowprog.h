@@ -49,6 +49,10 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
                 hipStream_t st, fe_t *out_host, std::string &err);
 int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err);
 
+// straight-line C++ of the structure's row program (tools/gen_rowprog_spec.py), its fingerprint and the
+// ahead-of-time kernel it maps to (-1: interpreter)
+const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf);
+
 void fold_w(int field, fe_t *out, const fe_t *w1, const fe_t *w2, const fe_t &r, size_t n, hipStream_t st);
 int fold_e(int field, fe_t *out, const fe_t *e, const fe_t *const *t_dev_ptrs_host, size_t n_terms, const fe_t &r, size_t n,
            hipStream_t st, std::string &err);

@@ -79,6 +79,25 @@ __device__ __forceinline__ fe_t small_times(const fe_t &x, uint32_t j) {   // j 
     return acc;
 }
 
+// column loads (PlonkEvalDomain::eval_column_var / eval_advice_var, src/plonk/eval.rs:57-69,153-228)
+template <class F>
+__device__ __forceinline__ fe_t ld_sel(const RowCtx &C, uint32_t col, uint32_t rr) { return C.sel[col][rr] ? F::one() : F::zero(); }
+template <class F>
+__device__ __forceinline__ fe_t ld_fix(const RowCtx &C, uint32_t col, uint32_t rr) { return C.fix[col][rr]; }
+template <class F>
+__device__ __forceinline__ fe_t ld_adv(const RowCtx &C, uint32_t col, uint32_t rr, uint32_t pt) {
+    size_t idx = (size_t)col * C.rows + rr;
+    if (C.wcoef == nullptr) {
+        fe_t r = C.W[0][idx];
+        if (C.J == 2 && pt) r = F::add(r, small_times<F>(C.W[1][idx], pt));
+        return r;
+    }
+    const fe_t *cf = C.wcoef + (size_t)pt * C.J;
+    fe_t r = F::mul(cf[0], C.W[0][idx]);
+    for (uint32_t j = 1; j < C.J; ++j) r = F::add(r, F::mul(cf[j], C.W[j][idx]));
+    return r;
+}
+
 // interpret one row program at evaluation point `pt`; registers = LDS slots [slot][thread]
 template <class F>
 __device__ __forceinline__ fe_t interp(fe_t *slots, const Insn *__restrict__ prog, uint32_t n_insn, uint32_t result,
@@ -89,21 +108,9 @@ __device__ __forceinline__ fe_t interp(fe_t *slots, const Insn *__restrict__ pro
         fe_t r;
         if (in.op <= I_LD_ADV) {
             uint32_t rr = (row + (uint32_t)(int32_t)in.b) & mask;     // (row + rot) rem_euclid 2^k
-            if (in.op == I_LD_SEL) {
-                r = C.sel[in.a][rr] ? F::one() : F::zero();
-            } else if (in.op == I_LD_FIX) {
-                r = C.fix[in.a][rr];
-            } else {
-                size_t idx = (size_t)in.a * C.rows + rr;
-                if (C.wcoef == nullptr) {
-                    r = C.W[0][idx];
-                    if (C.J == 2 && pt) r = F::add(r, small_times<F>(C.W[1][idx], pt));
-                } else {
-                    const fe_t *cf = C.wcoef + (size_t)pt * C.J;
-                    r = F::mul(cf[0], C.W[0][idx]);
-                    for (uint32_t j = 1; j < C.J; ++j) r = F::add(r, F::mul(cf[j], C.W[j][idx]));
-                }
-            }
+            if (in.op == I_LD_SEL) r = ld_sel<F>(C, in.a, rr);
+            else if (in.op == I_LD_FIX) r = ld_fix<F>(C, in.a, rr);
+            else r = ld_adv<F>(C, in.a, rr, pt);
         } else {
             fe_t a = (in.a & UNIFORM_BIT) ? U[in.a & ~UNIFORM_BIT] : slots[in.a * nthr + tid];
             if (in.op <= I_MUL) {
@@ -148,6 +155,47 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
             if (k < A.d) A.out[k][row] = T[k];
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Specialised row programs.  The interpreter above is the general path (any circuit).  For the gate
+// sets of the reference's own configurations (MainGate<5> + MainGate<3>, MainGate<5>: SURVEY.md H5)
+// the SSA program is additionally emitted as straight-line C++ (emit_spec_source below), compiled
+// ahead of time (tools/gen_rowprog_spec.py -> rowprog_spec.inc) and selected by program
+// fingerprint: registers instead of LDS slots, no decode, loads scheduled by the compiler.
+// ---------------------------------------------------------------------------------------------
+#define SRS_SPEC_PART 1
+#include "rowprog_spec.inc"
+#undef SRS_SPEC_PART
+
+template <class F, int ID>
+__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog_spec(DevArgs A) {
+    uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
+    const bool live = row < A.ctx.rows;
+    if (!live) row = A.ctx.rows - 1;
+    fe_t T[DMAX];
+#pragma unroll
+    for (uint32_t k = 0; k < DMAX; ++k) T[k] = F::zero();
+    for (uint32_t pt = 0; pt < A.npts; ++pt) {
+        fe_t P = SpecCall<F, ID>::run(A.ctx, row, pt, A.utab + (size_t)pt * A.n_uniform);
+        if (A.d == 0) {
+            if (live) A.out[0][row] = P;
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < DMAX; ++k) {
+                if (k < A.d) T[k] = F::add(T[k], F::mul(A.vinv[k * A.npts + pt], P));
+            }
+        }
+    }
+    if (A.d && live) {
+#pragma unroll
+        for (uint32_t k = 0; k < DMAX; ++k)
+            if (k < A.d) A.out[k][row] = T[k];
+    }
+}
+
+#define SRS_SPEC_PART 2
+#include "rowprog_spec.inc"
+#undef SRS_SPEC_PART
 
 // ---------------------------------------------------------------------------------------------
 // ProtoGalaxy: pow-weighted sums of gate evaluations (reference src/nifs/protogalaxy/poly/mod.rs)
@@ -694,7 +742,49 @@ struct Program {
     std::vector<Insn> insns;
     uint32_t result = 0, nslots = 1;
     Insn *d_insns = nullptr;
+    std::vector<VInsn> vins;        // SSA form (virtual registers), kept for emit_spec_source
+    int result_vreg = -1;
+    uint64_t fingerprint = 0;       // FNV-1a of the SSA program
+    int spec_id = -1;               // index into the ahead-of-time specialised kernels, or -1
 };
+
+static uint64_t fingerprint_of(const Program &p) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
+    for (auto &in : p.vins) { mix(in.op); mix((uint64_t)(int64_t)in.dst); mix((uint64_t)(int64_t)in.a); mix((uint64_t)(int64_t)in.b); }
+    mix((uint64_t)(int64_t)p.result_vreg);
+    mix(p.result);
+    mix(p.uops.size());
+    return h;
+}
+
+// straight-line C++ for the SSA program (one function template over the field)
+std::string emit_spec_source(const Program &p, const std::string &name) {
+    std::string o;
+    auto opnd = [](int x) { return x >= 0 ? "v" + std::to_string(x) : "U[" + std::to_string(-x - 1) + "]"; };
+    o += "template <class F>\n__device__ __forceinline__ fe_t " + name +
+         "(const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *__restrict__ U) {\n";
+    o += "    const uint32_t mask = C.rows - 1; (void)mask; (void)pt; (void)U;\n";
+    for (auto &in : p.vins) {
+        std::string d = "    const fe_t v" + std::to_string(in.dst) + " = ";
+        std::string rr = "(row + " + std::to_string((uint32_t)in.b) + "u) & mask";
+        switch (in.op) {
+        case I_LD_SEL: o += d + "ld_sel<F>(C, " + std::to_string(in.a) + ", " + rr + ");\n"; break;
+        case I_LD_FIX: o += d + "ld_fix<F>(C, " + std::to_string(in.a) + ", " + rr + ");\n"; break;
+        case I_LD_ADV: o += d + "ld_adv<F>(C, " + std::to_string(in.a) + ", " + rr + ", pt);\n"; break;
+        case I_ADD: o += d + "F::add(" + opnd(in.a) + ", " + opnd(in.b) + ");\n"; break;
+        case I_SUB: o += d + "F::sub(" + opnd(in.a) + ", " + opnd(in.b) + ");\n"; break;
+        case I_MUL: o += d + "F::mul(" + opnd(in.a) + ", " + opnd(in.b) + ");\n"; break;
+        case I_SQR: o += d + "F::sqr(" + opnd(in.a) + ");\n"; break;
+        case I_DBL: o += d + "F::dbl(" + opnd(in.a) + ");\n"; break;
+        default: o += d + "F::neg(" + opnd(in.a) + ");\n"; break;
+        }
+    }
+    if (p.result_vreg >= 0) o += "    return v" + std::to_string(p.result_vreg) + ";\n";
+    else o += "    return U[" + std::to_string(p.result & ~UNIFORM_BIT) + "];\n";
+    o += "}\n";
+    return o;
+}
 
 struct Structure {
     int field = 0;
@@ -729,6 +819,13 @@ static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx
     p.uops = c.uops;
     allocate(c.vins, c.nvreg, result_vreg, p.insns, p.result, p.nslots);
     if (result_vreg < 0) p.result = result_uniform;
+    p.vins = c.vins;
+    p.result_vreg = result_vreg;
+    p.fingerprint = fingerprint_of(p);
+    p.spec_id = -1;
+    for (size_t i = 0; i < sizeof(kSpecs) / sizeof(kSpecs[0]); ++i)
+        if (kSpecs[i].fingerprint == p.fingerprint && kSpecs[i].id >= 0) p.spec_id = kSpecs[i].id;
+    if (std::getenv("SRS_NO_SPEC")) p.spec_id = -1;
     if (std::getenv("SRS_DEBUG_ROWPROG")) {
         int cnt[9] = {0};
         for (auto &in : p.insns) cnt[in.op]++;
@@ -895,6 +992,14 @@ static void launch_rowprog(const DevArgs &A, uint32_t nslots, hipStream_t st) {
     else SRS_LAUNCH((k_rowprog<F, 32>), (blocks), (RP_THREADS), 0, st, A);
 }
 
+const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf) {
+    Program &p = which == 0 ? S->cross : (which == 1 ? S->plain_compressed : S->plain_homogeneous);
+    buf = emit_spec_source(p, "spec_fn");
+    if (fingerprint) *fingerprint = p.fingerprint;
+    if (spec_id) *spec_id = p.spec_id;
+    return buf.c_str();
+}
+
 // mode 0: cross terms (needs W2), outputs `degree` vectors; mode 1/2: plain evaluation of the
 // compressed / homogeneous expression on W1, one output vector.
 int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host, size_t n_ch,
@@ -937,7 +1042,8 @@ int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, con
     a.out = d_out;
     {
         prof::Scope ps(mode == 0 ? "rowprog_cross_terms" : "rowprog_eval", st, S->rows);
-        if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);
+        if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
+        else if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);
     }
     SRS_HIP_CHECK(hipStreamSynchronize(st));   // utab / pointer staging lives in the arena
     SRS_HIP_CHECK(hipGetLastError());
