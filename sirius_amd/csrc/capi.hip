@@ -66,11 +66,27 @@ size_t shard_count(size_t n, uint32_t rank, uint32_t world) {
     return cnt;
 }
 
+// XYZZ -> affine for a batch with ONE field inversion (Montgomery's trick); identities pass through
 template <class C>
-affine_t xyzz_to_affine(const xyzz_t &p) { return Ec<C>::to_affine(p); }
-
-affine_t to_affine_curve(int curve, const xyzz_t &p) {
-    return curve == SRS_CURVE_BN256 ? xyzz_to_affine<Bn256>(p) : xyzz_to_affine<Grumpkin>(p);
+void to_affine_batch_t(const xyzz_t *in, affine_t *out, size_t n) {
+    using F = typename C::F;
+    std::vector<fe_t> pre(n);
+    fe_t acc = F::one();
+    for (size_t i = 0; i < n; ++i) {
+        pre[i] = acc;
+        if (!Ec<C>::is_identity(in[i])) acc = F::mul(acc, F::mul(in[i].zz, in[i].zzz));
+    }
+    fe_t inv = F::inv(acc);
+    for (size_t i = n; i-- > 0;) {
+        if (Ec<C>::is_identity(in[i])) { out[i] = Ec<C>::affine_identity(); continue; }
+        fe_t d = F::mul(inv, pre[i]);                       // 1 / (zz * zzz)
+        inv = F::mul(inv, F::mul(in[i].zz, in[i].zzz));
+        out[i].x = F::mul(in[i].x, F::mul(d, in[i].zzz));
+        out[i].y = F::mul(in[i].y, F::mul(d, in[i].zz));
+    }
+}
+void to_affine_batch(int curve, const xyzz_t *in, affine_t *out, size_t n) {
+    if (curve == SRS_CURVE_BN256) to_affine_batch_t<Bn256>(in, out, n); else to_affine_batch_t<Grumpkin>(in, out, n);
 }
 
 #if !defined(SRS_EMU)
@@ -257,10 +273,9 @@ int srs_commit_batch(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, 
         }
         std::vector<xyzz_t> res(batch);
         msm::run(ck->key, dptr.data(), nloc.data(), (uint32_t)batch, repr == SRS_REPR_MONT, st, res.data());
-        for (size_t m = 0; m < batch; ++m) {
-            affine_t a = to_affine_curve(ck->key.curve, res[m]);
-            std::memcpy(&out[m], &a, sizeof(a));
-        }
+        std::vector<affine_t> aff(batch);
+        to_affine_batch(ck->key.curve, res.data(), aff.data(), batch);
+        std::memcpy(out, aff.data(), batch * sizeof(affine_t));
         return SRS_OK;
     });
 }

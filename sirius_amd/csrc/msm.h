@@ -12,7 +12,8 @@ constexpr uint32_t NBUCKET = 1u << (WBITS - 1);   // |digit| in 1..2^15 -> bucke
 constexpr uint32_t STRIPE_LOG = 10;       // multi-GPU block-cyclic stripe (entries)
 
 constexpr uint32_t SORT_THREADS = 1024;   // one workgroup per CU: 128 KiB LDS histogram
-constexpr uint32_t SORT_TILE = 16384;     // digits per workgroup
+constexpr uint32_t SORT_TILE_MIN = 8192;       // digits per workgroup (lower bound)
+constexpr uint32_t SORT_TARGET_BLOCKS = 256;   // ~one 128-KiB-LDS workgroup per CU
 constexpr uint32_t PLAN_THREADS = 1024;
 constexpr uint32_t ACC_THREADS = 128;
 constexpr uint32_t ACC_L0_LOG = 4, ACC_L0 = 1u << ACC_L0_LOG;   // gathered mixed adds per level-0 thread

@@ -187,7 +187,7 @@ __device__ __forceinline__ void tile_histogram(uint32_t *h, const uint16_t *__re
 
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     k_hist(const uint16_t *__restrict__ dig, size_t dig_stride, const uint32_t *__restrict__ n_batch,
-           uint32_t *__restrict__ count /* [batch][NBUCKET] */) {
+           uint32_t *__restrict__ count /* [batch][NBUCKET] */, uint32_t SORT_TILE) {
     __shared__ uint32_t h[NBUCKET];
     uint32_t m = blockIdx.z, w = blockIdx.y;
     uint32_t n = n_batch[m];
@@ -206,7 +206,7 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     k_scatter(const uint16_t *__restrict__ dig, size_t dig_stride, const uint32_t *__restrict__ n_batch,
               uint32_t *__restrict__ cursor /* [batch][NBUCKET] */, uint32_t *__restrict__ sorted,
-              size_t sorted_stride, uint32_t table_stride) {
+              size_t sorted_stride, uint32_t table_stride, uint32_t SORT_TILE) {
     __shared__ uint32_t h[NBUCKET];
     uint32_t m = blockIdx.z, w = blockIdx.y;
     uint32_t n = n_batch[m];
@@ -216,9 +216,14 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     const uint16_t *d = dig + (size_t)m * dig_stride + (size_t)w * n;
     tile_histogram(h, d, lo, hi);
     uint32_t *cur = cursor + (size_t)m * NBUCKET;
-    for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) {
-        uint32_t c = h[b];
-        if (c) h[b] = atomicAdd(&cur[b], c);   // reserve [base, base+c) in the bucket's segment
+    for (uint32_t b0 = threadIdx.x; b0 < NBUCKET; b0 += 4 * blockDim.x) {   // 4 reservations in flight per thread
+        uint32_t c[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = h[b0 + u * blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&cur[b0 + u * blockDim.x], c[u]) : 0u;   // reserve [base, base+c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (c[u]) h[b0 + u * blockDim.x] = r[u];
     }
     __syncthreads();
     uint32_t *out = sorted + (size_t)m * sorted_stride;
@@ -655,13 +660,18 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
 
     SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, (const fe_t *const *)d_ptrs,
                (const uint32_t *)d_n, dig, (size_t)M, is_mont, k.rank, k.world);
-    const uint32_t tiles = ceil_div(n_max, SORT_TILE);
+    // tile = digits per workgroup: large enough that the fixed 2^15-bin zero/scan of the LDS histogram is
+    // amortised, small enough to give ~SORT_TARGET_BLOCKS workgroups (one per CU, 128 KiB LDS each)
+    uint32_t tile = (uint32_t)(((uint64_t)n_max * NWIN * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
+    tile = (tile + 1023u) & ~1023u;
+    if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
+    const uint32_t tiles = ceil_div(n_max, tile);
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
-               (const uint32_t *)d_n, count);
+               (const uint32_t *)d_n, count, tile);
     SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
                levels, (uint32_t)ACC_L0_LOG, (uint32_t)ACC_L1_LOG);
     SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
-               (const uint32_t *)d_n, cursor, sorted, (size_t)M, (uint32_t)k.len);
+               (const uint32_t *)d_n, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
 
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
