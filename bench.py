@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--log-key", type=int, default=21, help="log2 commitment-key length per curve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU exchange; lets 2 ranks share one GPU in tests)")
     return ap.parse_args()
 
 
@@ -87,7 +88,7 @@ def combine(S, side, partial, dist, world, dev):
     if world == 1:
         return partial
     from sirius_amd.distributed import all_gather_commitments
-    return all_gather_commitments(side.curve, partial, device=dev)
+    return all_gather_commitments(side.curve, partial, device=dev if dist.get_backend() == "nccl" else None)
 
 
 def prove(S, side, dist, world, dev):
@@ -156,13 +157,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import sirius_amd as S
 
@@ -189,10 +194,34 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     S.profile_enable(False)
+    red_dev = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- N > 1 only: the same step as N independent replicas (one IVC chain per GPU, unsharded keys, no
+    # collective).  A single chain is sequential by construction, so this is the number that
+    # scales; it is reported as an extra field, `value` stays the sharded single-chain rate.
+    replicas = None
+    if world > 1:
+        rp = Side("primary", args.k, args.log_key, 0, 1, dev)
+        rs = Side("secondary", args.k, args.log_key, 0, 1, dev)
+        for side in (rp, rs):
+            side.inC = np.zeros(8, dtype=np.uint64)
+        witness_commit(S, rp, None, 1, dev)
+        witness_commit(S, rs, None, 1, dev)
+        fold_step(S, rp, rs, None, 1, dev)
+        rsteps = max(3, args.steps // 2)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(rsteps):
+            fold_step(S, rp, rs, None, 1, dev)
+        barrier()
+        rdt = time.perf_counter() - t1
+        tt = torch.tensor([rdt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        replicas = world * rsteps / float(tt.item())
 
     if rank == 0:
         acc0 = S.profile_get("msm_accum0") or dict(total_ms=0.0, launches=0, units=0)
@@ -216,6 +245,7 @@ def main():
                        "parallelism": f"msm-shard{world}" if world > 1 else "single-gpu"},
             "msm_scalars_per_s": round(scalars_per_step * args.steps / dt, 1),
             "roofline": roof,
+            "replicas_fold_steps_per_s": None if replicas is None else round(replicas, 3),
             "cross_terms_ms_per_launch": round(ct["total_ms"] / ct["launches"], 4) if ct and ct["launches"] else None,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -168,7 +168,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
 #undef SRS_SPEC_PART
 
 template <class F, int ID>
-__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog_spec(DevArgs A) {
+__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_rowprog_spec(DevArgs A) {
     uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
     const bool live = row < A.ctx.rows;
     if (!live) row = A.ctx.rows - 1;
