@@ -226,10 +226,18 @@ def main():
     if rank == 0:
         acc0 = S.profile_get("msm_accum0") or dict(total_ms=0.0, launches=0, units=0)
         roof = None
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_accum0.json")))
+            if acc0["launches"] and world == 1:
+                traffic = round(pmc["hbm_bytes_per_scalar"] * acc0["units"] / acc0["launches"])
+        except Exception:
+            traffic = None
         if acc0["launches"]:
             achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / (acc0["total_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "msm::k_accum0 (bucket accumulation)", "achieved": round(achieved, 3),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_accum0.json (PMC bytes/scalar x scalars per launch)" if traffic else None,
                     "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
                     "note": "integer-ALU bound (256-bit modmul), not HBM bound: see DESIGN.md"}
         ct = S.profile_get("rowprog_cross_terms")
