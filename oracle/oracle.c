@@ -236,8 +236,30 @@ static void jac_add(const cparams *c, ojac *o, const ojac *p, const ojac *q) {
     fmul(f, &z3, &z3, &h);
     o->x = x3; o->y = y3; o->z = z3;
 }
+/* mixed addition (madd-2007-bl, 7M + 4S), what halo2curves' `Curve + Affine` amounts to */
 static void jac_add_affine(const cparams *c, ojac *o, const ojac *p, const oaffine *q) {
-    ojac t; jac_from_affine(c, &t, q); jac_add(c, o, p, &t);
+    const fparams *f = c->f;
+    if (aff_is_id(q)) { *o = *p; return; }
+    if (jac_is_id(p)) { jac_from_affine(c, o, q); return; }
+    ofe z1z1, u2, s2, h, hh, i, j, r, v, t, x3, y3, z3;
+    fsqr(f, &z1z1, &p->z);
+    fmul(f, &u2, &q->x, &z1z1);
+    fmul(f, &s2, &q->y, &p->z); fmul(f, &s2, &s2, &z1z1);
+    if (fe_eq(&p->x, &u2)) {
+        if (fe_eq(&p->y, &s2)) { jac_dbl(c, o, p); return; }
+        jac_set_id(o); return;
+    }
+    fsub(f, &h, &u2, &p->x);
+    fsqr(f, &hh, &h);
+    fdbl(f, &i, &hh); fdbl(f, &i, &i);
+    fmul(f, &j, &h, &i);
+    fsub(f, &r, &s2, &p->y); fdbl(f, &r, &r);
+    fmul(f, &v, &p->x, &i);
+    fsqr(f, &x3, &r); fsub(f, &x3, &x3, &j); fdbl(f, &t, &v); fsub(f, &x3, &x3, &t);
+    fsub(f, &t, &v, &x3); fmul(f, &y3, &r, &t);
+    fmul(f, &t, &p->y, &j); fdbl(f, &t, &t); fsub(f, &y3, &y3, &t);
+    fadd(f, &z3, &p->z, &h); fsqr(f, &z3, &z3); fsub(f, &z3, &z3, &z1z1); fsub(f, &z3, &z3, &hh);
+    o->x = x3; o->y = y3; o->z = z3;
 }
 static void jac_to_affine(const cparams *c, oaffine *o, const ojac *p) {
     const fparams *f = c->f;
