@@ -45,7 +45,9 @@ enum {
     SRS_ERR_INVALID = 4,          /* bad argument (null pointer, unknown curve/field id, ...)     */
     SRS_ERR_DEVICE = 5,           /* HIP runtime failure / no gfx950 device                        */
     SRS_ERR_LAYOUT = 6,           /* srs_layout_selftest mismatch                                  */
-    SRS_ERR_EVAL_INDEX = 7        /* plonk::eval::Error::*OutOfBoundary (src/plonk/eval.rs:3-25)   */
+    SRS_ERR_EVAL_INDEX = 7,       /* plonk::eval::Error::*OutOfBoundary (src/plonk/eval.rs:3-25)   */
+    SRS_ERR_IO = 8,               /* io::Error from File::open / read_exact / write_all (src/commitment.rs:99-127) */
+    SRS_ERR_INVALID_DATA = 9      /* io::ErrorKind::InvalidData "Wrong file in cache, some ptr out of curve" (:152-158) */
 };
 
 enum { SRS_CURVE_BN256 = 0, SRS_CURVE_GRUMPKIN = 1 };   /* src/lib.rs:29-48 (C1 / C2 of the cycle) */
@@ -79,6 +81,14 @@ int srs_ck_setup_synthetic(int curve, size_t len, uint64_t seed, uint32_t rank, 
 /* Copies this rank's bases (`srs_ck_local_len` points, window 0 of the table) to host memory. */
 int srs_ck_get_bases(const srs_ck *ck, srs_affine *out);
 size_t srs_ck_local_len(const srs_ck *ck);
+/* Key cache file of the reference (src/commitment.rs:99-170): `{cache}/{label}/{k}.bin` = the raw memory of `[C; 2^k]`
+ * (x || y, Montgomery, identity all-zero).  srs_ck_load_file = load_from_file (reads exactly 2^k points; a short file is
+ * SRS_ERR_IO like read_exact) + the is_on_curve validation of load_or_setup_cache (any point off the curve ->
+ * SRS_ERR_INVALID_DATA) + the device table; srs_ck_save_file = save_to_file (unsharded keys). */
+int srs_ck_load_file(int curve, const char *path, size_t k, uint32_t rank, uint32_t world, srs_ck **out);
+int srs_ck_save_file(const srs_ck *ck, const char *path);
+/* number of bases of this rank's shard that fail y^2 = x^3 + b */
+int srs_ck_count_off_curve(const srs_ck *ck, size_t *bad);
 void srs_ck_free(srs_ck *ck);
 size_t srs_ck_len(const srs_ck *ck);         /* CommitmentKey::len (src/commitment.rs:47-49) */
 
@@ -167,6 +177,13 @@ int srs_commit_cross_terms(srs_structure *S, srs_ck *ck, const srs_fe *W1, const
  * gate with challenges = U.challenges || U.u (is_sat_accumulation, src/nifs/sangria/mod.rs:334-383). */
 int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges,
                    size_t n_challenges, int space, void *stream, srs_fe *out);
+
+/* Deciders' gate check: number of rows where the gate value differs from the expected one.
+ * homogeneous = 0: compressed gate vs 0   (PlonkStructure::is_sat, src/plonk/mod.rs:329-346; E must be NULL)
+ * homogeneous = 1: homogeneous gate vs E[row] (is_sat_accumulation, src/nifs/sangria/mod.rs:352-376)
+ * *mismatch_count == 0 <=> satisfied; the reference reports EvaluationMismatch { mismatch_count, total_row }. */
+int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges, size_t n_challenges,
+                     const srs_fe *E, int space, void *stream, size_t *mismatch_count);
 
 /* ---- RelaxedPlonkWitness::fold (src/nifs/sangria/accumulator.rs:364-404) ----
  * srs_fold_witness: out[i] = w1[i] + r * w2[i]                                   (:366-376)

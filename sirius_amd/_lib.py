@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsirius_amd.so")
 
-OK, ERR_TOO_LONG_INPUT, ERR_NOT_POW2, ERR_K_TOO_LARGE, ERR_INVALID, ERR_DEVICE, ERR_LAYOUT, ERR_EVAL_INDEX = range(8)
+OK, ERR_TOO_LONG_INPUT, ERR_NOT_POW2, ERR_K_TOO_LARGE, ERR_INVALID, ERR_DEVICE, ERR_LAYOUT, ERR_EVAL_INDEX, ERR_IO, ERR_INVALID_DATA = range(10)
 CURVE_BN256, CURVE_GRUMPKIN = 0, 1
 FIELD_FR, FIELD_FQ = 0, 1
 SPACE_HOST, SPACE_DEVICE = 0, 1
@@ -41,6 +41,10 @@ def _prototypes():
         "srs_profile_enable": (None, [i32]),
         "srs_profile_reset": (None, []),
         "srs_profile_get": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "srs_ck_load_file": (i32, [i32, C.c_char_p, sz, u32, u32, C.POINTER(vp)]),
+        "srs_ck_save_file": (i32, [vp, C.c_char_p]),
+        "srs_ck_count_off_curve": (i32, [vp, C.POINTER(sz)]),
+        "srs_is_sat_gates": (i32, [vp, i32, vp, vp, sz, vp, i32, vp, C.POINTER(sz)]),
         "srs_ck_free": (None, [vp]),
         "srs_ck_len": (sz, [vp]),
         "srs_commit": (i32, [vp, vp, sz, i32, i32, vp, vp]),

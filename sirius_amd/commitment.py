@@ -61,6 +61,51 @@ class CommitmentKey:
         self._h = h
         return self
 
+    @classmethod
+    def load_from_file(cls, curve, file_path, k, rank=0, world=1):
+        """`CommitmentKey::load_from_file` + the on-curve validation of `load_or_setup_cache`
+        (src/commitment.rs:112-160): raw `[C; 2^k]` dump; IOError on a short/missing file,
+        ValueError("Wrong file in cache, some ptr out of curve") on invalid points."""
+        self = cls.__new__(cls)
+        self.curve, self._len, self.rank, self.world = curve, 1 << k, rank, world
+        h = C.c_void_p()
+        rc = L.lib().srs_ck_load_file(curve, str(file_path).encode(), k, rank, world, C.byref(h))
+        if rc == L.ERR_IO:
+            raise IOError(L.lib().srs_last_error().decode())
+        if rc == L.ERR_INVALID_DATA:
+            raise ValueError(L.lib().srs_last_error().decode())
+        L.check(rc)
+        self._h = h
+        return self
+
+    def save_to_file(self, file_path):
+        """`CommitmentKey::save_to_file` (src/commitment.rs:99-104)."""
+        rc = L.lib().srs_ck_save_file(self._h, str(file_path).encode())
+        if rc == L.ERR_IO:
+            raise IOError(L.lib().srs_last_error().decode())
+        L.check(rc)
+
+    @classmethod
+    def load_or_setup_cache(cls, curve, cache_folder, label, k, setup=None):
+        """`load_or_setup_cache` (src/commitment.rs:137-170): `{cache}/{label}/{k}.bin`.  When the file is
+        missing the reference runs `setup` (SHAKE256 + hash_to_curve, un-vendored third-party code); here the
+        caller supplies `setup(k) -> CommitmentKey` (e.g. setup_synthetic) and the result is saved."""
+        import os
+        path = os.path.join(str(cache_folder), label, f"{k}.bin")
+        if os.path.exists(path):
+            return cls.load_from_file(curve, path, k)
+        if setup is None:
+            raise FileNotFoundError(path)
+        key = setup(k)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        key.save_to_file(path)
+        return key
+
+    def count_off_curve(self):
+        n = C.c_size_t()
+        L.check(L.lib().srs_ck_count_off_curve(self._h, C.byref(n)))
+        return n.value
+
     def bases(self):
         """This rank's bases as (local_len, 8) uint64."""
         n = L.lib().srs_ck_local_len(self._h)

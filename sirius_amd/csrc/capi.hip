@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" surface declared in include/sirius_amd.h.
 #include "../../include/sirius_amd.h"
 
+#include <cstdio>
 #include <cstring>
 #include <thread>
 #include <string>
@@ -224,6 +225,50 @@ int srs_ck_get_bases(const srs_ck *ck, srs_affine *out) {
     });
 }
 size_t srs_ck_local_len(const srs_ck *ck) { return ck ? ck->key.len : 0; }
+
+int srs_ck_load_file(int curve, const char *path, size_t k, uint32_t rank, uint32_t world, srs_ck **out) {
+    if (!valid_curve(curve) || !path || !out || k >= 32) return fail(SRS_ERR_INVALID, "srs_ck_load_file: bad argument");
+    const size_t len = (size_t)1 << k;
+    std::vector<srs_affine> host(len);
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(SRS_ERR_IO, std::string("srs_ck_load_file: cannot open ") + path);
+    size_t got = std::fread(host.data(), sizeof(srs_affine), len, f);
+    std::fclose(f);
+    if (got != len) return fail(SRS_ERR_IO, "srs_ck_load_file: failed to fill whole buffer");      // read_exact
+    srs_ck *ck = nullptr;
+    int rc = srs_ck_create_sharded(curve, host.data(), len, SRS_SPACE_HOST, rank, world, &ck);
+    if (rc) return rc;
+    size_t bad = 0;
+    rc = srs_ck_count_off_curve(ck, &bad);
+    if (rc == SRS_OK && bad) rc = fail(SRS_ERR_INVALID_DATA, "Wrong file in cache, some ptr out of curve");
+    if (rc) { srs_ck_free(ck); return rc; }
+    *out = ck;
+    return SRS_OK;
+}
+
+int srs_ck_save_file(const srs_ck *ck, const char *path) {
+    if (!ck || !path) return fail(SRS_ERR_INVALID, "srs_ck_save_file: bad argument");
+    if (ck->key.world != 1) return fail(SRS_ERR_INVALID, "srs_ck_save_file: sharded key");
+    std::vector<srs_affine> host(ck->key.len);
+    int rc = srs_ck_get_bases(ck, host.data());
+    if (rc) return rc;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(SRS_ERR_IO, std::string("srs_ck_save_file: cannot create ") + path);
+    size_t put = std::fwrite(host.data(), sizeof(srs_affine), host.size(), f);
+    int cl = std::fclose(f);
+    if (put != host.size() || cl != 0) return fail(SRS_ERR_IO, "srs_ck_save_file: short write");
+    return SRS_OK;
+}
+
+int srs_ck_count_off_curve(const srs_ck *ck, size_t *bad) {
+    if (!ck || !bad) return fail(SRS_ERR_INVALID, "srs_ck_count_off_curve: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        *bad = msm::count_off_curve(ck->key, nullptr);
+        return SRS_OK;
+    });
+}
 
 int srs_ck_create(int curve, const srs_affine *bases, size_t len, int space, srs_ck **out) {
     return srs_ck_create_sharded(curve, bases, len, space, 0, 1, out);
@@ -544,6 +589,40 @@ int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs
             SRS_HIP_CHECK(hipMemcpyAsync(out, dO, rows * sizeof(fe_t), hipMemcpyDeviceToHost, st));
             SRS_HIP_CHECK(hipStreamSynchronize(st));
         }
+        return SRS_OK;
+    });
+}
+
+int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges, size_t n_challenges,
+                     const srs_fe *E, int space, void *stream, size_t *mismatch_count) {
+    if (!S || !W || !mismatch_count || (n_challenges && !challenges) || (homogeneous && !E) || (!homogeneous && E))
+        return fail(SRS_ERR_INVALID, "srs_is_sat_gates: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        rowprog::Structure *s = S->s;
+        const size_t rows = rowprog::rows(s), wlen = rowprog::num_advice(s) * rows;
+        const bool host = space != SRS_SPACE_DEVICE;
+        S->io.reserve(Arena::pad((wlen + 1) * sizeof(fe_t)) + 2 * Arena::pad(rows * sizeof(fe_t)) + 1024);
+        S->io.reset();
+        const fe_t *dW = reinterpret_cast<const fe_t *>(W), *dE = reinterpret_cast<const fe_t *>(E);
+        if (host) {
+            fe_t *a = S->io.take<fe_t>(wlen + 1);
+            SRS_HIP_CHECK(hipMemcpyAsync(a, W, wlen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            dW = a;
+            if (E) {
+                fe_t *e = S->io.take<fe_t>(rows);
+                SRS_HIP_CHECK(hipMemcpyAsync(e, E, rows * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                dE = e;
+            }
+        }
+        fe_t *vals = S->io.take<fe_t>(rows);
+        fe_t *outs[1] = {vals};
+        std::string err;
+        int erc = rowprog::evaluate(s, homogeneous ? 2 : 1, dW, nullptr, reinterpret_cast<const fe_t *>(challenges), n_challenges, outs, st, err);
+        if (erc) return fail(erc, "srs_is_sat_gates: " + err);
+        *mismatch_count = rowprog::count_mismatch(vals, dE, rows, st);
         return SRS_OK;
     });
 }

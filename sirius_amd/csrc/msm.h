@@ -43,6 +43,9 @@ void build_table(Key &k, hipStream_t stream);
 // fills table[0 .. len) with the synthetic key (see k_gen_bases)
 void generate_bases(Key &k, uint64_t seed, hipStream_t stream);
 
+// number of bases in table[0 .. len) that are not on the curve (identity counts as on-curve)
+size_t count_off_curve(const Key &k, hipStream_t stream);
+
 size_t workspace_bytes(uint32_t n_max, uint32_t batch);
 
 // batch of MSMs over the base prefix: result_host[m] = sum_{i < n[m]} scalars[m][i] * P_i  (XYZZ).

@@ -139,6 +139,14 @@ __global__ void k_gen_bases(xyzz_t *__restrict__ tmp, uint32_t n, uint64_t seed,
     tmp[i] = Ec<C>::mul_canon(k, gen);
 }
 
+// is_on_curve over a key (reference: load_or_setup_cache validates every point, src/commitment.rs:148-160)
+template <class C>
+__global__ void k_on_curve(const affine_t *__restrict__ pts, uint32_t n, uint32_t *__restrict__ bad) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!Ec<C>::is_on_curve(pts[i])) atomicAdd(bad, 1u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 1. scalars -> signed 16-bit digits
 // dig[w * n + i] = 0xFFFF (zero digit) | (|d|-1) | sign << 15
@@ -586,6 +594,20 @@ static void generate_t(Key &k, uint64_t seed, hipStream_t stream) {
 }
 void generate_bases(Key &k, uint64_t seed, hipStream_t stream) {
     if (k.curve == 0) generate_t<Bn256>(k, seed, stream); else generate_t<Grumpkin>(k, seed, stream);
+}
+
+size_t count_off_curve(const Key &k, hipStream_t stream) {
+    if (k.len == 0) return 0;
+    uint32_t *d_bad = nullptr, bad = 0;
+    SRS_HIP_CHECK(hipMalloc((void **)&d_bad, sizeof(uint32_t)));
+    SRS_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream));
+    const uint32_t n = (uint32_t)k.len;
+    if (k.curve == 0) SRS_LAUNCH((k_on_curve<Bn256>), (ceil_div(n, 256)), (256), 0, stream, (const affine_t *)k.table, n, d_bad);
+    else SRS_LAUNCH((k_on_curve<Grumpkin>), (ceil_div(n, 256)), (256), 0, stream, (const affine_t *)k.table, n, d_bad);
+    SRS_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    SRS_HIP_CHECK(hipStreamSynchronize(stream));
+    (void)hipFree(d_bad);
+    return bad;
 }
 
 void build_table(Key &k, hipStream_t stream) {

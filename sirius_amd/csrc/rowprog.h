@@ -53,6 +53,8 @@ int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, s
 // ahead-of-time kernel it maps to (-1: interpreter)
 const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf);
 
+size_t count_mismatch(const fe_t *a_dev, const fe_t *b_dev /* or nullptr: compare with 0 */, size_t n, hipStream_t st);
+
 void fold_w(int field, fe_t *out, const fe_t *w1, const fe_t *w2, const fe_t &r, size_t n, hipStream_t st);
 int fold_e(int field, fe_t *out, const fe_t *e, const fe_t *const *t_dev_ptrs_host, size_t n_terms, const fe_t &r, size_t n,
            hipStream_t st, std::string &err);

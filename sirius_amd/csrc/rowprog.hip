@@ -239,20 +239,35 @@ __device__ __forceinline__ void weighted_tree(fe_t *red, fe_t x, const fe_t *__r
     }
 }
 
-// grid = (tiles_per_gate, n_gates), block = 2^tile_log threads
-template <class F, uint32_t NSLOT>
+// grid = (tiles_per_gate, n_gates), block = 2^(tile_log - log2 LPT) threads; every thread owns LPT consecutive
+// leaves and folds them in registers (LPT - 1 multiplies, no barrier) before the workgroup tree in LDS.
+template <class F, uint32_t NSLOT, uint32_t LPT>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_leaves(PgArgs A) {
     __shared__ fe_t slots[NSLOT * RP_THREADS];
     __shared__ fe_t red[RP_THREADS];
+    constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x;
     const GateProg G = A.gates[gate];
-    const uint32_t row = tile * blockDim.x + threadIdx.x;            // < rows (rows is a multiple of the tile)
-    const uint32_t erow = A.compat ? 0u : row;
-    fe_t v = F::zero();
+    const uint32_t row0 = (tile * blockDim.x + threadIdx.x) * LPT;   // < rows (rows is a multiple of the tile)
+    fe_t v[LPT];
     for (uint32_t p = 0; p < A.P; ++p) {
-        if (A.leaf_pts > 1 || p == 0)
-            v = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, erow, p, A.utab + G.utab_off + (size_t)p * G.n_uniform);
-        weighted_tree<F>(red, v, A.weights + (A.wpts > 1 ? p : 0), A.wpts, A.tile_log);
+        if (A.leaf_pts > 1 || p == 0) {
+#pragma unroll
+            for (uint32_t l = 0; l < LPT; ++l)
+                v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, A.compat ? 0u : row0 + l, p,
+                                 A.utab + G.utab_off + (size_t)p * G.n_uniform);
+        }
+        const fe_t *w = A.weights + (A.wpts > 1 ? p : 0);
+        fe_t t[LPT];
+#pragma unroll
+        for (uint32_t l = 0; l < LPT; ++l) t[l] = v[l];
+#pragma unroll
+        for (uint32_t lvl = 0; lvl < LPT_LOG; ++lvl) {
+            fe_t c = w[(size_t)lvl * A.wpts];
+#pragma unroll
+            for (uint32_t i = 0; i < (LPT >> (lvl + 1)); ++i) t[i] = F::add(t[2 * i], F::mul(t[2 * i + 1], c));
+        }
+        weighted_tree<F>(red, t[0], w + (size_t)LPT_LOG * A.wpts, A.wpts, A.tile_log - LPT_LOG);
         if (threadIdx.x == 0) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = red[0];
         __syncthreads();
     }
@@ -293,6 +308,16 @@ __global__ void k_pg_K_points(const fe_t *__restrict__ polyG, uint32_t nG, fe_t 
     else l0 = Fr::mul(inv_n, Fr::mul(xn1, Fr::inv(xm1)));
     if (Fr::is_zero(xn1)) { *err = 1; return; }                 // "Z(X) must be not equal to 0"
     out[i] = Fr::mul(Fr::sub(g, Fr::mul(f_alpha, l0)), Fr::inv(xn1));
+}
+
+// number of rows with a[i] != b[i] (b == nullptr: a[i] != 0): the deciders' mismatch count
+// (PlonkStructure::is_sat src/plonk/mod.rs:329-346; is_sat_accumulation src/nifs/sangria/mod.rs:352-376)
+__global__ void k_count_mismatch(const fe_t *__restrict__ a, const fe_t *__restrict__ b, size_t n, uint32_t *__restrict__ count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t x = a[i];
+    bool bad = b ? !Fr::eq(x, b[i]) : !Fr::is_zero(x);
+    if (bad) atomicAdd(count, 1u);
 }
 
 // out[i] = sum_j coef[j] * W[j][i]   (ProtoGalaxy::fold_witness, protogalaxy/mod.rs:176-210)
@@ -1127,8 +1152,9 @@ fe_t poly_eval(const fe_t *c, size_t n, const fe_t &x) {       // UnivariatePoly
 }
 
 template <uint32_t NS>
-static void launch_pg_leaves(const PgArgs &A, uint32_t tiles, uint32_t gates, uint32_t threads, hipStream_t st) {
-    SRS_LAUNCH((k_pg_leaves<Fr, NS>), (tiles, gates), (threads), 0, st, A);
+static void launch_pg_leaves(const PgArgs &A, uint32_t tiles, uint32_t gates, uint32_t threads, uint32_t lpt, hipStream_t st) {
+    if (lpt == 8) SRS_LAUNCH((k_pg_leaves<Fr, NS, 8>), (tiles, gates), (threads), 0, st, A);
+    else SRS_LAUNCH((k_pg_leaves<Fr, NS, 1>), (tiles, gates), (threads), 0, st, A);
 }
 
 // mode 0: compute_F, 1: compute_G, 2: evaluate_e.  W_dev: J device witness pointers (J = 1 for F / e).
@@ -1198,8 +1224,10 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
             if (!eval_uniform(p, f, ch_pt[lp].data(), n_ch, 0, false, 0, utab.data() + gp[g].utab_off + (size_t)lp * nu, err)) return 7;
     }
     if (max_slots > 32) { err = "row program needs more than 32 live registers"; return 4; }
-    const uint32_t tile_log = std::min<uint32_t>(7, S->k);
-    const uint32_t tile = 1u << tile_log, tiles_per_gate = (uint32_t)(S->rows >> tile_log);
+    // 8 leaves per thread once a gate has >= 1024 rows: 1024-leaf tiles, the first three tree levels in registers
+    const uint32_t lpt = S->k >= 10 ? 8u : 1u;
+    const uint32_t tile_log = lpt == 8 ? 10u : std::min<uint32_t>(7, S->k);
+    const uint32_t tile = (1u << tile_log) / lpt, tiles_per_gate = (uint32_t)(S->rows >> tile_log);
     const size_t n_tiles_valid = (size_t)n_gates * tiles_per_gate;
     const size_t n_tiles_padded = sz.count_with_padding >> tile_log;
     // ---- device staging
@@ -1239,10 +1267,10 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     a.partial = buf0;
     {
         prof::Scope ps(mode == 0 ? "pg_F_leaves" : (mode == 1 ? "pg_G_leaves" : "pg_e_leaves"), st, S->rows * n_gates);
-        if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, st);
-        else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, st);
-        else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, st);
-        else launch_pg_leaves<32>(a, tiles_per_gate, n_gates, tile, st);
+        if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, lpt, st);
+        else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, lpt, st);
+        else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, lpt, st);
+        else launch_pg_leaves<32>(a, tiles_per_gate, n_gates, tile, lpt, st);
     }
     // ---- upper levels of the tree over the tile partials (zero padding beyond the real gates)
     size_t m_valid = n_tiles_valid, m = n_tiles_padded;
@@ -1295,6 +1323,18 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
     (void)hipFree(d_g); (void)hipFree(d_out); (void)hipFree(d_err);
     if (herr) { err = "Z(X) must be not equal to 0"; return 4; }
     return 0;
+}
+
+size_t count_mismatch(const fe_t *a_dev, const fe_t *b_dev, size_t n, hipStream_t st) {
+    if (!n) return 0;
+    uint32_t *d = nullptr, h = 0;
+    SRS_HIP_CHECK(hipMalloc((void **)&d, sizeof(uint32_t)));
+    SRS_HIP_CHECK(hipMemsetAsync(d, 0, sizeof(uint32_t), st));
+    SRS_LAUNCH(k_count_mismatch, ((uint32_t)((n + 255) / 256)), (256), 0, st, a_dev, b_dev, n, d);
+    SRS_HIP_CHECK(hipMemcpyAsync(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SRS_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(d);
+    return h;
 }
 
 int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err) {

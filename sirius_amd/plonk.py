@@ -69,6 +69,23 @@ class PlonkStructure:
         return out
 
 
+    def is_sat_gates(self, W, challenges, E=None):
+        """Mismatch count of the deciders' gate check: E is None -> compressed gate == 0 per row
+        (PlonkStructure::is_sat, src/plonk/mod.rs:329-346, challenges = U.challenges); otherwise homogeneous
+        gate == E[row] (is_sat_accumulation, src/nifs/sangria/mod.rs:352-376, challenges = U.challenges || U.u)."""
+        addr, space, n, keep = _buf(W, 4)
+        assert n == self.num_advice_columns * self.rows
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4)
+        eaddr = None
+        if E is not None:
+            eaddr, espace, en, ekeep = _buf(E, 4)
+            assert espace == space and en == self.rows
+        cnt = C.c_size_t()
+        L.check(L.lib().srs_is_sat_gates(self._h, 0 if E is None else 1, addr, ch.ctypes.data, ch.shape[0], eaddr, space,
+                                         _stream(), C.byref(cnt)))
+        return cnt.value
+
+
 class VanillaFS:
     """Sangria NIFS prover pieces (src/nifs/sangria/mod.rs)."""
 

@@ -101,3 +101,37 @@ def test_commit_sharded_partials(srs, oracle):
         ck = srs.CommitmentKey(cid, bases, rank=r, world=world)
         parts.append(ck.commit(sc))
     assert np.array_equal(srs.point_sum(cid, np.stack(parts)), O.msm(cid, sc, bases[:4321]))
+
+
+def _key_file_roundtrip(S, O, tmp_path):
+    """CommitmentKey cache file (src/commitment.rs:99-170; reference test file_tests::consistency :199-213)."""
+    cid, k = 1, 9
+    key = S.CommitmentKey.setup_synthetic(cid, 1 << k, seed=77)
+    path = tmp_path / "grumpkin" / f"{k}.bin"
+    path.parent.mkdir(parents=True)
+    key.save_to_file(path)
+    raw = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
+    assert np.array_equal(raw, key.bases()) and raw.shape[0] == 1 << k       # raw memory dump of [C; 2^k]
+    loaded = S.CommitmentKey.load_from_file(cid, path, k)
+    sc = seeded_scalars(O, cid, 300, 4)
+    assert np.array_equal(loaded.commit(sc), key.commit(sc)) and loaded.count_off_curve() == 0
+    again = S.CommitmentKey.load_or_setup_cache(cid, tmp_path, "grumpkin", k)
+    assert np.array_equal(again.bases(), raw)
+    made = S.CommitmentKey.load_or_setup_cache(cid, tmp_path, "fresh", 6, setup=lambda kk: S.CommitmentKey.setup_synthetic(cid, 1 << kk, seed=1))
+    assert (tmp_path / "fresh" / "6.bin").exists() and len(made) == 64
+    # a point off the curve -> InvalidData ("Wrong file in cache, some ptr out of curve", :152-158)
+    bad = raw.copy()
+    bad[5, 0] ^= np.uint64(1)
+    bad.tofile(path)
+    with pytest.raises(ValueError, match="out of curve"):
+        S.CommitmentKey.load_from_file(cid, path, k)
+    # short file -> read_exact error
+    raw[: (1 << k) - 1].tofile(path)
+    with pytest.raises(IOError):
+        S.CommitmentKey.load_from_file(cid, path, k)
+    with pytest.raises(IOError):
+        S.CommitmentKey.load_from_file(cid, tmp_path / "missing.bin", k)
+
+
+def test_key_cache_file(srs, oracle, tmp_path):
+    _key_file_roundtrip(srs, oracle, tmp_path)

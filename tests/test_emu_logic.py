@@ -79,3 +79,11 @@ def test_emu_protogalaxy(emu, oracle):
     run_pg_case(emu, oracle, 3, [5, 3, 2], 1, False)
     run_pg_case(emu, oracle, 8, [5, 3], 1, True)
     run_pg_case(emu, oracle, 4, [2], 3, False)
+
+
+def test_emu_key_file_and_deciders(emu, oracle, tmp_path):
+    from test_commit_gpu import _key_file_roundtrip
+    from test_sangria_gpu import _is_sat_case
+    _key_file_roundtrip(emu, oracle, tmp_path)
+    _is_sat_case(emu, oracle, 0, 4, (5, 3))
+    _is_sat_case(emu, oracle, 1, 5, (2,))

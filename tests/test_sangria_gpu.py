@@ -138,3 +138,38 @@ def test_fold_step_device_resident_k17_properties(srs, oracle):
     for t, e in zip(terms, exp):
         assert np.array_equal(t[:sub].cpu().numpy().view(np.uint64), e)
     assert np.array_equal(commits[0], O.msm(curve, terms[0].cpu().numpy().view(np.uint64), bases[:rows]))
+
+
+def _is_sat_case(S, O, field=0, k=6, gate_T=(5, 3)):
+    """Deciders' gate check (src/plonk/mod.rs:329-346, src/nifs/sangria/mod.rs:352-376): mismatch counts vs the oracle."""
+    from workloads import rand_fe
+    gate_T = list(gate_T)
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(gate_T)
+    rng = np.random.default_rng(12)
+    fixed = [rand_fe(rng, rows, 0.5) for _ in range(nfix)]
+    W = rand_fe(rng, nadv * rows)
+    W.reshape(nadv, rows, 4)[:, : rows // 4] = 0            # rows where every advice cell is 0
+    for f in fixed[-1:] + fixed[2 * gate_T[0] + 4: 2 * gate_T[0] + 5]:
+        f[: rows // 4] = 0                                   # rc columns zero there -> those rows satisfy the gates
+    St = S.PlonkStructure(field, k, [], fixed, nadv, gates)
+    nch = St.num_challenges
+    uc, uu = rand_fe(rng, nch), rand_fe(rng, 1)[0]
+    ctx = OE.QueryIndexContext(0, nfix, nadv, 0, 0)
+    cg = OE.CompressedGates.new(_oracle_gates(gate_T), ctx)
+    p = P.MODULI[field]
+    comp = O.eval_program(field, OE.GraphEvaluator(cg.compressed, p).export(field, O), [], fixed, W, W, uc.reshape(-1, 4))
+    exp = int(np.count_nonzero(np.any(comp != 0, axis=1)))
+    assert St.is_sat_gates(W, uc) == exp and 0 < exp <= rows - rows // 4
+    chh = np.concatenate([uc.reshape(-1, 4), uu.reshape(1, 4)])
+    hom = O.eval_program(field, OE.GraphEvaluator(cg.homogeneous, p).export(field, O), [], fixed, W, W, chh)
+    E = hom.copy()
+    assert St.is_sat_gates(W, chh, E) == 0                   # E == P_hom(W, u): relaxed instance satisfied
+    E[::3] = rand_fe(rng, len(E[::3]))
+    assert St.is_sat_gates(W, chh, E) == len(E[::3])
+    St.close()
+
+
+def test_is_sat_gates(srs, oracle):
+    _is_sat_case(srs, oracle, 0, 6, (5, 3))
+    _is_sat_case(srs, oracle, 1, 9, (5,))
