@@ -372,6 +372,15 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
         }
         if (t == PLAN_THREADS - 1) o[NBUCKET] = total;
     }
+    // every bucket already a single part after the last level?  Then the wave-level pass is a pure copy:
+    // k_accum_final exits and k_rowcol reads the last level's parts directly (part index == bucket index).
+    {
+        uint32_t mx = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) mx = vals[j] > mx ? vals[j] : mx;
+        uint32_t p = block_max(mx, lds);
+        if (t == 0) pl[plan_stride - 3] = (p <= 1u) ? 1u : 0u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -456,6 +465,7 @@ __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
                   size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride,
                   xyzz_t *__restrict__ buckets) {
     uint32_t m = blockIdx.y;
+    if (plan[(size_t)m * plan_stride + plan_stride - 3]) return;              // all buckets single: nothing to combine
     const uint32_t level = plan[(size_t)m * plan_stride + plan_stride - 4];   // levels actually run
     const xyzz_t *in = (level & 1u) ? ping : pong;     // level 0 -> ping, level 1 -> pong, ...
     const size_t in_stride = (level & 1u) ? ping_stride : pong_stride;
@@ -507,10 +517,14 @@ __device__ __forceinline__ xyzz_t shfl_down_point_w(const xyzz_t &p, unsigned de
 // grid = (RED_ROWS / 4 + RED_COLS / 2, batch), block = 64
 template <class C>
 __global__ void SRS_KERNEL_BOUNDS(64, 1)
-    k_rowcol(const xyzz_t *__restrict__ buckets, xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */) {
+    k_rowcol(const xyzz_t *__restrict__ buckets, const xyzz_t *__restrict__ ping, size_t ping_stride,
+             const xyzz_t *__restrict__ pong, size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride,
+             xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */) {
     constexpr uint32_t SER = 8;
     const uint32_t m = blockIdx.y, lane = threadIdx.x;
-    const xyzz_t *B = buckets + (size_t)m * NBUCKET;
+    const uint32_t *hdr = plan + (size_t)m * plan_stride + plan_stride - 4;   // [0] levels run, [1] all buckets single
+    const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + (size_t)m * ping_stride : pong + (size_t)m * pong_stride)
+                             : buckets + (size_t)m * NBUCKET;
     xyzz_t *out = rc + (size_t)m * (RED_ROWS + RED_COLS);
     if (blockIdx.x < RED_ROWS / 4) {
         const uint32_t hi = blockIdx.x * 4 + (lane >> 4), sub = lane & 15u;     // 16 lanes x 8 = 128 = RED_COLS
@@ -720,7 +734,9 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap,
                (const uint32_t *)plan, plan_stride, buckets);
-    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 4 + RED_COLS / 2, batch), (64), 0, stream, (const xyzz_t *)buckets, rc);
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 4 + RED_COLS / 2, batch), (64), 0, stream, (const xyzz_t *)buckets,
+               (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap, (const uint32_t *)plan,
+               plan_stride, rc);
     SRS_LAUNCH((k_reduce_final<C>), (2, batch), (RED_ROWS), 0, stream, (const xyzz_t *)rc, d_out);
     std::vector<xyzz_t> two(2 * (size_t)batch);
     SRS_HIP_CHECK(hipMemcpyAsync(two.data(), d_out, two.size() * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
