@@ -147,20 +147,10 @@ struct Fp {
     // Device: finely-integrated product scanning (FIPS).  Column k accumulates sum a_i*b_(k-i) and
     // sum m_i*p_(k-i) in a 96-bit accumulator; every term is ONE v_mad_u64_u32 whose carry-out
     // (vcc) is folded into the third limb by ONE v_addc_co_u32 -- 2 half-rate VALU ops per 32x32
-    // product, no zero-extension moves (the C/CIOS form below compiles to 575 instructions, 250
-    // of them v_mov; this form to ~330).  Measured rates: profiles/r01_ubench_gfx950.txt.
-    // Host (and the CPU logic emulator): portable CIOS, identical results.
+    // product, no zero-extension moves (a C CIOS form compiles to 575 instructions, 250 of them
+    // v_mov; this form to 405).  Measured rates: profiles/r01_ubench_gfx950*.txt.
+    // Host (and the CPU logic emulator): portable 4x64 CIOS, identical results.
 #if defined(__HIP_DEVICE_COMPILE__)
-    // (hi:acc) += a * b      acc: 64-bit VGPR pair, hi: 32-bit
-    static __device__ __forceinline__ void mac_vv(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b) {
-        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-            : "+v"(acc), "+v"(hi) : "v"(a), "v"(b) : "vcc");
-    }
-    // same with a wave-uniform multiplier (modulus limb) in an SGPR
-    static __device__ __forceinline__ void mac_vs(uint64_t &acc, uint32_t &hi, uint32_t a, uint32_t b) {
-        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-            : "+v"(acc), "+v"(hi) : "v"(a), "s"(b) : "vcc");
-    }
     static __device__ __forceinline__ fe_t mul(const fe_t &a, const fe_t &b) {
 #include "field_fips.inc"
     }
