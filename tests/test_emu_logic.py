@@ -87,3 +87,15 @@ def test_emu_key_file_and_deciders(emu, oracle, tmp_path):
     _key_file_roundtrip(emu, oracle, tmp_path)
     _is_sat_case(emu, oracle, 0, 4, (5, 3))
     _is_sat_case(emu, oracle, 1, 5, (2,))
+
+
+def test_emu_fold_then_decider(emu, oracle):
+    from test_sangria_gpu import _fold_then_decide
+    _fold_then_decide(emu, oracle, 0, 0, 4, (5, 3))
+    _fold_then_decide(emu, oracle, 1, 1, 3, (2,))
+
+
+def test_emu_protogalaxy_fold_identity(emu, oracle):
+    from test_protogalaxy_gpu import _pg_fold_identity
+    _pg_fold_identity(emu, oracle, 4, (5, 3), True)
+    _pg_fold_identity(emu, oracle, 3, (2,), False)

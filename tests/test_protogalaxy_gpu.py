@@ -66,3 +66,52 @@ def test_cyclefold_shape_k17_properties(srs, oracle):
     pG2 = O.mont_to_ints(O.FR, PG.compute_G(ctx, m(bs), [W0, W1], reference_compat=False))
     e2 = O.mont_to_ints(O.FR, PG.evaluate_e_from_trace(ctx, m(bs), W0, reference_compat=False))[0]
     assert sum(pG2) % P.FR == e2 and pG2 != pG
+
+
+def _pg_fold_identity(S, O, k, gate_T, compat):
+    """ProtoGalaxy correctness identity the reference's decider checks (is_sat_accumulation, src/nifs/protogalaxy/mod.rs:
+    `acc.e == evaluate_e_from_trace(acc)`): with a SATISFYING incoming trace, after folding with gamma
+        calculate_e(F, K, gamma, alpha) == evaluate_e_from_trace(fold_witness(acc, incoming; L(gamma)), betas_stroke)."""
+    import random
+    from oracle import pyref as P
+    from sirius_amd import protogalaxy as PG
+    from test_sangria_gpu import _satisfying_witness
+    from workloads import gates_for, rand_fe
+    gate_T = list(gate_T)
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(gate_T)
+    rng = np.random.default_rng(k + 17)
+    fixed = [rand_fe(rng, rows, 0.2) for _ in range(nfix)]
+    one = O.ints_to_mont(O.FR, [1])[0]
+    fo = 0
+    for T in gate_T:
+        fixed[fo + 2 * T + 3][:] = one
+        fo += 2 * T + 5
+    St = S.PlonkStructure(0, k, [], fixed, nadv, gates)
+    ctx = PG.PolyContext(St, 1)
+    Wacc = rand_fe(rng, nadv * rows)                       # arbitrary accumulator
+    Win = _satisfying_witness(O, 0, k, gate_T, fixed, rng)  # satisfying incoming trace: f_i(w_in) = 0
+    rnd = random.Random(k)
+    m = lambda v: O.ints_to_mont(O.FR, list(v))
+    betas = [rnd.randrange(P.FR) for _ in range(ctx.betas_count)]
+    delta, alpha, gamma = (rnd.randrange(P.FR) for _ in range(3))
+    pF = PG.compute_F(ctx, m(betas), m([delta])[0], Wacc, reference_compat=compat)
+    bs, d = [], delta
+    for b in betas:
+        bs.append((b + alpha * d) % P.FR); d = d * d % P.FR
+    pG = PG.compute_G(ctx, m(bs), [Wacc, Win], reference_compat=compat)
+    Fa = PG.poly_eval(pF, m([alpha])[0])
+    pK = PG.compute_K_from_G(ctx, pG, Fa)
+    e_new = PG.calculate_e(pF, pK, m([gamma])[0], m([alpha])[0], ctx.lagrange_domain)
+    Lg = PG.eval_lagrange_poly_for_cyclic_group(m([gamma])[0], ctx.lagrange_domain)
+    Wf = PG.fold_witness(0, [Wacc, Win], Lg)
+    assert np.array_equal(e_new, PG.evaluate_e_from_trace(ctx, m(bs), Wf, reference_compat=compat))
+    # and G(gamma) itself equals that value: K was an exact quotient
+    assert np.array_equal(PG.poly_eval(pG, m([gamma])[0]), e_new)
+    St.close()
+
+
+def test_protogalaxy_fold_identity(srs, oracle):
+    _pg_fold_identity(srs, oracle, 6, (5, 3), True)
+    _pg_fold_identity(srs, oracle, 10, (5, 3), False)
+    _pg_fold_identity(srs, oracle, 5, (2,), False)

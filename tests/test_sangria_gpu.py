@@ -173,3 +173,82 @@ def _is_sat_case(S, O, field=0, k=6, gate_T=(5, 3)):
 def test_is_sat_gates(srs, oracle):
     _is_sat_case(srs, oracle, 0, 6, (5, 3))
     _is_sat_case(srs, oracle, 1, 9, (5,))
+
+
+def _satisfying_witness(O, field, k, gate_T, fixed, rng):
+    """Advice values that satisfy every MainGate<T> of the structure on every row: random state/input cells, and
+    `out` solved from the gate (q_o is forced to 1).  Returns W (num_advice * rows, Montgomery)."""
+    from workloads import rand_fe
+    p = P.MODULI[field]
+    rows = 1 << k
+    nadv = sum(T + 2 for T in gate_T)
+    Wi = [O.mont_to_ints(field, rand_fe(rng, rows)) for _ in range(nadv)]
+    Fi = [O.mont_to_ints(field, f) for f in fixed]
+    fo = ao = 0
+    for T in gate_T:
+        q1, q5 = Fi[fo:fo + T], Fi[fo + T:fo + 2 * T]
+        qm, qi, qo, rc = Fi[fo + 2 * T:fo + 2 * T + 2], Fi[fo + 2 * T + 2], Fi[fo + 2 * T + 3], Fi[fo + 2 * T + 4]
+        st, inp = Wi[ao:ao + T], Wi[ao + T]
+        out = []
+        for r in range(rows):
+            acc = qm[0][r] * st[0][r] * st[1][r] + qi[r] * inp[r] + rc[r]
+            if T >= 4:
+                acc += qm[1][r] * st[2][r] * st[3][r]
+            for i in range(T):
+                acc += q1[i][r] * st[i][r] + q5[i][r] * pow(st[i][r], 5, p)
+            assert qo[r] == 1
+            out.append((-acc) % p)
+        Wi[ao + T + 1] = out
+        fo += 2 * T + 5
+        ao += T + 2
+    return O.ints_to_mont(field, [v for col in Wi for v in col])
+
+
+def _fold_then_decide(S, O, field, curve, k, gate_T):
+    """The reference's protocol tests (src/nifs/sangria/tests.rs:256-346) in miniature: fold a satisfying fresh
+    instance into a satisfying accumulator, then run the decider's checks on the result:
+      gate check  P_hom(W', u')[row] == E'[row]        (is_sat_accumulation, sangria/mod.rs:352-376)
+      commitments commit(W') == C_W1 + r C_W2,  commit(E') == C_E + sum r^k C_Tk   (is_sat_witness_commit :455-474)"""
+    from workloads import rand_fe
+    gate_T = list(gate_T)
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(gate_T)
+    rng = np.random.default_rng(k * 3 + len(gate_T))
+    fixed = [rand_fe(rng, rows, 0.2) for _ in range(nfix)]
+    fo = 0
+    one = O.ints_to_mont(field, [1])[0]
+    for T in gate_T:                       # q_o := 1 so that `out` can be solved for
+        fixed[fo + 2 * T + 3][:] = one
+        fo += 2 * T + 5
+    St = S.PlonkStructure(field, k, [], fixed, nadv, gates)
+    nch = St.num_challenges
+    y1, y2 = rand_fe(rng, nch), rand_fe(rng, nch)
+    W1 = _satisfying_witness(O, field, k, gate_T, fixed, rng)
+    W2 = _satisfying_witness(O, field, k, gate_T, fixed, rng)
+    zeroE = np.zeros((rows, 4), np.uint64)
+    # both are satisfying instances with u = 1, E = 0 (a fresh PlonkInstance viewed as relaxed)
+    assert St.is_sat_gates(W1, y1) == 0 and St.is_sat_gates(W2, y2) == 0
+    ch1 = np.concatenate([y1.reshape(-1, 4), one.reshape(1, 4)])
+    assert St.is_sat_gates(W1, ch1, zeroE) == 0
+    ck = S.CommitmentKey.setup_synthetic(curve, nadv * rows, seed=5)
+    terms, commits = S.VanillaFS.commit_cross_terms(ck, St, y1, one, W1, y2, W2)
+    # Q4: the last cross term (pure W2, u2 = 1) of a satisfied fresh instance is identically zero -> identity commitment
+    assert not terms[-1].any() and not commits[-1].any()
+    r = rand_fe(rng, 1)[0]
+    acc = S.RelaxedPlonkWitness(field, [W1], zeroE).fold([W2], terms, r)
+    chf = O.fe_add(field, ch1, O.fe_mul(field, np.broadcast_to(r, ch1.shape).copy(), np.concatenate([y2.reshape(-1, 4), one.reshape(1, 4)])))
+    assert St.is_sat_gates(acc.W[0], chf, acc.E) == 0                      # folded accumulator satisfies the relaxed relation
+    bad = acc.E.copy(); bad[3] = one
+    assert St.is_sat_gates(acc.W[0], chf, bad) == 1
+    sf = O.SCALAR_FIELD[curve]
+    rp = [r]
+    for _ in range(len(terms) - 1):
+        rp.append(O.fe_mul(sf, rp[-1].reshape(1, 4), r.reshape(1, 4))[0])
+    assert np.array_equal(ck.commit(acc.W[0]), S.point_lincomb(curve, ck.commit(W1), ck.commit(W2).reshape(1, 8), r.reshape(1, 4)))
+    assert np.array_equal(ck.commit(acc.E), S.point_lincomb(curve, None, commits, np.stack(rp)))
+    St.close()
+
+
+def test_fold_then_decider(srs, oracle):
+    _fold_then_decide(srs, oracle, 0, 0, 7, (5, 3))     # primary: bn256 / Fr, 2 gates (challenge y folds too)
+    _fold_then_decide(srs, oracle, 1, 1, 6, (5,))       # secondary: grumpkin / Fq
