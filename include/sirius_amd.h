@@ -133,9 +133,8 @@ int srs_ntt_set_max_radix_bits(int bits);
 
 /* ---- PlonkStructure slice for the row programs (src/plonk/mod.rs:127-157) ----
  * What the kernels need of `PlonkStructure<F>`: k (rows = 2^k), selectors (bool columns), fixed
- * columns, num_advice_columns and the gate expressions `S.gates`.  Lookup arguments are not
- * supported (num_lookups = 0; the Poseidon configurations have none) -- the shim keeps the CPU
- * path for structures with lookups.
+ * columns, num_advice_columns and the gate expressions `S.gates`.  Structures with lookup arguments
+ * are created with srs_structure_create_lookup below.
  *
  * `gates`: the `Vec<Expression<F>>` (src/polynomial/expression.rs:112-120) serialised as a postfix
  * stream of u64 words, one SRS_EX_END per gate:
@@ -151,7 +150,26 @@ enum { SRS_EX_CONST = 0, SRS_EX_POLY = 1, SRS_EX_CHALLENGE = 2, SRS_EX_NEG = 3, 
 int srs_structure_create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
                          const uint8_t *const *selectors, const srs_fe *const *fixed, int space,
                          const uint64_t *gates, size_t gates_words, size_t num_gates, srs_structure **out);
+/* PlonkStructure WITH lookup arguments (log-derivative lookups, src/plonk/lookup.rs:72-133):
+ *   gates        = S.gates as ConstraintSystemMetainfo::build leaves them: the custom gates FOLLOWED by
+ *                  Arguments::to_expressions (vanishing L_i - l_i, T_i - t_i, then the log-derivative lhs/rhs);
+ *   lookup_exprs = Arguments::lookup_polys (num_lookups expressions) then Arguments::table_polys (num_lookups),
+ *                  same postfix stream; they see the advice COLUMNS only (LookupEvalDomain, src/plonk/eval.rs:106-134)
+ *                  and the single challenge r.
+ * Each lookup adds the five fold variables (l, t, m, h, g) as query indices after the advice columns; the
+ * gate-compression challenge comes after r1 [, r2] (constraint_system_metainfo.rs:81-97).
+ * WITNESS LAYOUT for every entry point below that takes W of such a structure: the ROUNDS of PlonkWitness::W
+ * CONCATENATED, W[0] || W[1] (|| W[2]) -- (num_advice + 5 * num_lookups) * 2^k elements
+ * (srs_structure_num_witness_columns); query index -> column is PlonkEvalDomain::eval_advice_var's index_map
+ * (src/plonk/eval.rs:169-201), reproduced literally (for num_lookups > 1 it addresses (l,t,m) / (h,g)
+ * interleaved per lookup although run_sps_protocol_* concatenates them grouped -- DESIGN.md quirk Q5). */
+int srs_structure_create_lookup(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
+                                const uint8_t *const *selectors, const srs_fe *const *fixed, int space,
+                                const uint64_t *gates, size_t gates_words, size_t num_gates,
+                                size_t num_lookups, int has_vector_lookup,
+                                const uint64_t *lookup_exprs, size_t lookup_words, srs_structure **out);
 void srs_structure_free(srs_structure *S);
+size_t srs_structure_num_witness_columns(const srs_structure *S);   /* num_advice + 5 * num_lookups */
 size_t srs_structure_num_cross_terms(const srs_structure *S);   /* d = grouped().len() - 1 */
 size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructure::num_challenges */
 /* Developer hook: the straight-line C++ of a compiled row program (which: 0 cross terms, 1 compressed,
@@ -161,7 +179,7 @@ size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size
 
 /* Evaluation half of VanillaFS::commit_cross_terms (src/nifs/sangria/mod.rs:102-148):
  *   T_out[k-1][row] = coefficient of X^k in P_homogeneous(fixed, W1 + X*W2, ch1 + X*ch2)[row],  k = 1..d
- * W1, W2: round-0 witness vectors, column-major num_advice * 2^k (PlonkWitness::W[0]);
+ * W1, W2: witness vectors, column-major num_advice * 2^k (PlonkWitness::W[0]; all rounds concatenated with lookups);
  * challenges = U1.challenges || U1.u || U2.challenges || 1  (src/nifs/sangria/mod.rs:113-118);
  * a challenge index outside that vector -> SRS_ERR_EVAL_INDEX (ChallengeIndexOutOfBoundary). */
 int srs_cross_terms(srs_structure *S, const srs_fe *W1, const srs_fe *W2, const srs_fe *challenges,
@@ -184,6 +202,21 @@ int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs
  * *mismatch_count == 0 <=> satisfied; the reference reports EvaluationMismatch { mismatch_count, total_row }. */
 int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges, size_t n_challenges,
                      const srs_fe *E, int space, void *stream, size_t *mismatch_count);
+
+/* ---- lookup arguments: prover coefficients and the decider's log-derivative check ----
+ * srs_lookup_coeff_1 = Arguments::evaluate_coefficient_1 (src/plonk/lookup.rs:319-341): for every lookup i
+ *   ls[i][row] = L_i(advice, r)[row], ts[i][row] = T_i(fixed, r)[row]               (evaluate_ls / _ts, :209-272)
+ *   ms[i][row] = #{ j : ls[i][j] == ts[i][row] } on the first row holding that table value, 0 on repeats (:275-303)
+ *   advice: the advice columns, column-major num_advice * 2^k; ls / ts / ms: arrays of num_lookups vectors of 2^k.
+ * srs_lookup_coeff_2 = Arguments::evaluate_h_g (:305-317) for ONE lookup: h = 1 / (l + r), g = m / (t + r), 1/0 := 0.
+ * srs_is_sat_log_derivative = PlonkStructure::is_sat_log_derivative (src/plonk/mod.rs:366-398): number of lookups
+ *   whose sum_row (h_i - g_i) is non-zero (0 <=> satisfied; the reference returns LogDerivativeNotSat otherwise);
+ *   W is the concatenated witness described at srs_structure_create_lookup. */
+int srs_lookup_coeff_1(srs_structure *S, const srs_fe *advice, const srs_fe *r, int space, void *stream,
+                       srs_fe *const *ls, srs_fe *const *ts, srs_fe *const *ms);
+int srs_lookup_coeff_2(int field, const srs_fe *l, const srs_fe *t, const srs_fe *m, const srs_fe *r, size_t n,
+                       int space, void *stream, srs_fe *h, srs_fe *g);
+int srs_is_sat_log_derivative(srs_structure *S, const srs_fe *W, int space, void *stream, size_t *mismatch_count);
 
 /* ---- RelaxedPlonkWitness::fold (src/nifs/sangria/accumulator.rs:364-404) ----
  * srs_fold_witness: out[i] = w1[i] + r * w2[i]                                   (:366-376)

@@ -161,24 +161,46 @@ def coset_ifft(a, threads=0): return _ntt("o_coset_ifft", a, threads)
 
 class _EvalDomain(C.Structure):
     _fields_ = [("field", C.c_int), ("rows", C.c_size_t), ("n_sel", C.c_size_t),
-                ("n_fixed", C.c_size_t), ("num_advice", C.c_size_t),
+                ("n_fixed", C.c_size_t), ("num_advice", C.c_size_t), ("num_lookup", C.c_size_t),
                 ("selectors", C.POINTER(C.c_void_p)), ("fixed", C.POINTER(C.c_void_p)),
-                ("W1", C.c_void_p), ("W2", C.c_void_p),
+                ("n_w1", C.c_size_t), ("n_w2", C.c_size_t),
+                ("W1s", C.c_void_p * 3), ("W2s", C.c_void_p * 3),
+                ("w1_len", C.c_size_t * 3), ("w2_len", C.c_size_t * 3),
                 ("challenges", C.c_void_p), ("n_challenges", C.c_size_t)]
 
 
-def eval_program(field, prog, selectors, fixed, W1, W2, challenges, threads=0):
-    """prog = dict(calcs (n,8) int64, constants (m,4) mont, rotations int32, n_intermediates)."""
+def _rounds(W):
+    """a single (n,4) vector or a list of round vectors -> list of contiguous round arrays"""
+    if W is None:
+        return []
+    if isinstance(W, (list, tuple)):
+        return [_fe(np.asarray(w).reshape(-1, 4)) for w in W]
+    return [_fe(np.asarray(W).reshape(-1, 4))]
+
+
+def eval_program(field, prog, selectors, fixed, W1, W2, challenges, threads=0, num_advice=None, num_lookup=0):
+    """prog = dict(calcs (n,8) int64, constants (m,4) mont, rotations int32, n_intermediates).
+    W1 / W2: one round-0 vector, or the list of witness rounds (PlonkWitness::W) when the structure has lookups
+    (then num_advice must be given)."""
     rows = fixed[0].shape[0] if len(fixed) else selectors[0].shape[0]
     sel = [np.ascontiguousarray(s, dtype=np.uint8) for s in selectors]
     fx = [_fe(f) for f in fixed]
-    W1, W2 = _fe(W1), _fe(W2)
+    r1, r2 = _rounds(W1), _rounds(W2)
     ch = _fe(np.asarray(challenges, dtype=np.uint64).reshape(-1, 4))
-    num_advice = W1.size // 4 // rows
+    if num_advice is None:
+        assert num_lookup == 0 and len(r1) == 1
+        num_advice = r1[0].shape[0] // rows
     selp = (C.c_void_p * max(len(sel), 1))(*[s.ctypes.data for s in sel])
     fxp = (C.c_void_p * max(len(fx), 1))(*[f.ctypes.data for f in fx])
-    d = _EvalDomain(field, rows, len(sel), len(fx), num_advice, selp, fxp,
-                    W1.ctypes.data, W2.ctypes.data, ch.ctypes.data, ch.shape[0])
+    d = _EvalDomain()
+    d.field, d.rows, d.n_sel, d.n_fixed, d.num_advice, d.num_lookup = field, rows, len(sel), len(fx), num_advice, num_lookup
+    d.selectors, d.fixed = selp, fxp
+    d.n_w1, d.n_w2 = len(r1), len(r2)
+    for i, w in enumerate(r1):
+        d.W1s[i], d.w1_len[i] = w.ctypes.data, w.shape[0]
+    for i, w in enumerate(r2):
+        d.W2s[i], d.w2_len[i] = w.ctypes.data, w.shape[0]
+    d.challenges, d.n_challenges = ch.ctypes.data, ch.shape[0]
     calcs = np.ascontiguousarray(prog["calcs"], dtype=np.int64).reshape(-1, 8)
     consts = _fe(prog["constants"])
     rots = np.ascontiguousarray(prog["rotations"], dtype=np.int32)

@@ -508,9 +508,10 @@ int o_coset_ifft(ofe *a, size_t n, int threads) {
 /* ------------------------------------------------------------------ row-program interpreter
  * src/polynomial/graph_evaluator.rs:93-149 (Calculation::evaluate), :361-388 (evaluate);
  * value fetch = GetDataForEval::eval_column_var (src/plonk/eval.rs:57-69) +
- * PlonkEvalDomain::eval_advice_var (src/plonk/eval.rs:153-228) with num_lookup = 0:
- *   Poly{index}: index < n_sel -> selector bit; < n_sel+n_fixed -> fixed; else advice j = index - ...,
- *   j < num_advice -> W1[j*rows + row] else W2[(j-num_advice)*rows + row].
+ * PlonkEvalDomain::eval_advice_var (src/plonk/eval.rs:153-228):
+ *   Poly{index}: index < n_sel -> selector bit; < n_sel+n_fixed -> fixed; else fold variable
+ *   j = index - ..., width = num_advice + 5 * num_lookup: j < width -> first instance (W1s), else second (W2s);
+ *   (round, column) = index_map(j), eval.rs:169-201 -- depends on the NUMBER of rounds of that instance.
  * Rotation: (row + rot) rem_euclid rows  (graph_evaluator.rs:51-53).
  */
 enum { K_CONST = 0, K_INTER = 1, K_FIXED = 2, K_POLY = 3, K_CHAL = 4 };
@@ -529,9 +530,24 @@ static inline int fetch(const o_eval_domain *d, const fparams *f, int64_t kind, 
         i -= d->n_sel;
         if (i < d->n_fixed) { *o = d->fixed[i][row]; return 0; }
         i -= d->n_fixed;
-        if (i < d->num_advice) { *o = d->W1[i * d->rows + row]; return 0; }
-        i -= d->num_advice;
-        if (i < d->num_advice) { *o = d->W2[i * d->rows + row]; return 0; }
+        const size_t width = d->num_advice + 5 * d->num_lookup;
+        const int first = i < width;
+        if (!first) i -= width;
+        const size_t nw = first ? d->n_w1 : d->n_w2;
+        const ofe *const *Ws = first ? d->W1s : d->W2s;
+        const size_t *lens = first ? d->w1_len : d->w2_len;
+        size_t round, col;
+        if (i < d->num_advice) { round = 0; col = i; }
+        else {
+            size_t li = (i - d->num_advice) / 5, sub = (i - d->num_advice) % 5;
+            int first_round = sub < 3; if (!first_round) sub -= 3;
+            if (nw == 2) { if (first_round) { round = 0; col = d->num_advice + li * 3 + sub; } else { round = 1; col = li * 2 + sub; } }
+            else if (nw == 3) { if (first_round) { round = 1; col = li * 3 + sub; } else { round = 2; col = li * 2 + sub; } }
+            else return 1;
+        }
+        if (nw <= round || lens[round] <= col * d->rows + row) return 1;
+        *o = Ws[round][col * d->rows + row];
+        return 0;
         return 1;
     }
     }

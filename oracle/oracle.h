@@ -77,17 +77,22 @@ int o_coset_ifft(ofe *a, size_t n, int threads);   /* :194-198 */
  * kinds: 0 Constant(idx) 1 Intermediate(idx) 2 Fixed{idx,rot} 3 Poly{idx,rot} 4 Challenge{idx}
  * ops:   0 Add 1 Sub 2 Mul 3 Square 4 Double 5 Negate 6 Store   (Horner is never emitted by
  * add_expression, graph_evaluator.rs:261-351)
- * Data (= PlonkEvalDomain, src/plonk/eval.rs:93-104,153-228; lookups unsupported: num_lookup = 0):
+ * Data (= PlonkEvalDomain, src/plonk/eval.rs:93-104,153-228):
  *   selectors: n_sel byte columns of `rows`; fixed: n_fixed columns of `rows` field elements;
- *   W1, W2: round-0 witness vectors, column-major (num_advice * rows) each.
+ *   W1s / W2s: the witness ROUNDS of the two instances (PlonkWitness::W), n_w1 / n_w2 of them
+ *   (1 without lookups, 2 or 3 with), each column-major with w*_len[i] elements.
+ *   Column j >= num_advice is lookup variable (j - num_advice) / 5, sub-index % 5 of (l, t, m, h, g),
+ *   mapped to (round, column) exactly as eval.rs:169-201 does.
  */
 typedef struct {
     int field;
     size_t rows;
-    size_t n_sel, n_fixed, num_advice;
+    size_t n_sel, n_fixed, num_advice, num_lookup;
     const uint8_t *const *selectors;
     const ofe *const *fixed;
-    const ofe *W1, *W2;
+    size_t n_w1, n_w2;
+    const ofe *W1s[3], *W2s[3];
+    size_t w1_len[3], w2_len[3];
     const ofe *challenges; size_t n_challenges;
 } o_eval_domain;
 

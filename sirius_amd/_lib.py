@@ -52,6 +52,12 @@ def _prototypes():
         "srs_point_sum": (i32, [i32, vp, sz, vp]),
         "srs_point_mul": (i32, [i32, vp, i32, vp, vp]),
         "srs_structure_create": (i32, [i32, u32, sz, sz, sz, C.POINTER(vp), C.POINTER(vp), i32, vp, sz, sz, C.POINTER(vp)]),
+        "srs_structure_create_lookup": (i32, [i32, u32, sz, sz, sz, C.POINTER(vp), C.POINTER(vp), i32, vp, sz, sz, sz, i32, vp, sz,
+                                              C.POINTER(vp)]),
+        "srs_structure_num_witness_columns": (sz, [vp]),
+        "srs_lookup_coeff_1": (i32, [vp, vp, vp, i32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "srs_lookup_coeff_2": (i32, [i32, vp, vp, vp, vp, sz, i32, vp, vp, vp]),
+        "srs_is_sat_log_derivative": (i32, [vp, vp, i32, vp, C.POINTER(sz)]),
         "srs_structure_free": (None, [vp]),
         "srs_structure_num_cross_terms": (sz, [vp]),
         "srs_structure_num_challenges": (sz, [vp]),

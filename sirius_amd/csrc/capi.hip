@@ -460,11 +460,13 @@ int srs_profile_get(const char *name, double *total_ms, uint64_t *launches, uint
 }
 
 // ------------------------------------------------------------------ row programs
-int srs_structure_create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
-                         const uint8_t *const *selectors, const srs_fe *const *fixed, int space, const uint64_t *gates,
-                         size_t gates_words, size_t num_gates, srs_structure **out) {
-    if (!valid_field(field) || !out || k > 30 || (num_selectors && !selectors) || (num_fixed && !fixed) || (gates_words && !gates))
-        return fail(SRS_ERR_INVALID, "srs_structure_create: bad argument");
+static int structure_create_impl(const char *who, int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
+                                 const uint8_t *const *selectors, const srs_fe *const *fixed, int space, const uint64_t *gates,
+                                 size_t gates_words, size_t num_gates, size_t num_lookups, int has_vector_lookup,
+                                 const uint64_t *lookup_exprs, size_t lookup_words, srs_structure **out) {
+    if (!valid_field(field) || !out || k > 30 || (num_selectors && !selectors) || (num_fixed && !fixed) || (gates_words && !gates) ||
+        (num_lookups && (!lookup_exprs || !lookup_words)))
+        return fail(SRS_ERR_INVALID, std::string(who) + ": bad argument");
     int rc = ensure_device();
     if (rc) return rc;
     return guarded([&]() -> int {
@@ -472,13 +474,27 @@ int srs_structure_create(int field, uint32_t k, size_t num_selectors, size_t num
         int crc = 0;
         rowprog::Structure *s = rowprog::create(field, k, num_selectors, num_fixed, num_advice, selectors,
                                                 reinterpret_cast<const fe_t *const *>(fixed), space == SRS_SPACE_DEVICE, gates,
-                                                gates_words, num_gates, crc, err);
-        if (!s) return fail(crc ? crc : SRS_ERR_INVALID, "srs_structure_create: " + err);
+                                                gates_words, num_gates, num_lookups, has_vector_lookup != 0, lookup_exprs,
+                                                lookup_words, crc, err);
+        if (!s) return fail(crc ? crc : SRS_ERR_INVALID, std::string(who) + ": " + err);
         srs_structure *S = new srs_structure();
         S->s = s;
         *out = S;
         return SRS_OK;
     });
+}
+int srs_structure_create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
+                         const uint8_t *const *selectors, const srs_fe *const *fixed, int space, const uint64_t *gates,
+                         size_t gates_words, size_t num_gates, srs_structure **out) {
+    return structure_create_impl("srs_structure_create", field, k, num_selectors, num_fixed, num_advice, selectors, fixed, space, gates,
+                                 gates_words, num_gates, 0, 0, nullptr, 0, out);
+}
+int srs_structure_create_lookup(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
+                                const uint8_t *const *selectors, const srs_fe *const *fixed, int space, const uint64_t *gates,
+                                size_t gates_words, size_t num_gates, size_t num_lookups, int has_vector_lookup,
+                                const uint64_t *lookup_exprs, size_t lookup_words, srs_structure **out) {
+    return structure_create_impl("srs_structure_create_lookup", field, k, num_selectors, num_fixed, num_advice, selectors, fixed, space,
+                                 gates, gates_words, num_gates, num_lookups, has_vector_lookup, lookup_exprs, lookup_words, out);
 }
 
 void srs_structure_free(srs_structure *S) {
@@ -489,6 +505,7 @@ void srs_structure_free(srs_structure *S) {
 }
 size_t srs_structure_num_cross_terms(const srs_structure *S) { return S ? rowprog::degree(S->s) : 0; }
 size_t srs_structure_num_challenges(const srs_structure *S) { return S ? rowprog::num_challenges(S->s) : 0; }
+size_t srs_structure_num_witness_columns(const srs_structure *S) { return S ? rowprog::num_witness_columns(S->s) : 0; }
 size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id) {
     if (!S) return 0;
     std::string src;
@@ -510,7 +527,7 @@ static int cross_terms_impl(srs_structure *S, srs_ck *ck, const srs_fe *W1, cons
     return guarded([&]() -> int {
         hipStream_t st = (hipStream_t)stream;
         rowprog::Structure *s = S->s;
-        const size_t d = rowprog::degree(s), rows = rowprog::rows(s), wlen = rowprog::num_advice(s) * rows;
+        const size_t d = rowprog::degree(s), rows = rowprog::rows(s), wlen = rowprog::num_witness_columns(s) * rows;
         if (d == 0) return SRS_OK;
         if (ck && rows > ck->key.global_len)
             return fail(SRS_ERR_TOO_LONG_INPUT, "Can't commit too long input: input len: " + std::to_string(rows) +
@@ -569,7 +586,7 @@ int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs
     return guarded([&]() -> int {
         hipStream_t st = (hipStream_t)stream;
         rowprog::Structure *s = S->s;
-        const size_t rows = rowprog::rows(s), wlen = rowprog::num_advice(s) * rows;
+        const size_t rows = rowprog::rows(s), wlen = rowprog::num_witness_columns(s) * rows;
         const bool host = space != SRS_SPACE_DEVICE;
         const fe_t *dW = reinterpret_cast<const fe_t *>(W);
         fe_t *dO = reinterpret_cast<fe_t *>(out);
@@ -602,7 +619,7 @@ int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const s
     return guarded([&]() -> int {
         hipStream_t st = (hipStream_t)stream;
         rowprog::Structure *s = S->s;
-        const size_t rows = rowprog::rows(s), wlen = rowprog::num_advice(s) * rows;
+        const size_t rows = rowprog::rows(s), wlen = rowprog::num_witness_columns(s) * rows;
         const bool host = space != SRS_SPACE_DEVICE;
         S->io.reserve(Arena::pad((wlen + 1) * sizeof(fe_t)) + 2 * Arena::pad(rows * sizeof(fe_t)) + 1024);
         S->io.reset();
@@ -623,6 +640,105 @@ int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const s
         int erc = rowprog::evaluate(s, homogeneous ? 2 : 1, dW, nullptr, reinterpret_cast<const fe_t *>(challenges), n_challenges, outs, st, err);
         if (erc) return fail(erc, "srs_is_sat_gates: " + err);
         *mismatch_count = rowprog::count_mismatch(vals, dE, rows, st);
+        return SRS_OK;
+    });
+}
+
+// ------------------------------------------------------------------ lookup arguments
+int srs_lookup_coeff_1(srs_structure *S, const srs_fe *advice, const srs_fe *r, int space, void *stream, srs_fe *const *ls,
+                       srs_fe *const *ts, srs_fe *const *ms) {
+    if (!S || !advice || !r || !ls || !ts || !ms) return fail(SRS_ERR_INVALID, "srs_lookup_coeff_1: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        rowprog::Structure *s = S->s;
+        const size_t L = rowprog::num_lookups(s), rows = rowprog::rows(s), alen = rowprog::num_advice(s) * rows;
+        if (!L) return fail(SRS_ERR_INVALID, "srs_lookup_coeff_1: structure has no lookup arguments");
+        const bool host = space != SRS_SPACE_DEVICE;
+        std::vector<fe_t *> dl(L), dt(L), dm(L);
+        const fe_t *dA = reinterpret_cast<const fe_t *>(advice);
+        if (host) {
+            S->io.reserve(Arena::pad((alen + 1) * sizeof(fe_t)) + 3 * L * Arena::pad(rows * sizeof(fe_t)) + 1024);
+            S->io.reset();
+            fe_t *a = S->io.take<fe_t>(alen + 1);
+            SRS_HIP_CHECK(hipMemcpyAsync(a, advice, alen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            dA = a;
+            for (size_t i = 0; i < L; ++i) { dl[i] = S->io.take<fe_t>(rows); dt[i] = S->io.take<fe_t>(rows); dm[i] = S->io.take<fe_t>(rows); }
+        } else {
+            for (size_t i = 0; i < L; ++i) {
+                dl[i] = reinterpret_cast<fe_t *>(ls[i]); dt[i] = reinterpret_cast<fe_t *>(ts[i]); dm[i] = reinterpret_cast<fe_t *>(ms[i]);
+            }
+        }
+        fe_t rr;
+        std::memcpy(&rr, r, 32);
+        std::string err;
+        int erc = rowprog::lookup_coeff_1(s, dA, rr, dl.data(), dt.data(), dm.data(), st, err);
+        if (erc) return fail(erc, "srs_lookup_coeff_1: " + err);
+        if (host) {
+            for (size_t i = 0; i < L; ++i) {
+                SRS_HIP_CHECK(hipMemcpyAsync(ls[i], dl[i], rows * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipMemcpyAsync(ts[i], dt[i], rows * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipMemcpyAsync(ms[i], dm[i], rows * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+            }
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        return SRS_OK;
+    });
+}
+
+int srs_lookup_coeff_2(int field, const srs_fe *l, const srs_fe *t, const srs_fe *m, const srs_fe *r, size_t n, int space,
+                       void *stream, srs_fe *h, srs_fe *g) {
+    if (!valid_field(field) || !r || n > 0xFFFFFFFFull || (n && (!l || !t || !m || !h || !g)))
+        return fail(SRS_ERR_INVALID, "srs_lookup_coeff_2: bad argument");
+    if (!n) return SRS_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        fe_t rr;
+        std::memcpy(&rr, r, 32);
+        if (space == SRS_SPACE_DEVICE) {
+            rowprog::lookup_coeff_2(field, reinterpret_cast<const fe_t *>(l), reinterpret_cast<const fe_t *>(t),
+                                    reinterpret_cast<const fe_t *>(m), rr, n, reinterpret_cast<fe_t *>(h), reinterpret_cast<fe_t *>(g), st);
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            fe_t *buf = nullptr;
+            SRS_HIP_CHECK(hipMalloc((void **)&buf, 5 * n * sizeof(fe_t)));
+            try {
+                SRS_HIP_CHECK(hipMemcpyAsync(buf, l, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                SRS_HIP_CHECK(hipMemcpyAsync(buf + n, t, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                SRS_HIP_CHECK(hipMemcpyAsync(buf + 2 * n, m, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                rowprog::lookup_coeff_2(field, buf, buf + n, buf + 2 * n, rr, n, buf + 3 * n, buf + 4 * n, st);
+                SRS_HIP_CHECK(hipMemcpyAsync(h, buf + 3 * n, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipMemcpyAsync(g, buf + 4 * n, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+                SRS_HIP_CHECK(hipStreamSynchronize(st));
+            } catch (...) { (void)hipFree(buf); throw; }
+            (void)hipFree(buf);
+        }
+        SRS_HIP_CHECK(hipGetLastError());
+        prof::collect();
+        return SRS_OK;
+    });
+}
+
+int srs_is_sat_log_derivative(srs_structure *S, const srs_fe *W, int space, void *stream, size_t *mismatch_count) {
+    if (!S || !W || !mismatch_count) return fail(SRS_ERR_INVALID, "srs_is_sat_log_derivative: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        rowprog::Structure *s = S->s;
+        const size_t wlen = rowprog::num_witness_columns(s) * rowprog::rows(s);
+        const fe_t *dW = reinterpret_cast<const fe_t *>(W);
+        if (space != SRS_SPACE_DEVICE && rowprog::num_lookups(s)) {
+            S->io.reserve(Arena::pad((wlen + 1) * sizeof(fe_t)) + 1024);
+            S->io.reset();
+            fe_t *a = S->io.take<fe_t>(wlen + 1);
+            SRS_HIP_CHECK(hipMemcpyAsync(a, W, wlen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            dW = a;
+        }
+        *mismatch_count = rowprog::log_derivative_mismatches(s, dW, st);
         return SRS_OK;
     });
 }
@@ -721,7 +837,7 @@ static int pg_impl(srs_structure *S, int mode, const srs_fe *weights, size_t n_w
     return guarded([&]() -> int {
         hipStream_t st = (hipStream_t)stream;
         rowprog::Structure *s = S->s;
-        const size_t wlen = rowprog::num_advice(s) * rowprog::rows(s);
+        const size_t wlen = rowprog::num_witness_columns(s) * rowprog::rows(s);
         std::vector<const fe_t *> dW(J);
         if (space == SRS_SPACE_DEVICE) {
             for (size_t j = 0; j < J; ++j) dW[j] = reinterpret_cast<const fe_t *>(W[j]);

@@ -19,11 +19,14 @@ struct Structure;
 // rc: 0 ok, 4 invalid, 5 device, 7 index out of range
 Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
                   const uint8_t *const *selectors, const fe_t *const *fixed, int space_device,
-                  const uint64_t *gates, size_t gates_words, size_t num_gates, int &rc, std::string &err);
+                  const uint64_t *gates, size_t gates_words, size_t num_gates, size_t num_lookups, bool has_vector_lookup,
+                  const uint64_t *lookup_exprs, size_t lookup_words, int &rc, std::string &err);
 void destroy(Structure *S);
 size_t degree(const Structure *S);            // homogeneous degree d = number of cross terms
 size_t num_challenges(const Structure *S);    // PlonkStructure::num_challenges
 size_t num_advice(const Structure *S);
+size_t num_witness_columns(const Structure *S);   // num_advice + 5 * num_lookups: columns of W[0] || W[1] || ...
+size_t num_lookups(const Structure *S);
 size_t rows(const Structure *S);
 int field(const Structure *S);
 
@@ -52,6 +55,12 @@ int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, s
 // straight-line C++ of the structure's row program (tools/gen_rowprog_spec.py), its fingerprint and the
 // ahead-of-time kernel it maps to (-1: interpreter)
 const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf);
+
+// lookup arguments (src/plonk/lookup.rs): all pointers DEVICE; ls / ts / ms HOST arrays of num_lookups DEVICE vectors
+int lookup_coeff_1(Structure *S, const fe_t *advice_dev, const fe_t &r, fe_t *const *ls, fe_t *const *ts, fe_t *const *ms,
+                   hipStream_t st, std::string &err);
+void lookup_coeff_2(int field, const fe_t *l, const fe_t *t, const fe_t *m, const fe_t &r, size_t n, fe_t *h, fe_t *g, hipStream_t st);
+size_t log_derivative_mismatches(Structure *S, const fe_t *W_dev, hipStream_t st);
 
 size_t count_mismatch(const fe_t *a_dev, const fe_t *b_dev /* or nullptr: compare with 0 */, size_t n, hipStream_t st);
 

@@ -320,6 +320,119 @@ __global__ void k_count_mismatch(const fe_t *__restrict__ a, const fe_t *__restr
     if (bad) atomicAdd(count, 1u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// lookup arguments (log-derivative), src/plonk/lookup.rs
+// ---------------------------------------------------------------------------------------------
+// evaluate_m (lookup.rs:275-303): m[i] = #{ j : l[j] == t[i] } for the FIRST row i holding a given table value,
+// 0 for its repeats.  The reference builds a HashMap over l and walks t serially; here t is inserted into an
+// open-addressing table (slot = row index of the smallest row with that value, resolved with atomicMin so the
+// result does not depend on scheduling), l is counted into the slots, and every row of t reads its slot back.
+// Values compare by their Montgomery limbs (a bijection of the canonical form `to_repr` the reference hashes).
+constexpr uint32_t M_EMPTY = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t fe_hash(const fe_t &x) {
+    uint32_t h = 0x9E3779B9u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h ^= x.v[i];
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 15;
+    }
+    return h;
+}
+__global__ void k_m_insert(const fe_t *__restrict__ t, uint32_t n, uint32_t *__restrict__ slot_row, uint32_t mask) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fe_t key = t[i];
+    uint32_t s = fe_hash(key) & mask;
+    for (;;) {
+        uint32_t cur = atomicCAS(&slot_row[s], M_EMPTY, i);
+        if (cur == M_EMPTY) return;
+        if (Fr::eq(t[cur], key)) { atomicMin(&slot_row[s], i); return; }
+        s = (s + 1) & mask;
+    }
+}
+__global__ void k_m_count(const fe_t *__restrict__ l, uint32_t n, const fe_t *__restrict__ t, const uint32_t *__restrict__ slot_row,
+                          uint32_t *__restrict__ slot_cnt, uint32_t mask) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const fe_t key = l[j];
+    uint32_t s = fe_hash(key) & mask;
+    for (;;) {
+        uint32_t cur = slot_row[s];
+        if (cur == M_EMPTY) return;                       // value not in the table
+        if (Fr::eq(t[cur], key)) { atomicAdd(&slot_cnt[s], 1u); return; }
+        s = (s + 1) & mask;
+    }
+}
+template <class F>
+__global__ void k_m_emit(const fe_t *__restrict__ t, uint32_t n, const uint32_t *__restrict__ slot_row,
+                         const uint32_t *__restrict__ slot_cnt, uint32_t mask, fe_t *__restrict__ m) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fe_t key = t[i];
+    uint32_t s = fe_hash(key) & mask;
+    for (;;) {
+        uint32_t cur = slot_row[s];
+        if (cur == i || Fr::eq(t[cur], key)) break;     // every row of t was inserted: the probe terminates
+        s = (s + 1) & mask;
+    }
+    uint32_t c = slot_row[s] == i ? slot_cnt[s] : 0u;
+    m[i] = c ? F::from_u64(c) : F::zero();               // F::from_u128(count), lookup.rs:295-300
+}
+
+// evaluate_h_g (lookup.rs:305-317): h = 1 / (l + r), g = m / (t + r), with 1/0 := 0.
+// One field inversion per HG_CHUNK elements (Montgomery's trick); elements of a chunk are blockDim apart, so
+// every load / store is coalesced.  blockIdx.y: 0 -> h, 1 -> g.
+constexpr uint32_t HG_THREADS = 128, HG_CHUNK = 8;
+template <class F>
+__global__ void SRS_KERNEL_BOUNDS(HG_THREADS, 1)
+k_lookup_hg(const fe_t *__restrict__ l, const fe_t *__restrict__ t, const fe_t *__restrict__ m, fe_t r, uint32_t n,
+            fe_t *__restrict__ h, fe_t *__restrict__ g) {
+    const bool is_g = blockIdx.y == 1;
+    const fe_t *__restrict__ src = is_g ? t : l;
+    fe_t *__restrict__ dst = is_g ? g : h;
+    const uint32_t base = blockIdx.x * HG_THREADS * HG_CHUNK + threadIdx.x;
+    fe_t v[HG_CHUNK], pref[HG_CHUNK];
+    uint32_t zero_mask = 0;
+    fe_t acc = F::one();
+#pragma unroll
+    for (uint32_t j = 0; j < HG_CHUNK; ++j) {
+        uint32_t idx = base + j * HG_THREADS;
+        fe_t x = idx < n ? F::add(src[idx], r) : F::one();
+        if (F::is_zero(x)) { zero_mask |= 1u << j; x = F::one(); }
+        v[j] = x;
+        pref[j] = acc;
+        acc = F::mul(acc, x);
+    }
+    fe_t inv = F::inv(acc);
+#pragma unroll
+    for (int j = (int)HG_CHUNK - 1; j >= 0; --j) {
+        uint32_t idx = base + (uint32_t)j * HG_THREADS;
+        fe_t o = F::mul(inv, pref[j]);
+        inv = F::mul(inv, v[j]);
+        if (idx < n) {
+            if ((zero_mask >> j) & 1u) o = F::zero();
+            else if (is_g) o = F::mul(o, m[idx]);
+            dst[idx] = o;
+        }
+    }
+}
+
+// partial sums of a[i] - b[i] (is_sat_log_derivative, src/plonk/mod.rs:366-378): one value per workgroup
+template <class F>
+__global__ void k_sum_diff(const fe_t *__restrict__ a, const fe_t *__restrict__ b, uint32_t n, fe_t *__restrict__ partial) {
+    __shared__ fe_t red[256];
+    fe_t acc = F::zero();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc = F::add(acc, F::sub(a[i], b[i]));
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = F::add(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // out[i] = sum_j coef[j] * W[j][i]   (ProtoGalaxy::fold_witness, protogalaxy/mod.rs:176-210)
 struct LincombArgs {
     const fe_t *w[JMAX];
@@ -507,6 +620,18 @@ static int challenge_in_degree(Ast &ast, size_t idx, size_t degree) {   // expre
 // Expression::homogeneous (src/polynomial/expression.rs:356-429)
 struct Ctx {
     size_t num_selectors, num_fixed, num_advice, num_challenges;
+    size_t num_lookups = 0;     // each adds the 5 fold variables (l, t, m, h, g) after the advice columns
+    size_t num_fold_vars() const { return num_advice + 5 * num_lookups; }   // expression.rs:61-63
+    // Column of fold variable j inside the CONCATENATED witness W[0] || W[1] (|| W[2]).  This is index_map of
+    // PlonkEvalDomain::eval_advice_var (src/plonk/eval.rs:169-201) composed with the round sizes of
+    // ConstraintSystemMetainfo::build (constraint_system_metainfo.rs:58-79): in both the 2-round and the
+    // 3-round layout (l,t,m) of lookup li sits at columns num_advice + 3 li + {0,1,2} and (h,g) at
+    // num_advice + 3 L + 2 li + {0,1}.
+    size_t witness_col(size_t j) const {
+        if (j < num_advice) return j;
+        size_t li = (j - num_advice) / 5, sub = (j - num_advice) % 5;
+        return sub < 3 ? num_advice + li * 3 + sub : num_advice + 3 * num_lookups + li * 2 + (sub - 3);
+    }
 };
 static bool homogeneous(Ast &ast, int r, const Ctx &ctx, int &out, size_t &degree, std::string &err) {
     const Node x = ast.n[r];
@@ -515,8 +640,8 @@ static bool homogeneous(Ast &ast, int r, const Ctx &ctx, int &out, size_t &degre
     case N_POLY: {
         size_t i = (size_t)x.index;
         if (i < ctx.num_selectors + ctx.num_fixed) degree = 0;
-        else if (i < ctx.num_selectors + ctx.num_fixed + ctx.num_advice) degree = 1;
-        else { err = "unknown query index " + std::to_string(i) + " (lookups are not supported)"; return false; }
+        else if (i < ctx.num_selectors + ctx.num_fixed + ctx.num_fold_vars()) degree = 1;   // Advice | Lookup
+        else { err = "unknown query index " + std::to_string(i); return false; }
         out = r;
         return true;
     }
@@ -696,8 +821,8 @@ struct Compiler {
             int col;
             if (i < ctx.num_selectors) { op = I_LD_SEL; col = (int)i; }
             else if (i < ctx.num_selectors + ctx.num_fixed) { op = I_LD_FIX; col = (int)(i - ctx.num_selectors); }
-            else if (i < ctx.num_selectors + ctx.num_fixed + ctx.num_advice) { op = I_LD_ADV; col = (int)(i - ctx.num_selectors - ctx.num_fixed); }
-            else { err = "column index out of range"; v = known(f.zero()); break; }
+            else if (i < ctx.num_selectors + ctx.num_fixed + ctx.num_fold_vars()) { op = I_LD_ADV; col = (int)ctx.witness_col(i - ctx.num_selectors - ctx.num_fixed); }
+            else { err = "column index " + std::to_string(i) + " out of range"; v = known(f.zero()); break; }
             auto key = std::make_tuple(op, col, (int)x.rot);
             auto c = r_cse.find(key);
             if (c != r_cse.end()) { v = rowv(c->second); break; }
@@ -821,6 +946,9 @@ struct Structure {
     Program cross;                 // homogeneous expression, fold mode
     Program plain_compressed;      // compressed expression, single witness (decider, plonk/mod.rs:328)
     Program plain_homogeneous;     // homogeneous expression, single witness (decider, sangria/mod.rs:351)
+    size_t num_lookups = 0;        // lookup arguments (src/plonk/lookup.rs:72-82); 5 fold variables each
+    bool has_vector_lookup = false;
+    std::vector<Program> lookup_progs;   // lookup_polys L_i then table_polys T_i (LookupEvalDomain: advice columns, challenges = [r])
     std::vector<Program> gate_progs;   // S.gates one by one (ProtoGalaxy leaves, plonk/mod.rs:697-701)
     size_t max_gate_degree = 0;    // max_i gates[i].degree()  (get_points_count, poly/mod.rs:535-545)
     GateProg *d_gate_progs = nullptr;
@@ -893,12 +1021,15 @@ static void upload_program(Program &p, Structure &S) {
 
 Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed, size_t num_advice,
                   const uint8_t *const *selectors, const fe_t *const *fixed, int space_device,
-                  const uint64_t *gates, size_t gates_words, size_t num_gates, int &rc, std::string &err) {
+                  const uint64_t *gates, size_t gates_words, size_t num_gates, size_t num_lookups, bool has_vector_lookup,
+                  const uint64_t *lookup_exprs, size_t lookup_words, int &rc, std::string &err) {
     rc = 4;
     FieldOps f{field};
     Ast ast;
-    std::vector<int> roots;
+    std::vector<int> roots, lroots;
     if (!parse_gates(gates, gates_words, num_gates, ast, roots, err)) return nullptr;
+    if (num_lookups && !parse_gates(lookup_exprs, lookup_words, 2 * num_lookups, ast, lroots, err)) return nullptr;
+    if (!num_lookups && has_vector_lookup) { err = "has_vector_lookup without lookups"; return nullptr; }
     if (num_selectors + num_fixed == 0) { err = "Fixed & Selectors can't be empty in one time"; return nullptr; }   // eval.rs:47-54
     std::unique_ptr<Structure> S(new Structure());
     S->field = field;
@@ -907,9 +1038,13 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     S->num_selectors = num_selectors;
     S->num_fixed = num_fixed;
     S->num_advice = num_advice;
-    // ConstraintSystemMetainfo::build with no lookups: ctx.num_challenges starts at 0
+    S->num_lookups = num_lookups;
+    S->has_vector_lookup = has_vector_lookup;
+    // ConstraintSystemMetainfo::build: the gate-compression challenge comes after the lookup challenges
+    // (r1 [, r2]), i.e. ctx.num_challenges starts at 2 / 1 / 0
     // (src/table/constraint_system_metainfo.rs:81-97) -> CompressedGates::new (src/plonk/mod.rs:84-107)
-    Ctx ctx{num_selectors, num_fixed, num_advice, 0};
+    Ctx ctx{num_selectors, num_fixed, num_advice, has_vector_lookup ? (size_t)2 : (num_lookups ? (size_t)1 : (size_t)0)};
+    ctx.num_lookups = num_lookups;
     int compressed = compress(ast, roots, ctx.num_challenges, f);
     ctx.num_challenges = num_challenges(ast, compressed);
     S->s_num_challenges = ctx.num_challenges;
@@ -931,8 +1066,16 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         if (!build_program(ast, roots[g], f, ctx, false, S->gate_progs[g], err)) { rc = 7; return nullptr; }
         S->max_gate_degree = std::max(S->max_gate_degree, expr_degree(ast, roots[g], ctx));
     }
+    // lookup / table polynomials see the advice COLUMNS only (LookupEvalDomain, src/plonk/eval.rs:106-134)
+    {
+        Ctx lctx{num_selectors, num_fixed, num_advice, 0};
+        S->lookup_progs.resize(lroots.size());
+        for (size_t i = 0; i < lroots.size(); ++i)
+            if (!build_program(ast, lroots[i], f, lctx, false, S->lookup_progs[i], err)) { rc = 7; return nullptr; }
+    }
     // ---- device residency: programs, fixed columns, selectors
     rc = 5;
+    for (auto &lp : S->lookup_progs) upload_program(lp, *S);
     upload_program(S->cross, *S);
     upload_program(S->plain_compressed, *S);
     upload_program(S->plain_homogeneous, *S);
@@ -975,6 +1118,8 @@ void destroy(Structure *S) {
 size_t degree(const Structure *S) { return S->degree; }
 size_t num_challenges(const Structure *S) { return S->s_num_challenges; }
 size_t num_advice(const Structure *S) { return S->num_advice; }
+size_t num_witness_columns(const Structure *S) { return S->num_advice + 5 * S->num_lookups; }
+size_t num_lookups(const Structure *S) { return S->num_lookups; }
 size_t rows(const Structure *S) { return S->rows; }
 int field(const Structure *S) { return S->field; }
 
@@ -1027,10 +1172,16 @@ const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spe
 
 // mode 0: cross terms (needs W2), outputs `degree` vectors; mode 1/2: plain evaluation of the
 // compressed / homogeneous expression on W1, one output vector.
+static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host,
+                         size_t n_ch, fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err);
 int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host, size_t n_ch,
              fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err) {
-    FieldOps f{S->field};
     Program &p = mode == 0 ? S->cross : (mode == 1 ? S->plain_compressed : S->plain_homogeneous);
+    return evaluate_prog(S, p, mode, W1_dev, W2_dev, challenges_host, n_ch, out_dev_ptrs_host, st, err);
+}
+static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host,
+                         size_t n_ch, fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err) {
+    FieldOps f{S->field};
     const uint32_t d = mode == 0 ? (uint32_t)S->degree : 0;
     const uint32_t npts = mode == 0 ? d + 1 : 1;
     const uint32_t nout = mode == 0 ? d : 1;
@@ -1335,6 +1486,84 @@ size_t count_mismatch(const fe_t *a_dev, const fe_t *b_dev, size_t n, hipStream_
     SRS_HIP_CHECK(hipStreamSynchronize(st));
     (void)hipFree(d);
     return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lookup arguments: host side
+// ---------------------------------------------------------------------------------------------
+// Arguments::evaluate_coefficient_1 (src/plonk/lookup.rs:319-341): ls[i] = L_i(row), ts[i] = T_i(row), ms[i].
+// advice_dev: the advice columns, column-major num_advice * rows; outputs: HOST arrays of L DEVICE vectors.
+int lookup_coeff_1(Structure *S, const fe_t *advice_dev, const fe_t &r, fe_t *const *ls, fe_t *const *ts, fe_t *const *ms,
+                   hipStream_t st, std::string &err) {
+    const size_t L = S->num_lookups;
+    if (!L) { err = "structure has no lookup arguments"; return 4; }    // SpsError::LackOfLookupArguments
+    const uint32_t n = (uint32_t)S->rows;
+    for (size_t i = 0; i < 2 * L; ++i) {
+        fe_t *outs[1] = {i < L ? ls[i] : ts[i - L]};
+        int rc = evaluate_prog(S, S->lookup_progs[i], 1, advice_dev, nullptr, &r, 1, outs, st, err);
+        if (rc) return rc;
+    }
+    uint32_t cap = 2;
+    while (cap < 2 * n) cap <<= 1;
+    uint32_t *d_row = nullptr, *d_cnt = nullptr;
+    SRS_HIP_CHECK(hipMalloc((void **)&d_row, (size_t)cap * 2 * sizeof(uint32_t)));
+    d_cnt = d_row + cap;
+    try {
+        const uint32_t blocks = (n + 255) / 256;
+        for (size_t i = 0; i < L; ++i) {
+            prof::Scope ps("lookup_m", st, n);
+            SRS_HIP_CHECK(hipMemsetAsync(d_row, 0xFF, (size_t)cap * sizeof(uint32_t), st));
+            SRS_HIP_CHECK(hipMemsetAsync(d_cnt, 0, (size_t)cap * sizeof(uint32_t), st));
+            SRS_LAUNCH(k_m_insert, (blocks), (256), 0, st, (const fe_t *)ts[i], n, d_row, cap - 1);
+            SRS_LAUNCH(k_m_count, (blocks), (256), 0, st, (const fe_t *)ls[i], n, (const fe_t *)ts[i], (const uint32_t *)d_row, d_cnt, cap - 1);
+            if (S->field == 0) SRS_LAUNCH((k_m_emit<Fr>), (blocks), (256), 0, st, (const fe_t *)ts[i], n, (const uint32_t *)d_row, (const uint32_t *)d_cnt, cap - 1, ms[i]);
+            else SRS_LAUNCH((k_m_emit<Fq>), (blocks), (256), 0, st, (const fe_t *)ts[i], n, (const uint32_t *)d_row, (const uint32_t *)d_cnt, cap - 1, ms[i]);
+        }
+        SRS_HIP_CHECK(hipStreamSynchronize(st));
+        SRS_HIP_CHECK(hipGetLastError());
+    } catch (...) { (void)hipFree(d_row); throw; }
+    (void)hipFree(d_row);
+    prof::collect();
+    return 0;
+}
+
+// Arguments::evaluate_h_g (lookup.rs:305-317) for one lookup: h = 1/(l + r), g = m/(t + r)
+void lookup_coeff_2(int field, const fe_t *l, const fe_t *t, const fe_t *m, const fe_t &r, size_t n, fe_t *h, fe_t *g, hipStream_t st) {
+    if (!n) return;
+    prof::Scope ps("lookup_hg", st, n);
+    const uint32_t gx = (uint32_t)((n + HG_THREADS * HG_CHUNK - 1) / (HG_THREADS * HG_CHUNK));
+    if (field == 0) SRS_LAUNCH((k_lookup_hg<Fr>), (gx, 2), (HG_THREADS), 0, st, l, t, m, r, (uint32_t)n, h, g);
+    else SRS_LAUNCH((k_lookup_hg<Fq>), (gx, 2), (HG_THREADS), 0, st, l, t, m, r, (uint32_t)n, h, g);
+}
+
+// PlonkStructure::is_sat_log_derivative (src/plonk/mod.rs:366-398) on the concatenated witness:
+// number of lookups i whose sum_row (h_i - g_i) != 0; h_i / g_i are columns 2 i / 2 i + 1 of the LAST round.
+size_t log_derivative_mismatches(Structure *S, const fe_t *W_dev, hipStream_t st) {
+    const size_t L = S->num_lookups;
+    if (!L) return 0;
+    FieldOps f{S->field};
+    const uint32_t n = (uint32_t)S->rows, blocks = std::min<uint32_t>((n + 255) / 256, 256);
+    const fe_t *last = W_dev + (S->num_advice + 3 * L) * S->rows;
+    fe_t *d_part = nullptr;
+    SRS_HIP_CHECK(hipMalloc((void **)&d_part, L * blocks * sizeof(fe_t)));
+    std::vector<fe_t> part(L * blocks);
+    try {
+        for (size_t i = 0; i < L; ++i) {
+            const fe_t *h = last + (2 * i) * S->rows, *g = last + (2 * i + 1) * S->rows;
+            if (S->field == 0) SRS_LAUNCH((k_sum_diff<Fr>), (blocks), (256), 0, st, h, g, n, d_part + i * blocks);
+            else SRS_LAUNCH((k_sum_diff<Fq>), (blocks), (256), 0, st, h, g, n, d_part + i * blocks);
+        }
+        SRS_HIP_CHECK(hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+        SRS_HIP_CHECK(hipStreamSynchronize(st));
+    } catch (...) { (void)hipFree(d_part); throw; }
+    (void)hipFree(d_part);
+    size_t bad = 0;
+    for (size_t i = 0; i < L; ++i) {
+        fe_t acc = f.zero();
+        for (uint32_t b = 0; b < blocks; ++b) acc = f.add(acc, part[i * blocks + b]);
+        if (!f.is_zero(acc)) ++bad;
+    }
+    return bad;
 }
 
 int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err) {

@@ -49,6 +49,50 @@ def serialize_gates(exprs, field):
     return np.array(words, dtype=np.uint64)
 
 
+def compress_expression(exprs, challenge_index):
+    """src/plonk/util.rs:34-56: fold(0, |acc, e| e + acc * y), y = Challenge(challenge_index); a single expression is kept."""
+    y = Challenge(challenge_index)
+    if len(exprs) > 1:
+        acc = Constant(0)
+        for ex in exprs:
+            acc = Sum(ex, Product(acc, y))
+        return acc
+    return exprs[0] if exprs else Constant(0)
+
+
+class LookupArguments:
+    """`plonk::lookup::Arguments` (src/plonk/lookup.rs:72-206): the expression-building half of the log-derivative
+    lookup argument.  `lookups` = [(input_expressions, table_expressions), ...] as Sirius expressions
+    (halo2 expressions after Expression::from_halo2_expr)."""
+
+    def __init__(self, lookups):
+        lens = [len(inp) for inp, _ in lookups]
+        if not lens or max(lens) == 0:
+            raise ValueError("no lookup arguments")            # compress_from returns None (:87-93)
+        self.has_vector_lookup = max(lens) > 1
+        # vector lookups are compressed with r1 = Challenge(0)  (:97-121, compress_halo2_expression util.rs:12-32)
+        self.lookup_polys = [compress_expression(list(inp), 0) for inp, _ in lookups]
+        self.table_polys = [compress_expression(list(tab), 0) for _, tab in lookups]
+
+    @property
+    def num_lookups(self):
+        return len(self.lookup_polys)
+
+    def to_expressions(self, num_selectors, num_fixed, num_advice):
+        """vanishing_lookup_polys ++ log_derivative_lhs_and_rhs (:129-206); fold variables (l,t,m,h,g) of lookup i
+        are query indices offset + 5 i + {0..4}."""
+        off = num_selectors + num_fixed + num_advice
+        var = lambda i, j: Polynomial(off + 5 * i + j)
+        out = [Sum(L, Negated(var(i, 0))) for i, L in enumerate(self.lookup_polys)]
+        out += [Sum(T, Negated(var(i, 1))) for i, T in enumerate(self.table_polys)]
+        r = Challenge(1 if self.has_vector_lookup else 0)
+        for i in range(self.num_lookups):
+            l, t, m, h, g = [var(i, j) for j in range(5)]
+            out.append(Sum(Product(h, Sum(l, r)), Negated(Constant(1))))       # h (l + r) - 1
+            out.append(Sum(Product(g, Sum(t, r)), Negated(m)))                 # g (t + r) - m
+        return out
+
+
 def main_gate(T, num_selectors=0, fixed_offset=0, advice_offset=0, num_fixed_total=None):
     """The polynomial of `MainGate<T>::configure` (reference src/main_gate.rs:535-583):
       q_m[0]*s[0]*s[1] + q_m[1]*s[2]*s[3] + sum_i q_1[i]*s[i] + sum_i q_5[i]*s[i]^5 + rc + q_i*input + q_o*out

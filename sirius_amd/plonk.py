@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib as L
 from .commitment import _buf, _is_torch, _stream
-from .expression import serialize_gates
+from .expression import LookupArguments, serialize_gates
 
 
 def _alloc_like(ref, rows):
@@ -22,25 +22,61 @@ def _alloc_like(ref, rows):
     return np.zeros((rows, 4), dtype=np.uint64)
 
 
-class PlonkStructure:
-    """k, selectors, fixed_columns, num_advice_columns, gates  (no lookups, src/plonk/mod.rs:127-157)."""
+def _cat_rounds(W):
+    """PlonkWitness::W (a list of round vectors) -> the concatenated vector the library addresses; a single
+    vector passes through."""
+    if not isinstance(W, (list, tuple)):
+        return W
+    if len(W) == 1:
+        return W[0]
+    if _is_torch(W[0]):
+        import torch
+        return torch.cat([w.reshape(-1, 4) for w in W], dim=0)
+    return np.ascontiguousarray(np.concatenate([np.asarray(w, dtype=np.uint64).reshape(-1, 4) for w in W], axis=0))
 
-    def __init__(self, field, k, selectors, fixed_columns, num_advice_columns, gates):
+
+class PlonkStructure:
+    """k, selectors, fixed_columns, num_advice_columns, gates, lookup arguments  (src/plonk/mod.rs:127-157).
+
+    `gates` are the custom gates; `lookups` = [(input_expressions, table_expressions), ...] (or None).  As
+    ConstraintSystemMetainfo::build does (src/table/constraint_system_metainfo.rs:27-97), the lookup expressions are
+    appended to `self.gates` and `round_sizes` is derived."""
+
+    def __init__(self, field, k, selectors, fixed_columns, num_advice_columns, gates, lookups=None):
         self.field, self.k, self.num_advice_columns = field, k, num_advice_columns
         rows = 1 << k
         sel = [np.ascontiguousarray(s, dtype=np.uint8) for s in selectors]
         fix = [np.ascontiguousarray(f, dtype=np.uint64) for f in fixed_columns]
         assert all(s.shape == (rows,) for s in sel) and all(f.shape == (rows, 4) for f in fix)
         self.num_selectors, self.num_fixed = len(sel), len(fix)
-        words = serialize_gates(gates, field)
         selp = (C.c_void_p * max(len(sel), 1))(*[s.ctypes.data for s in sel])
         fixp = (C.c_void_p * max(len(fix), 1))(*[f.ctypes.data for f in fix])
         h = C.c_void_p()
-        L.check(L.lib().srs_structure_create(field, k, len(sel), len(fix), num_advice_columns, selp, fixp, L.SPACE_HOST,
-                                             words.ctypes.data, len(words), len(gates), C.byref(h)))
+        self.lookup_arguments = LookupArguments(lookups) if lookups else None
+        if self.lookup_arguments is None:
+            self.gates = list(gates)
+            self.num_lookups, self.has_vector_lookup = 0, False
+            self.round_sizes = [num_advice_columns * rows]
+            words = serialize_gates(self.gates, field)
+            L.check(L.lib().srs_structure_create(field, k, len(sel), len(fix), num_advice_columns, selp, fixp, L.SPACE_HOST,
+                                                 words.ctypes.data, len(words), len(self.gates), C.byref(h)))
+        else:
+            la = self.lookup_arguments
+            self.gates = list(gates) + la.to_expressions(len(sel), len(fix), num_advice_columns)
+            self.num_lookups, self.has_vector_lookup = la.num_lookups, la.has_vector_lookup
+            nl = la.num_lookups
+            self.round_sizes = ([num_advice_columns * rows, 3 * nl * rows, 2 * nl * rows] if la.has_vector_lookup
+                                else [(num_advice_columns + 3 * nl) * rows, 2 * nl * rows])
+            words = serialize_gates(self.gates, field)
+            lwords = serialize_gates(la.lookup_polys + la.table_polys, field)
+            L.check(L.lib().srs_structure_create_lookup(field, k, len(sel), len(fix), num_advice_columns, selp, fixp,
+                                                        L.SPACE_HOST, words.ctypes.data, len(words), len(self.gates), nl,
+                                                        1 if la.has_vector_lookup else 0, lwords.ctypes.data, len(lwords),
+                                                        C.byref(h)))
         self._h = h
         self.num_challenges = L.lib().srs_structure_num_challenges(h)
         self.num_cross_terms = L.lib().srs_structure_num_cross_terms(h)
+        self.num_witness_columns = L.lib().srs_structure_num_witness_columns(h)
 
     @property
     def rows(self):
@@ -60,8 +96,9 @@ class PlonkStructure:
     def eval_gates(self, W, challenges, homogeneous=False):
         """Per-row gate value; homogeneous=False: compressed gate, challenges = U.challenges;
         homogeneous=True: challenges = U.challenges || U.u."""
+        W = _cat_rounds(W)
         addr, space, n, keep = _buf(W, 4)
-        assert n == self.num_advice_columns * self.rows
+        assert n == self.num_witness_columns * self.rows
         ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4)
         out = _alloc_like(W, self.rows)
         oaddr = out.data_ptr() if _is_torch(out) else out.ctypes.data
@@ -73,8 +110,9 @@ class PlonkStructure:
         """Mismatch count of the deciders' gate check: E is None -> compressed gate == 0 per row
         (PlonkStructure::is_sat, src/plonk/mod.rs:329-346, challenges = U.challenges); otherwise homogeneous
         gate == E[row] (is_sat_accumulation, src/nifs/sangria/mod.rs:352-376, challenges = U.challenges || U.u)."""
+        W = _cat_rounds(W)
         addr, space, n, keep = _buf(W, 4)
-        assert n == self.num_advice_columns * self.rows
+        assert n == self.num_witness_columns * self.rows
         ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1, 4)
         eaddr = None
         if E is not None:
@@ -83,6 +121,44 @@ class PlonkStructure:
         cnt = C.c_size_t()
         L.check(L.lib().srs_is_sat_gates(self._h, 0 if E is None else 1, addr, ch.ctypes.data, ch.shape[0], eaddr, space,
                                          _stream(), C.byref(cnt)))
+        return cnt.value
+
+    # ---- lookup arguments (src/plonk/lookup.rs) ----
+    def lookup_coeff_1(self, advice, r):
+        """Arguments::evaluate_coefficient_1 (lookup.rs:319-341) -> (ls, ts, ms), each a list of num_lookups vectors.
+        advice: the advice columns (num_advice * 2^k, column-major); r: the challenge the vector lookups are
+        compressed with (r1 in run_sps_protocol_3, 0 in run_sps_protocol_2, plonk/mod.rs:515,618)."""
+        addr, space, n, keep = _buf(advice, 4)
+        assert n == self.num_advice_columns * self.rows and self.num_lookups > 0
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        outs = [[_alloc_like(advice, self.rows) for _ in range(self.num_lookups)] for _ in range(3)]
+        ptrs = [(C.c_void_p * self.num_lookups)(*[(v.data_ptr() if _is_torch(v) else v.ctypes.data) for v in vs]) for vs in outs]
+        L.check(L.lib().srs_lookup_coeff_1(self._h, addr, r.ctypes.data, space, _stream(), ptrs[0], ptrs[1], ptrs[2]))
+        return tuple(outs)
+
+    def lookup_coeff_2(self, ls, ts, ms, r):
+        """ArgumentCoefficient1::evaluate_coefficient_2 (lookup.rs:350-365) -> (hs, gs)."""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        hs, gs = [], []
+        for l, t, m in zip(ls, ts, ms):
+            (al, space, n, _), (at, s2, n2, _), (am, s3, n3, _) = _buf(l, 4), _buf(t, 4), _buf(m, 4)
+            assert space == s2 == s3 and n == n2 == n3
+            h, g = _alloc_like(l, n), _alloc_like(l, n)
+            L.check(L.lib().srs_lookup_coeff_2(self.field, al, at, am, r.ctypes.data, n, space, _stream(),
+                                               h.data_ptr() if _is_torch(h) else h.ctypes.data,
+                                               g.data_ptr() if _is_torch(g) else g.ctypes.data))
+            hs.append(h)
+            gs.append(g)
+        return hs, gs
+
+    def is_sat_log_derivative(self, W):
+        """Number of lookups violating sum_row (h_i - g_i) == 0 (PlonkStructure::is_sat_log_derivative,
+        src/plonk/mod.rs:366-398); 0 <=> satisfied."""
+        W = _cat_rounds(W)
+        addr, space, n, keep = _buf(W, 4)
+        assert n == self.num_witness_columns * self.rows
+        cnt = C.c_size_t()
+        L.check(L.lib().srs_is_sat_log_derivative(self._h, addr, space, _stream(), C.byref(cnt)))
         return cnt.value
 
 
@@ -102,9 +178,10 @@ class VanillaFS:
         """-> (cross_terms: list of d vectors, cross_term_commits: (d, 8) affine points).
         With ck=None only the evaluation half runs (commits = None)."""
         ch = VanillaFS.cross_term_challenges(U1_challenges, U1_u, U2_challenges, S.field)
+        W1, W2 = _cat_rounds(W1), _cat_rounds(W2)
         a1, space, n1, k1 = _buf(W1, 4)
         a2, space2, n2, k2 = _buf(W2, 4)
-        assert space == space2 and n1 == n2 == S.num_advice_columns * S.rows
+        assert space == space2 and n1 == n2 == S.num_witness_columns * S.rows
         d = S.num_cross_terms
         terms = [_alloc_like(W1, S.rows) for _ in range(d)] if (want_terms or ck is None) else None
         tp = None

@@ -99,3 +99,10 @@ def test_emu_protogalaxy_fold_identity(emu, oracle):
     from test_protogalaxy_gpu import _pg_fold_identity
     _pg_fold_identity(emu, oracle, 4, (5, 3), True)
     _pg_fold_identity(emu, oracle, 3, (2,), False)
+
+
+def test_emu_lookup_arguments(emu, oracle):
+    from lookup_cases import run_lookup_case
+    run_lookup_case(emu, oracle, "vector", 5)
+    run_lookup_case(emu, oracle, "scalar", 4)
+    run_lookup_case(emu, oracle, "two", 4)
