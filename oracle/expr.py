@@ -240,6 +240,7 @@ class GraphEvaluator:                      # graph_evaluator.rs:166-351
         self.constants = [0, 1, 2]         # :186
         self.rotations = []
         self.calcs = []                    # (calc tuple, target)
+        self._index = {}                   # calc tuple -> target (same "first equal entry" as the reference's linear scan)
         self.num_intermediates = 0
         vs = self.add_expression(expr)
         self.add_calculation((OP_STORE, vs, None))
@@ -258,11 +259,12 @@ class GraphEvaluator:                      # graph_evaluator.rs:166-351
         return (K_CONST, len(self.constants) - 1)
 
     def add_calculation(self, calc):
-        for c, target in self.calcs:
-            if c == calc:
-                return (K_INTER, target)
+        hit = self._index.get(calc)
+        if hit is not None:
+            return (K_INTER, hit)
         target = self.num_intermediates
         self.calcs.append((calc, target))
+        self._index[calc] = target
         self.num_intermediates += 1
         return (K_INTER, target)
 

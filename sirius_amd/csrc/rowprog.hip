@@ -37,7 +37,8 @@ namespace rowprog {
 enum : uint32_t { I_LD_SEL = 0, I_LD_FIX, I_LD_ADV, I_ADD, I_SUB, I_MUL, I_SQR, I_DBL, I_NEG };
 constexpr uint32_t UNIFORM_BIT = 0x80000000u;
 constexpr uint32_t RP_THREADS = 128;
-constexpr uint32_t DMAX = 8;   // cross terms kept in VGPRs; larger degrees are rejected at create time
+constexpr uint32_t DMAX = 8;   // cross terms kept in VGPRs per pass; higher degrees take ceil(d / 8) passes over the points
+constexpr uint32_t DEGREE_LIMIT = 255;   // evaluation points 0..d must stay < 2^8 (small_times)
 
 constexpr uint32_t JMAX = 4;   // witnesses combined by one advice load (cross terms: 2; ProtoGalaxy G: L + 1 <= 4)
 
@@ -69,7 +70,7 @@ template <class F>
 __device__ __forceinline__ fe_t small_times(const fe_t &x, uint32_t j) {   // j * x for a tiny j
     fe_t acc = F::zero();
     bool any = false;
-    for (int b = 4; b >= 0; --b) {
+    for (int b = j < 32u ? 4 : 7; b >= 0; --b) {
         if (any) acc = F::dbl(acc);
         if ((j >> b) & 1u) {
             acc = any ? F::add(acc, x) : x;
@@ -463,7 +464,7 @@ struct FoldEArgs {
     uint32_t n_terms;
 };
 template <class F>
-__global__ void k_fold_e(fe_t *__restrict__ out, const fe_t *__restrict__ e, FoldEArgs fa, size_t n) {
+__global__ void k_fold_e(fe_t *out, const fe_t *e, FoldEArgs fa, size_t n) {   // out may alias e
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -1053,7 +1054,7 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     if (!homogeneous(ast, compressed, ctx, homog, degree, err)) { rc = 7; return nullptr; }
     S->h_num_challenges = num_challenges(ast, homog);
     S->degree = degree;
-    if (degree > DMAX) { err = "gate degree " + std::to_string(degree) + " exceeds the supported maximum"; return nullptr; }
+    if (degree > DEGREE_LIMIT) { err = "folding degree " + std::to_string(degree) + " exceeds the supported maximum 255"; return nullptr; }
     if (!build_program(ast, homog, f, ctx, true, S->cross, err) ||
         !build_program(ast, compressed, f, ctx, false, S->plain_compressed, err) ||
         !build_program(ast, homog, f, ctx, false, S->plain_homogeneous, err)) {
@@ -1213,10 +1214,12 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
     a.utab = d_utab;
     a.n_uniform = (uint32_t)nu;
     a.npts = npts;
-    a.d = d;
-    a.vinv = S->d_vinv;
-    a.out = d_out;
-    {
+    // d <= 8: one pass.  Higher folding degrees (many gates compressed with y^(n-1)): every pass evaluates all
+    // d + 1 points again and accumulates the next 8 coefficients (a.d = outputs of THIS pass).
+    for (uint32_t k0 = 0; k0 < (d ? d : 1); k0 += DMAX) {
+        a.d = d ? std::min<uint32_t>(DMAX, d - k0) : 0;
+        a.vinv = S->d_vinv ? S->d_vinv + (size_t)k0 * npts : nullptr;
+        a.out = d_out + k0;
         prof::Scope ps(mode == 0 ? "rowprog_cross_terms" : "rowprog_eval", st, S->rows);
         if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
         else if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);
@@ -1236,20 +1239,24 @@ void fold_w(int field, fe_t *out, const fe_t *w1, const fe_t *w2, const fe_t &r,
 
 int fold_e(int field, fe_t *out, const fe_t *e, const fe_t *const *t_dev_ptrs_host, size_t n_terms, const fe_t &r, size_t n,
            hipStream_t st, std::string &err) {
-    if (n_terms > DMAX) { err = "more than 8 cross terms"; return 4; }
+    (void)err;
     FieldOps f{field};
-    FoldEArgs fa;
-    fa.n_terms = (uint32_t)n_terms;
-    fe_t acc = r;   // r^1, r^2, ...  (accumulator.rs:380-383)
-    for (uint32_t k = 0; k < DMAX; ++k) {
-        fa.t[k] = k < n_terms ? t_dev_ptrs_host[k] : nullptr;
-        fa.rpow[k] = acc;
-        acc = f.mul(acc, r);
-    }
     if (!n) return 0;
     uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, 256 * 16);
-    if (field == 0) SRS_LAUNCH((k_fold_e<Fr>), (blocks), (256), 0, st, out, e, fa, n);
-    else SRS_LAUNCH((k_fold_e<Fq>), (blocks), (256), 0, st, out, e, fa, n);
+    fe_t acc = r;   // r^1, r^2, ...  (accumulator.rs:380-383)
+    const fe_t *src = e;
+    for (size_t k0 = 0; k0 == 0 || k0 < n_terms; k0 += DMAX) {      // 8 terms per launch; later launches accumulate onto out
+        FoldEArgs fa;
+        fa.n_terms = (uint32_t)std::min<size_t>(DMAX, n_terms - k0);
+        for (uint32_t k = 0; k < DMAX; ++k) {
+            fa.t[k] = k < fa.n_terms ? t_dev_ptrs_host[k0 + k] : nullptr;
+            fa.rpow[k] = acc;
+            if (k < fa.n_terms) acc = f.mul(acc, r);
+        }
+        if (field == 0) SRS_LAUNCH((k_fold_e<Fr>), (blocks), (256), 0, st, out, src, fa, n);
+        else SRS_LAUNCH((k_fold_e<Fq>), (blocks), (256), 0, st, out, src, fa, n);
+        src = out;
+    }
     return 0;
 }
 

@@ -106,3 +106,9 @@ def test_emu_lookup_arguments(emu, oracle):
     run_lookup_case(emu, oracle, "vector", 5)
     run_lookup_case(emu, oracle, "scalar", 4)
     run_lookup_case(emu, oracle, "two", 4)
+
+
+def test_emu_high_folding_degree(emu, oracle):
+    from test_sangria_gpu import _high_degree_case
+    _high_degree_case(emu, oracle, 0, 3, 10)
+    _high_degree_case(emu, oracle, 1, 3, 12)

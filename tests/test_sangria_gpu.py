@@ -252,3 +252,77 @@ def _fold_then_decide(S, O, field, curve, k, gate_T):
 def test_fold_then_decider(srs, oracle):
     _fold_then_decide(srs, oracle, 0, 0, 7, (5, 3))     # primary: bn256 / Fr, 2 gates (challenge y folds too)
     _fold_then_decide(srs, oracle, 1, 1, 6, (5,))       # secondary: grumpkin / Fq
+
+
+def _high_degree_case(S, O, field, k, n_gates):
+    """Folding degree above 8 (n gates compressed with y^(n-1): degree = 2 + n - 1): the cross terms take several
+    passes over the evaluation points, the error fold several launches.  Checked against the reference's symbolic
+    GroupedPoly route and through fold-then-decide."""
+    from workloads import rand_fe
+    X = S.expression
+    rows = 1 << k
+    rng = np.random.default_rng(n_gates * 7 + k)
+    nfix, nadv = n_gates, 3
+    mk = lambda M, i: M.Prod(M.Poly(i), M.Sum(M.Prod(M.Poly(nfix), M.Poly(nfix + 1, 1 if i % 3 == 0 else 0)), M.Neg(M.Poly(nfix + 2)))) \
+        if hasattr(M, "Poly") else M.Product(M.Polynomial(i), M.Sum(M.Product(M.Polynomial(nfix), M.Polynomial(nfix + 1, 1 if i % 3 == 0 else 0)), M.Negated(M.Polynomial(nfix + 2))))
+    og = [mk(OE, i) for i in range(n_gates)]
+    pg = [mk(X, i) for i in range(n_gates)]
+    fixed = [rand_fe(rng, rows, 0.5) for _ in range(nfix)]
+    W1, W2 = rand_fe(rng, nadv * rows), rand_fe(rng, nadv * rows)
+    St = S.PlonkStructure(field, k, [], fixed, nadv, pg)
+    assert St.num_cross_terms == n_gates + 1 and St.num_challenges == 1
+    u1c, u1u, u2c = rand_fe(rng, 1), rand_fe(rng, 1)[0], rand_fe(rng, 1)
+    terms, _ = S.VanillaFS.commit_cross_terms(None, St, u1c, u1u, W1, u2c, W2)
+    ch = S.VanillaFS.cross_term_challenges(u1c, u1u, u2c, field)
+    cg, exp = OE.cross_terms_oracle(O, field, og, 0, nfix, nadv, [], fixed, W1, W2, ch)
+    assert len(terms) == cg.degree == n_gates + 1
+    for a, b in zip(terms, exp):
+        assert np.array_equal(a, b)
+    r, E = rand_fe(rng, 1)[0], rand_fe(rng, rows)
+    acc = S.RelaxedPlonkWitness(field, [W1], E).fold([W2], terms, r)
+    assert np.array_equal(acc.E, O.fold_e(field, E, exp, r))
+    # definition of the cross terms: P_hom(fold) == P_hom(W1) + sum r^k T_k
+    one = O.ints_to_mont(field, [1])[0]
+    ch1 = np.concatenate([u1c.reshape(-1, 4), u1u.reshape(1, 4)])
+    ch2 = np.concatenate([u2c.reshape(-1, 4), one.reshape(1, 4)])
+    chf = O.fe_add(field, ch1, O.fe_mul(field, np.broadcast_to(r, ch2.shape).copy(), ch2))
+    p0 = St.eval_gates(W1, ch1, homogeneous=True)
+    rhs = S.RelaxedPlonkWitness(field, [], p0).fold([], terms, r).E
+    assert St.is_sat_gates(acc.W[0], chf, rhs) == 0
+    St.close()
+
+
+def test_high_folding_degree(srs, oracle):
+    _high_degree_case(srs, oracle, 0, 6, 10)      # degree 11: two passes
+    _high_degree_case(srs, oracle, 1, 8, 14)      # degree 15
+    # (the symbolic oracle grows exponentially with the gate count; 17+ gates = three passes run in the emulator-free
+    #  property test below)
+    _high_degree_props(srs, oracle, 0, 10, 30)
+
+
+def _high_degree_props(S, O, field, k, n_gates):
+    """degree 31 (four passes) without the symbolic oracle: the defining identity of the cross terms."""
+    from workloads import rand_fe
+    X = S.expression
+    rows = 1 << k
+    rng = np.random.default_rng(n_gates)
+    nfix, nadv = n_gates, 3
+    pg = [X.Product(X.Polynomial(i), X.Sum(X.Product(X.Polynomial(nfix), X.Polynomial(nfix + 1)), X.Negated(X.Polynomial(nfix + 2))))
+          for i in range(n_gates)]
+    fixed = [rand_fe(rng, rows, 0.5) for _ in range(nfix)]
+    W1, W2 = rand_fe(rng, nadv * rows), rand_fe(rng, nadv * rows)
+    St = S.PlonkStructure(field, k, [], fixed, nadv, pg)
+    assert St.num_cross_terms == n_gates + 1
+    u1c, u1u, u2c = rand_fe(rng, 1), rand_fe(rng, 1)[0], rand_fe(rng, 1)
+    terms, _ = S.VanillaFS.commit_cross_terms(None, St, u1c, u1u, W1, u2c, W2)
+    one = O.ints_to_mont(field, [1])[0]
+    ch1 = np.concatenate([u1c.reshape(-1, 4), u1u.reshape(1, 4)])
+    ch2 = np.concatenate([u2c.reshape(-1, 4), one.reshape(1, 4)])
+    for _ in range(2):
+        r = rand_fe(rng, 1)[0]
+        acc = S.RelaxedPlonkWitness(field, [W1], St.eval_gates(W1, ch1, homogeneous=True)).fold([W2], terms, r)
+        chf = O.fe_add(field, ch1, O.fe_mul(field, np.broadcast_to(r, ch2.shape).copy(), ch2))
+        assert St.is_sat_gates(acc.W[0], chf, acc.E) == 0
+    # the last term is P_hom(W2, ch2) itself (coefficient of X^d)
+    assert np.array_equal(terms[-1], St.eval_gates(W2, ch2, homogeneous=True))
+    St.close()
