@@ -203,6 +203,28 @@ int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs
 int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges, size_t n_challenges,
                      const srs_fe *E, int space, void *stream, size_t *mismatch_count);
 
+/* ---- deciders: permutation (copy-constraint) check and witness-commitment check ----
+ * srs_sparse = the reference's SparseMatrix<F> = Vec<(row, col, value)> (src/polynomial/sparse.rs:5) of an n x n matrix,
+ * kept on the device in CSR form.  A column index >= n is the reference's panic "invalid matrix multiply" (:15-17) and is
+ * rejected at creation (SRS_ERR_INVALID), as is a row index >= n.
+ * srs_sparse_matvec        = sparse::matrix_multiply (sparse.rs:7-19): y = M * Z.
+ * srs_is_sat_permutation   = the counting half of VanillaFS::is_sat_permutation (src/nifs/sangria/mod.rs:425-452) /
+ *                            PlonkStructure permutation check: number of rows with (M * Z)[row] != Z[row]; the caller builds
+ *                            Z = instances (with padding) || W[0][.. num_advice * 2^k]  (:415-423) and M = permutation matrix.
+ * srs_is_sat_witness_commit = VanillaFS::is_sat_witness_commit (src/nifs/sangria/mod.rs:455-474; src/plonk/mod.rs:350-358 with
+ *                            E == NULL): *w_mismatch_count = #{ i : ck.commit(W[i]) != W_commitments[i] } over the n_rounds
+ *                            witness rounds (CommitmentMismatch), *e_mismatch = (ck.commit(E) != *E_commitment) (ECommitmentMismatch).
+ *                            One batched MSM.  A round longer than the key -> SRS_ERR_TOO_LONG_INPUT (the reference unwrap()s). */
+typedef struct srs_sparse srs_sparse;
+int srs_sparse_create(int field, size_t n, const uint64_t *rows, const uint64_t *cols, const srs_fe *values, size_t nnz,
+                      srs_sparse **out);
+void srs_sparse_free(srs_sparse *M);
+int srs_sparse_matvec(srs_sparse *M, const srs_fe *Z, int space, void *stream, srs_fe *y);
+int srs_is_sat_permutation(srs_sparse *M, const srs_fe *Z, int space, void *stream, size_t *mismatch_count);
+int srs_is_sat_witness_commit(srs_ck *ck, const srs_fe *const *W, const size_t *n, size_t n_rounds,
+                              const srs_affine *W_commitments, const srs_fe *E, size_t n_E, const srs_affine *E_commitment,
+                              int space, void *stream, size_t *w_mismatch_count, int *e_mismatch);
+
 /* ---- lookup arguments: prover coefficients and the decider's log-derivative check ----
  * srs_lookup_coeff_1 = Arguments::evaluate_coefficient_1 (src/plonk/lookup.rs:319-341): for every lookup i
  *   ls[i][row] = L_i(advice, r)[row], ts[i][row] = T_i(fixed, r)[row]               (evaluate_ls / _ts, :209-272)

@@ -58,6 +58,11 @@ def _prototypes():
         "srs_lookup_coeff_1": (i32, [vp, vp, vp, i32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "srs_lookup_coeff_2": (i32, [i32, vp, vp, vp, vp, sz, i32, vp, vp, vp]),
         "srs_is_sat_log_derivative": (i32, [vp, vp, i32, vp, C.POINTER(sz)]),
+        "srs_sparse_create": (i32, [i32, sz, vp, vp, vp, sz, C.POINTER(vp)]),
+        "srs_sparse_free": (None, [vp]),
+        "srs_sparse_matvec": (i32, [vp, vp, i32, vp, vp]),
+        "srs_is_sat_permutation": (i32, [vp, vp, i32, vp, C.POINTER(sz)]),
+        "srs_is_sat_witness_commit": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, vp, vp, sz, vp, i32, vp, C.POINTER(sz), C.POINTER(i32)]),
         "srs_structure_free": (None, [vp]),
         "srs_structure_num_cross_terms": (sz, [vp]),
         "srs_structure_num_challenges": (sz, [vp]),

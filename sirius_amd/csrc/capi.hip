@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "curve.cuh"
+#include "decider.h"
 #include "devrt.h"
 #include "msm.h"
 #include "ntt.h"
@@ -27,6 +28,11 @@ static_assert(sizeof(srs_fe) == sizeof(fe_t) && sizeof(srs_affine) == sizeof(aff
 struct srs_ck {
     msm::Key key;
     Arena staging;      // H2D staging of host scalars
+};
+
+struct srs_sparse {
+    decider::Sparse *m = nullptr;
+    Arena io;
 };
 
 struct srs_structure {
@@ -642,6 +648,82 @@ int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const s
         *mismatch_count = rowprog::count_mismatch(vals, dE, rows, st);
         return SRS_OK;
     });
+}
+
+// ------------------------------------------------------------------ deciders
+int srs_sparse_create(int field, size_t n, const uint64_t *rows, const uint64_t *cols, const srs_fe *values, size_t nnz, srs_sparse **out) {
+    if (!valid_field(field) || !out || (nnz && (!rows || !cols || !values))) return fail(SRS_ERR_INVALID, "srs_sparse_create: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        std::string err;
+        int crc = 0;
+        decider::Sparse *m = decider::create(field, n, rows, cols, reinterpret_cast<const fe_t *>(values), nnz, crc, err);
+        if (!m) return fail(crc ? crc : SRS_ERR_INVALID, "srs_sparse_create: " + err);
+        srs_sparse *M = new srs_sparse();
+        M->m = m;
+        *out = M;
+        return SRS_OK;
+    });
+}
+void srs_sparse_free(srs_sparse *M) {
+    if (!M) return;
+    decider::destroy(M->m);
+    M->io.release();
+    delete M;
+}
+static int sparse_apply(srs_sparse *M, const srs_fe *Z, int space, void *stream, srs_fe *y, size_t *mismatch_count) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        const size_t n = decider::dim(M->m);
+        const bool host = space != SRS_SPACE_DEVICE;
+        const fe_t *dZ = reinterpret_cast<const fe_t *>(Z);
+        fe_t *dY = reinterpret_cast<fe_t *>(y);
+        if (host) {
+            M->io.reserve(2 * Arena::pad((n + 1) * sizeof(fe_t)) + 1024);
+            M->io.reset();
+            fe_t *a = M->io.take<fe_t>(n + 1);
+            SRS_HIP_CHECK(hipMemcpyAsync(a, Z, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            dZ = a;
+            if (y) dY = M->io.take<fe_t>(n + 1);
+        }
+        if (mismatch_count) *mismatch_count = decider::permutation_mismatches(M->m, dZ, st);
+        else decider::matvec(M->m, dZ, dY, st);
+        if (host && y) {
+            SRS_HIP_CHECK(hipMemcpyAsync(y, dY, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        return SRS_OK;
+    });
+}
+int srs_sparse_matvec(srs_sparse *M, const srs_fe *Z, int space, void *stream, srs_fe *y) {
+    if (!M || (decider::dim(M->m) && (!Z || !y))) return fail(SRS_ERR_INVALID, "srs_sparse_matvec: bad argument");
+    return sparse_apply(M, Z, space, stream, y, nullptr);
+}
+int srs_is_sat_permutation(srs_sparse *M, const srs_fe *Z, int space, void *stream, size_t *mismatch_count) {
+    if (!M || !mismatch_count || (decider::dim(M->m) && !Z)) return fail(SRS_ERR_INVALID, "srs_is_sat_permutation: bad argument");
+    return sparse_apply(M, Z, space, stream, nullptr, mismatch_count);
+}
+int srs_is_sat_witness_commit(srs_ck *ck, const srs_fe *const *W, const size_t *n, size_t n_rounds, const srs_affine *W_commitments,
+                              const srs_fe *E, size_t n_E, const srs_affine *E_commitment, int space, void *stream,
+                              size_t *w_mismatch_count, int *e_mismatch) {
+    if (!ck || !w_mismatch_count || (n_rounds && (!W || !n || !W_commitments)) || (E && (!E_commitment || !e_mismatch)))
+        return fail(SRS_ERR_INVALID, "srs_is_sat_witness_commit: bad argument");
+    std::vector<const srs_fe *> v(W, W + n_rounds);
+    std::vector<size_t> nn(n, n + n_rounds);
+    if (E) { v.push_back(E); nn.push_back(n_E); }
+    std::vector<srs_affine> got(v.size());
+    if (!v.empty()) {
+        int rc = srs_commit_batch(ck, v.data(), nn.data(), v.size(), space, SRS_REPR_MONT, stream, got.data());
+        if (rc) return rc;
+    }
+    size_t bad = 0;
+    for (size_t i = 0; i < n_rounds; ++i) bad += std::memcmp(&got[i], &W_commitments[i], sizeof(srs_affine)) != 0;
+    *w_mismatch_count = bad;
+    if (e_mismatch) *e_mismatch = E ? (std::memcmp(&got[n_rounds], E_commitment, sizeof(srs_affine)) != 0) : 0;
+    return SRS_OK;
 }
 
 // ------------------------------------------------------------------ lookup arguments

@@ -162,8 +162,73 @@ class PlonkStructure:
         return cnt.value
 
 
+class SparseMatrix:
+    """`SparseMatrix<F>` = Vec<(row, col, value)> of an n x n matrix (src/polynomial/sparse.rs:5), device resident.
+    The reference builds it from the copy constraints (PermutationData::matrix, src/plonk/permutation.rs)."""
+
+    def __init__(self, field, n, rows, cols, values):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        values = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        assert rows.shape == cols.shape == (values.shape[0],)
+        self.field, self.n = field, n
+        h = C.c_void_p()
+        L.check(L.lib().srs_sparse_create(field, n, rows.ctypes.data, cols.ctypes.data, values.ctypes.data, rows.shape[0], C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().srs_sparse_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def matrix_multiply(self, Z):
+        """sparse::matrix_multiply (sparse.rs:7-19)."""
+        addr, space, n, keep = _buf(Z, 4)
+        assert n == self.n
+        y = _alloc_like(Z, n)
+        L.check(L.lib().srs_sparse_matvec(self._h, addr, space, _stream(), y.data_ptr() if _is_torch(y) else y.ctypes.data))
+        return y
+
+
 class VanillaFS:
     """Sangria NIFS prover pieces (src/nifs/sangria/mod.rs)."""
+
+    @staticmethod
+    def is_sat_permutation(P, Z):
+        """Mismatch count of the copy-constraint check: #{row : (P Z)[row] != Z[row]}  (src/nifs/sangria/mod.rs:425-452)."""
+        addr, space, n, keep = _buf(Z, 4)
+        assert n == P.n
+        cnt = C.c_size_t()
+        L.check(L.lib().srs_is_sat_permutation(P._h, addr, space, _stream(), C.byref(cnt)))
+        return cnt.value
+
+    @staticmethod
+    def is_sat_witness_commit(ck, W, W_commitments, E=None, E_commitment=None):
+        """-> (number of rounds with ck.commit(W[i]) != W_commitments[i], E mismatch flag)  (src/nifs/sangria/mod.rs:455-474)."""
+        bufs = [_buf(w, 4) for w in W]
+        space = bufs[0][1] if bufs else L.SPACE_HOST
+        assert all(b[1] == space for b in bufs)
+        wp = (C.c_void_p * max(len(bufs), 1))(*[b[0] for b in bufs])
+        wn = (C.c_size_t * max(len(bufs), 1))(*[b[2] for b in bufs])
+        cm = np.ascontiguousarray(W_commitments, dtype=np.uint64).reshape(-1, 8)
+        assert cm.shape[0] == len(bufs)
+        ea = en = ec = None
+        keep = None
+        if E is not None:
+            ea, espace, en, keep = _buf(E, 4)
+            assert espace == space
+            ec = np.ascontiguousarray(E_commitment, dtype=np.uint64).reshape(8)
+        bad, ebad = C.c_size_t(), C.c_int()
+        L.check(L.lib().srs_is_sat_witness_commit(ck._h, wp, wn, len(bufs), cm.ctypes.data, ea, en or 0,
+                                                  ec.ctypes.data if ec is not None else None, space, _stream(),
+                                                  C.byref(bad), C.byref(ebad)))
+        return bad.value, bool(ebad.value)
 
     @staticmethod
     def cross_term_challenges(U1_challenges, U1_u, U2_challenges, field):

@@ -112,3 +112,10 @@ def test_emu_high_folding_degree(emu, oracle):
     from test_sangria_gpu import _high_degree_case
     _high_degree_case(emu, oracle, 0, 3, 10)
     _high_degree_case(emu, oracle, 1, 3, 12)
+
+
+def test_emu_deciders(emu, oracle):
+    from test_deciders_gpu import _general_sparse_case, _permutation_case, _witness_commit_case
+    _permutation_case(emu, oracle, 0, 5, 3, 2)
+    _general_sparse_case(emu, oracle, 1, 40, 200, 3)
+    _witness_commit_case(emu, oracle, 1, 200, 96)
