@@ -39,6 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from concurrent.futures import ThreadPoolExecutor
 
 POOL = ThreadPoolExecutor(max_workers=2)     # host-side instance folds overlap the GPU witness fold
+MADD_PEAK_G = 10.6
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 MSM_BYTES_PER_SCALAR = 96.0    # 64 B base + 32 B scalar, each read once
 
@@ -83,6 +84,9 @@ class Side:
         self.accCE = np.zeros(8, dtype=np.uint64)
 
 
+COUNT_NONZERO = False
+
+
 def combine(S, side, partial, dist, world, dev):
     """all-gather the per-rank partial commitments (RCCL) and sum them on the host."""
     if world == 1:
@@ -94,6 +98,8 @@ def combine(S, side, partial, dist, world, dev):
 def prove(S, side, dist, world, dev):
     """VanillaFS::prove hot path (src/nifs/sangria/mod.rs:253-277)."""
     terms, commits = S.VanillaFS.commit_cross_terms(side.ck, side.S, side.u1c, side.u1u, side.accW, side.u2c, side.inW)
+    if COUNT_NONZERO:     # untimed warm-up only: mixed additions issued = 16 windows x non-zero scalars (ALU roofline)
+        side.nz_terms = sum(int((t != 0).any(dim=1).sum().item()) for t in terms)
     commits = combine(S, side, commits, dist, world, dev)
     # generate_challenge: Poseidon RO on the CPU in the reference -> seeded constant r here.
     # Both folds depend only on r: the instance fold (host scalar-muls, accumulator.rs:201-264:
@@ -119,11 +125,25 @@ def fold_step(S, pri, sec, dist, world, dev):
     witness_commit(S, sec, dist, world, dev)  # D
 
 
+def host_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup v2 quota).  On the GPU box os.cpu_count() is 256 but the
+    container's cpu.max is 16 CPUs -- 256 OpenMP threads there are throttled to a crawl (tools/cpu_probe.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, pri, sec):
     """The CPU oracle (port of the reference algorithms) on ONE fold step of the same workload."""
     import oracle as O
     from oracle import expr as OE
-    threads = args.cpu_threads or (os.cpu_count() or 1)
+    quota = host_cpus()
+    threads = args.cpu_threads or min(2 * quota, os.cpu_count() or 1)     # 2 threads per granted CPU measured fastest
     t_all = 0.0
     for side in (sec, pri):
         w = side.w
@@ -147,7 +167,8 @@ def cpu_baseline(args, pri, sec):
         t_all += time.perf_counter() - t0
     return dict(value=1.0 / t_all, unit="fold-steps/s", cores=threads, kind="port",
                 sample=f"1 fold step, k={args.k} (same synthetic workload; oracle/ = C port of best_multiexp + "
-                       f"GroupedPoly/GraphEvaluator interpreter, OpenMP {threads} threads)")
+                       f"GroupedPoly/GraphEvaluator interpreter, OpenMP {threads} threads; host grants {quota} CPUs "
+                       f"of {os.cpu_count()} via cgroup cpu.max)")
 
 
 def main():
@@ -183,6 +204,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    global COUNT_NONZERO
+    COUNT_NONZERO = True
+    fold_step(S, pri, sec, dist, world, dev)          # extra untimed step that also counts non-zero scalars
+    COUNT_NONZERO = False
     for _ in range(args.warmup):
         fold_step(S, pri, sec, dist, world, dev)
     S.profile_enable(True)
@@ -239,7 +264,14 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "traffic_source": "profiles/r01_pmc_accum0.json (PMC bytes/scalar x scalars per launch)" if traffic else None,
                     "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
-                    "note": "integer-ALU bound (256-bit modmul), not HBM bound: see DESIGN.md"}
+                    "note": "integer-ALU bound (256-bit modmul), not HBM bound: see DESIGN.md and the `alu` object"}
+            # the bound that actually applies: mixed additions (8M+2S in XYZZ) per second against the rate the same
+            # instruction mix reaches in isolation on this chip (tools/ubench.hip, profiles/r01_ubench_gfx950_v2_fips_mul.txt)
+            nz = sum(int((sd.inW != 0).any(dim=1).sum().item()) + getattr(sd, "nz_terms", 0) for sd in (pri, sec))
+            madds = 16.0 * nz * args.steps / max(world, 1)
+            roof["alu"] = {"unit": "G mixed-add/s", "achieved": round(madds / (acc0["total_ms"] * 1e-3) / 1e9, 3),
+                           "peak": MADD_PEAK_G, "frac": round(madds / (acc0["total_ms"] * 1e-3) / 1e9 / MADD_PEAK_G, 4),
+                           "peak_source": "measured: profiles/r01_ubench_gfx950_v2_fips_mul.txt (madd 10.6 G/s)"}
         ct = S.profile_get("rowprog_cross_terms")
         scalars_per_step = (12 + 7 + 6 + 5) * (1 << args.k)
         out = {
