@@ -98,14 +98,21 @@ void to_affine_batch(int curve, const xyzz_t *in, affine_t *out, size_t n) {
 
 #if !defined(SRS_EMU)
 bool g_device_ok = false;
+int g_device = -1;        // the one device of this process (one process per GPU); bound by the first srs_init
 #endif
 
+// HIP's current device is per host thread: a caller's worker thread starts on device 0.  Every entry point rebinds the
+// calling thread to the process's device so that handles created on one thread work from any other.
 int ensure_device() {
 #if defined(SRS_EMU)
     return SRS_OK;
 #else
-    if (g_device_ok) return SRS_OK;
-    return srs_init(-1);
+    if (!g_device_ok) return srs_init(-1);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != g_device) {
+        if (hipSetDevice(g_device) != hipSuccess) return fail(SRS_ERR_DEVICE, "hipSetDevice failed");
+    }
+    return SRS_OK;
 #endif
 }
 
@@ -133,6 +140,7 @@ int srs_init(int device_ordinal) {
         SRS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(SRS_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+        g_device = dev;
         g_device_ok = true;
         return SRS_OK;
     });
@@ -225,6 +233,8 @@ int srs_ck_setup_synthetic(int curve, size_t len, uint64_t seed, uint32_t rank, 
 
 int srs_ck_get_bases(const srs_ck *ck, srs_affine *out) {
     if (!ck || (ck->key.len && !out)) return fail(SRS_ERR_INVALID, "srs_ck_get_bases: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
     return guarded([&]() -> int {
         if (ck->key.len) SRS_HIP_CHECK(hipMemcpy(out, ck->key.table, ck->key.len * sizeof(affine_t), hipMemcpyDeviceToHost));
         return SRS_OK;

@@ -135,3 +135,38 @@ def _key_file_roundtrip(S, O, tmp_path):
 
 def test_key_cache_file(srs, oracle, tmp_path):
     _key_file_roundtrip(srs, oracle, tmp_path)
+
+
+def test_two_host_threads_distinct_handles(srs, oracle):
+    """SURVEY 8b threading contract: calls on DISTINCT handles may run concurrently from different host threads
+    (HIP's current device is per thread; the library rebinds it).  Two threads hammer their own key / structure / NTTs;
+    every result must equal the single-threaded one."""
+    import threading
+    from workloads import make_structure_inputs
+    O = oracle
+    jobs, errs = [], []
+    for t, (which, cid) in enumerate((("primary", 0), ("secondary", 1))):
+        w = make_structure_inputs(which, 10, seed=90 + t)
+        ck = srs.CommitmentKey.setup_synthetic(cid, w["num_advice"] * w["rows"], seed=7 + t)
+        St = srs.PlonkStructure(w["field"], 10, [], w["fixed"], w["num_advice"], w["gates"])
+        a = O.to_mont(O.FR, np.random.default_rng(t).integers(0, 1 << 62, size=(1 << 12, 4), dtype=np.uint64))
+        exp_c = ck.commit(w["W1"])
+        exp_t, exp_tc = srs.VanillaFS.commit_cross_terms(ck, St, w["u1_challenges"], w["u1_u"], w["W1"], w["u2_challenges"], w["W2"])
+        exp_f = srs.fft.fft(a.copy())
+        jobs.append((w, ck, St, a, exp_c, exp_t, exp_tc, exp_f))
+
+    def run(job):
+        w, ck, St, a, exp_c, exp_t, exp_tc, exp_f = job
+        try:
+            for _ in range(25):
+                assert np.array_equal(ck.commit(w["W1"]), exp_c)
+                tt, tc = srs.VanillaFS.commit_cross_terms(ck, St, w["u1_challenges"], w["u1_u"], w["W1"], w["u2_challenges"], w["W2"])
+                assert np.array_equal(tc, exp_tc) and all(np.array_equal(x, y) for x, y in zip(tt, exp_t))
+                assert np.array_equal(srs.fft.fft(a.copy()), exp_f)
+        except Exception as e:      # surfaced in the main thread
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
