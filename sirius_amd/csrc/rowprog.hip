@@ -194,10 +194,6 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_rowprog_spec(DevArgs A) {
     }
 }
 
-#define SRS_SPEC_PART 2
-#include "rowprog_spec.inc"
-#undef SRS_SPEC_PART
-
 // ---------------------------------------------------------------------------------------------
 // ProtoGalaxy: pow-weighted sums of gate evaluations (reference src/nifs/protogalaxy/poly/mod.rs)
 //   Out[p] = sum_{i < n} pow_i(c^(p)) * f_i^(p),   pow_i(c) = prod_{b in bits(i)} c_b
@@ -240,8 +236,11 @@ __device__ __forceinline__ void weighted_tree(fe_t *red, fe_t x, const fe_t *__r
     }
 }
 
-// grid = (tiles_per_gate, n_gates), block = 2^(tile_log - log2 LPT) threads; every thread owns LPT consecutive
-// leaves and folds them in registers (LPT - 1 multiplies, no barrier) before the workgroup tree in LDS.
+// grid = (tiles_per_gate, n_gates), block = T = 2^(tile_log - log2 LPT) threads.  Thread t owns the LPT leaves
+// base + l * T + t (l < LPT): consecutive lanes read consecutive rows, so every column load is coalesced.  The sum
+// sum_i pow_i(c) f_i does not care about the order of additions (exact arithmetic), only that leaf i meets the weights
+// of ITS index bits: the in-register combine over l therefore uses the weights of bits log2(T).., the LDS tree over
+// the threads those of bits 0 .. log2(T) - 1.
 template <class F, uint32_t NSLOT, uint32_t LPT>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_leaves(PgArgs A) {
     __shared__ fe_t slots[NSLOT * RP_THREADS];
@@ -249,13 +248,14 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_leaves(PgArgs A) {
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x;
     const GateProg G = A.gates[gate];
-    const uint32_t row0 = (tile * blockDim.x + threadIdx.x) * LPT;   // < rows (rows is a multiple of the tile)
+    const uint32_t TL = A.tile_log - LPT_LOG;                          // log2(blockDim.x)
+    const uint32_t row0 = (tile << A.tile_log) + threadIdx.x;          // < rows (rows is a multiple of the tile)
     fe_t v[LPT];
     for (uint32_t p = 0; p < A.P; ++p) {
         if (A.leaf_pts > 1 || p == 0) {
 #pragma unroll
             for (uint32_t l = 0; l < LPT; ++l)
-                v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, A.compat ? 0u : row0 + l, p,
+                v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, A.compat ? 0u : row0 + (l << TL), p,
                                  A.utab + G.utab_off + (size_t)p * G.n_uniform);
         }
         const fe_t *w = A.weights + (A.wpts > 1 ? p : 0);
@@ -264,15 +264,53 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_leaves(PgArgs A) {
         for (uint32_t l = 0; l < LPT; ++l) t[l] = v[l];
 #pragma unroll
         for (uint32_t lvl = 0; lvl < LPT_LOG; ++lvl) {
-            fe_t c = w[(size_t)lvl * A.wpts];
+            fe_t c = w[(size_t)(TL + lvl) * A.wpts];
 #pragma unroll
             for (uint32_t i = 0; i < (LPT >> (lvl + 1)); ++i) t[i] = F::add(t[2 * i], F::mul(t[2 * i + 1], c));
         }
-        weighted_tree<F>(red, t[0], w + (size_t)LPT_LOG * A.wpts, A.wpts, A.tile_log - LPT_LOG);
+        weighted_tree<F>(red, t[0], w, A.wpts, TL);
         if (threadIdx.x == 0) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = red[0];
         __syncthreads();
     }
 }
+
+// k_pg_leaves with the gate programs of a known gate set compiled ahead of time (rowprog_spec.inc, PgSpecCall):
+// no LDS register file, no decode -- same leaf mapping and tree.
+template <class F, int ID, uint32_t LPT>
+__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_spec(PgArgs A) {
+    __shared__ fe_t red[RP_THREADS];
+    constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
+    const uint32_t gate = blockIdx.y, tile = blockIdx.x;
+    const GateProg G = A.gates[gate];
+    const uint32_t TL = A.tile_log - LPT_LOG;
+    const uint32_t row0 = (tile << A.tile_log) + threadIdx.x;
+    fe_t v[LPT];
+    for (uint32_t p = 0; p < A.P; ++p) {
+        if (A.leaf_pts > 1 || p == 0) {
+#pragma unroll
+            for (uint32_t l = 0; l < LPT; ++l)
+                v[l] = PgSpecCall<F, ID>::run(gate, A.ctx, A.compat ? 0u : row0 + (l << TL), p,
+                                              A.utab + G.utab_off + (size_t)p * G.n_uniform);
+        }
+        const fe_t *w = A.weights + (A.wpts > 1 ? p : 0);
+        fe_t t[LPT];
+#pragma unroll
+        for (uint32_t l = 0; l < LPT; ++l) t[l] = v[l];
+#pragma unroll
+        for (uint32_t lvl = 0; lvl < LPT_LOG; ++lvl) {
+            fe_t c = w[(size_t)(TL + lvl) * A.wpts];
+#pragma unroll
+            for (uint32_t i = 0; i < (LPT >> (lvl + 1)); ++i) t[i] = F::add(t[2 * i], F::mul(t[2 * i + 1], c));
+        }
+        weighted_tree<F>(red, t[0], w, A.wpts, TL);
+        if (threadIdx.x == 0) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = red[0];
+        __syncthreads();
+    }
+}
+
+#define SRS_SPEC_PART 2
+#include "rowprog_spec.inc"
+#undef SRS_SPEC_PART
 
 // continues the tree over the per-tile partials: in[m_valid][P] (zero beyond m_valid) -> out[ceil(m / 2^lv)][P]
 // grid = number of output nodes, block = 2^lv threads
@@ -951,6 +989,7 @@ struct Structure {
     bool has_vector_lookup = false;
     std::vector<Program> lookup_progs;   // lookup_polys L_i then table_polys T_i (LookupEvalDomain: advice columns, challenges = [r])
     std::vector<Program> gate_progs;   // S.gates one by one (ProtoGalaxy leaves, plonk/mod.rs:697-701)
+    int pg_spec_id = -1;           // ahead-of-time specialised leaf kernel for this gate set, or -1
     size_t max_gate_degree = 0;    // max_i gates[i].degree()  (get_points_count, poly/mod.rs:535-545)
     GateProg *d_gate_progs = nullptr;
     std::vector<fe_t> vinv;        // [degree][degree+1]
@@ -1067,6 +1106,12 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         if (!build_program(ast, roots[g], f, ctx, false, S->gate_progs[g], err)) { rc = 7; return nullptr; }
         S->max_gate_degree = std::max(S->max_gate_degree, expr_degree(ast, roots[g], ctx));
     }
+    for (size_t e = 0; e < sizeof(kPgSpecs) / sizeof(kPgSpecs[0]); ++e) {
+        if ((size_t)kPgSpecs[e].n_gates != S->gate_progs.size()) continue;
+        bool same = true;
+        for (size_t g = 0; g < S->gate_progs.size(); ++g) same = same && kPgSpecs[e].fp[g] == S->gate_progs[g].fingerprint;
+        if (same && !std::getenv("SRS_NO_SPEC")) S->pg_spec_id = kPgSpecs[e].id;
+    }
     // lookup / table polynomials see the advice COLUMNS only (LookupEvalDomain, src/plonk/eval.rs:106-134)
     {
         Ctx lctx{num_selectors, num_fixed, num_advice, 0};
@@ -1164,7 +1209,8 @@ static void launch_rowprog(const DevArgs &A, uint32_t nslots, hipStream_t st) {
 }
 
 const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf) {
-    Program &p = which == 0 ? S->cross : (which == 1 ? S->plain_compressed : S->plain_homogeneous);
+    if (which >= 3 && (size_t)(which - 3) >= S->gate_progs.size()) { buf.clear(); return buf.c_str(); }
+    Program &p = which >= 3 ? S->gate_progs[which - 3] : (which == 0 ? S->cross : (which == 1 ? S->plain_compressed : S->plain_homogeneous));
     buf = emit_spec_source(p, "spec_fn");
     if (fingerprint) *fingerprint = p.fingerprint;
     if (spec_id) *spec_id = p.spec_id;
@@ -1425,7 +1471,8 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     a.partial = buf0;
     {
         prof::Scope ps(mode == 0 ? "pg_F_leaves" : (mode == 1 ? "pg_G_leaves" : "pg_e_leaves"), st, S->rows * n_gates);
-        if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, lpt, st);
+        if (S->pg_spec_id >= 0 && lpt == 8) launch_pg_spec(S->pg_spec_id, a, tiles_per_gate, n_gates, tile, st);
+        else if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else launch_pg_leaves<32>(a, tiles_per_gate, n_gates, tile, lpt, st);
