@@ -9,6 +9,9 @@
 // identity is ZZ = 0.  Formulas: EFD shortw/xyzz  madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1.
 #pragma once
 #include "field.cuh"
+#if defined(SRS_EMU)
+#include "hipemu.h"   // CPU logic emulator (tests/emu): quad exchange primitive
+#endif
 
 namespace srs {
 
@@ -30,6 +33,57 @@ struct Grumpkin {
     using S = Fq;
     static constexpr int ID = 1;
 };
+
+// ---- quad cooperation: 4 adjacent lanes (a DPP "quad") hold identical operands and share one group addition ----
+// The tail of an MSM (bucket-part levels, row/column sums, weighted suffix sums) is a chain of ~30 DEPENDENT XYZZ
+// additions on a nearly idle chip; one addition is 14 dependent-or-not modmuls that a single lane issues back to back
+// (~12 us).  Spread over a quad, the 14 products form 4 levels of <= 4 independent products, exchanged with DPP
+// quad_perm moves (register crossbar, no LDS): ~3.5 us per addition for ~20 % more lane-cycles.
+#if defined(SRS_EMU)
+template <int K>
+SRS_D uint32_t quad_bcast_u32(uint32_t v) { return __emu_quad_bcast(v, K); }
+#elif defined(__HIP_DEVICE_COMPILE__)
+template <int K>
+SRS_D uint32_t quad_bcast_u32(uint32_t v) {   // quad_perm:[K,K,K,K]
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xF, 0xF, true);
+}
+#else
+template <int K>
+SRS_D uint32_t quad_bcast_u32(uint32_t v) { return v; }   // host pass of hipcc: never executed
+#endif
+template <int K>
+SRS_D fe_t quad_bcast(const fe_t &x) {
+    fe_t o;
+#if defined(SRS_EMU)
+    __emu_quad_bcast8(x.v, K, o.v);
+#else
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = quad_bcast_u32<K>(x.v[i]);
+#endif
+    return o;
+}
+// operand of the lane's role: value selects limb by limb on by-value arguments.  (A nested ?: over references, or
+// reference parameters here, make the compiler select POINTERS and park the points in scratch memory -- measured:
+// 144-336 B of scratch per lane and no latency gain at all; tools/scratch/quad_probe.hip.)
+SRS_D fe_t quad_select(uint32_t q, fe_t a0, fe_t a1, fe_t a2, fe_t a3) {   // BY VALUE, see below
+    fe_t o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t x = a0.v[i];
+        x = q == 1 ? a1.v[i] : x;
+        x = q == 2 ? a2.v[i] : x;
+        x = q == 3 ? a3.v[i] : x;
+        o.v[i] = x;
+    }
+    return o;
+}
+
+SRS_HD fe_t fe_select(bool c, const fe_t &x, const fe_t &y) {   // c ? x : y, limb by limb
+    fe_t o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = c ? x.v[i] : y.v[i];
+    return o;
+}
 
 template <class C>
 struct Ec {
@@ -154,6 +208,42 @@ struct Ec {
         o.y = F::sub(F::mul(r, F::sub(qv, o.x)), F::mul(s1, ppp));
         o.zz = F::mul(F::mul(a.zz, b.zz), pp);
         o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
+        return o;
+    }
+    // a + b computed by the 4 lanes of a quad together (add-2008-s split into 4 levels of independent products).
+    // Preconditions: the 4 lanes hold the same a and b, q = lane index inside the quad, the quad is convergent.
+    // All 4 lanes return the same sum (bit-identical to add(a, b)).
+    SRS_D static xyzz_t add_quad(const xyzz_t &a, const xyzz_t &b, uint32_t q) {
+        // identity operands: the 4 lanes hold the same a, b, so the branch is quad-uniform and the DPP exchanges
+        // below still see whole quads
+        const bool ia = is_identity(a), ib = is_identity(b);
+        xyzz_t o;
+        if (ia || ib) {                            // a + O = a ; O + b = b
+            o.x = fe_select(ib, a.x, b.x);
+            o.y = fe_select(ib, a.y, b.y);
+            o.zz = fe_select(ib, a.zz, b.zz);
+            o.zzz = fe_select(ib, a.zzz, b.zzz);
+            return o;
+        }
+        // level 1: u1 = X1 ZZ2 | u2 = X2 ZZ1 | s1 = Y1 ZZZ2 | s2 = Y2 ZZZ1
+        fe_t m1 = F::mul(quad_select(q, a.x, b.x, a.y, b.y), quad_select(q, b.zz, a.zz, b.zzz, a.zzz));
+        fe_t u1 = quad_bcast<0>(m1), u2 = quad_bcast<1>(m1), s1 = quad_bcast<2>(m1), s2 = quad_bcast<3>(m1);
+        fe_t p = F::sub(u2, u1), r = F::sub(s2, s1);
+        // level 2: PP = P^2 | RR = R^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2
+        fe_t m2 = F::mul(quad_select(q, p, r, a.zz, a.zzz), quad_select(q, p, r, b.zz, b.zzz));
+        fe_t pp = quad_bcast<0>(m2), rr = quad_bcast<1>(m2), zzz12 = quad_bcast<3>(m2);
+        // level 3: PPP = P PP | Q = U1 PP | ZZ3 = ZZ1 ZZ2 PP | (lane 3 repeats lane 0)
+        fe_t m3 = F::mul(quad_select(q, p, u1, m2, p), pp);
+        fe_t ppp = quad_bcast<0>(m3), qv = quad_bcast<1>(m3), zz3 = quad_bcast<2>(m3);
+        fe_t x3 = F::sub(F::sub(rr, ppp), F::dbl(qv));
+        // level 4: R (Q - X3) | S1 PPP | ZZZ3 = ZZZ1 ZZZ2 PPP | (lane 3 repeats lane 1)
+        fe_t m4 = F::mul(quad_select(q, r, s1, zzz12, s1), quad_select(q, F::sub(qv, x3), ppp, ppp, ppp));
+        fe_t t2 = quad_bcast<0>(m4), t1 = quad_bcast<1>(m4), zzz3 = quad_bcast<2>(m4);
+        o.x = x3;
+        o.y = F::sub(t2, t1);
+        o.zz = zz3;
+        o.zzz = zzz3;
+        if (F::is_zero(p)) o = F::is_zero(r) ? dbl(a) : identity();   // P2 = +-P1 (quad-uniform as well)
         return o;
     }
     // -> affine (one field inversion): x = X/ZZ, y = Y/ZZZ

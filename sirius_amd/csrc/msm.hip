@@ -425,7 +425,11 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     parts[(size_t)m * parts_stride + t] = acc;
 }
 
-// level >= 1: thread t = (bucket, part) over the previous level's parts, <= L1 full adds
+// level >= 1: (bucket, part) over the previous level's parts, <= L1 full adds each.
+// Two modes, chosen on the device from the number of outputs of this level:
+//   many outputs  -> one lane per output (throughput-bound, every lane runs its own additions)
+//   few outputs   -> one QUAD per output (latency-bound tail: Ec::add_quad cuts the dependent chain 3.3x)
+// The grid is sized for the quad mode; in lane mode the surplus workgroups exit.
 template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum1(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
@@ -434,8 +438,11 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     if ((uint32_t)level >= plan[(size_t)m * plan_stride + plan_stride - 4]) return;   // level not needed (k_plan)
     const uint32_t *tp_prev = plan + (size_t)m * plan_stride + (size_t)level * (NBUCKET + 1);
     const uint32_t *tp = tp_prev + (NBUCKET + 1);
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= tp[NBUCKET]) return;
+    const uint32_t n_out = tp[NBUCKET];
+    const bool quad = (uint64_t)n_out * gridDim.y <= ACC1_QUAD_MAX;   // whole batch: latency-bound only while the chip is not full
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = quad ? (lin >> 2) : lin;
+    if (t >= n_out) return;                    // in quad mode the 4 lanes of a quad leave together
     uint32_t b = upper_bucket(tp, t);
     uint32_t part = t - tp[b];
     uint32_t s = tp_prev[b] + part * l1;
@@ -443,13 +450,23 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     if (e > s + l1) e = s + l1;
     const xyzz_t *src = in + (size_t)m * in_stride;
     xyzz_t acc = src[s];
-    for (uint32_t j = s + 1; j < e; ++j) acc = Ec<C>::add(acc, src[j]);
-    out[(size_t)m * out_stride + t] = acc;
+    if (quad) {
+        const uint32_t q = threadIdx.x & 3u;
+        for (uint32_t j = s + 1; j < e; ++j) acc = Ec<C>::add_quad(acc, src[j], q);
+        if (q == 0) out[(size_t)m * out_stride + t] = acc;
+    } else {
+        for (uint32_t j = s + 1; j < e; ++j) acc = Ec<C>::add(acc, src[j]);
+        out[(size_t)m * out_stride + t] = acc;
+    }
 }
 
 // 64-lane exchange of an XYZZ point
 __device__ __forceinline__ xyzz_t shfl_down_point(const xyzz_t &p, unsigned delta) {
     xyzz_t o;
+#if defined(SRS_EMU)
+    __emu_shfl_down_bulk128(&p, &o, delta, 64);
+    return o;
+#endif
     const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
     uint32_t *d = reinterpret_cast<uint32_t *>(&o);
 #pragma unroll
@@ -504,6 +521,10 @@ __device__ __forceinline__ void lds_tree_sum(xyzz_t *v, uint32_t n_pow2) {
 // 64-lane exchange of an XYZZ point inside groups of `width` lanes
 __device__ __forceinline__ xyzz_t shfl_down_point_w(const xyzz_t &p, unsigned delta, int width) {
     xyzz_t o;
+#if defined(SRS_EMU)
+    __emu_shfl_down_bulk128(&p, &o, delta, width);
+    return o;
+#endif
     const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
     uint32_t *d = reinterpret_cast<uint32_t *>(&o);
 #pragma unroll
@@ -511,67 +532,102 @@ __device__ __forceinline__ xyzz_t shfl_down_point_w(const xyzz_t &p, unsigned de
     return o;
 }
 
-// Row / column sums with full lanes: every lane first adds RC_SERIAL consecutive elements serially,
-// then the lanes of a group (16 for a 128-element row, 32 for a 256-element column) combine by a
-// shuffle tree.  One wavefront = 4 row sums or 2 column sums; 128 wavefronts per MSM.
-// grid = (RED_ROWS / 4 + RED_COLS / 2, batch), block = 64
+// Row / column sums, one QUAD per lane-task (Ec::add_quad): a quad first adds RC_SER consecutive elements, then the
+// 16 quads of a wavefront combine by a shuffle tree (partner quad = 4 d lanes further).  A row (128 elements) is one
+// wavefront; a column (256 elements) is the two wavefronts of a workgroup, joined through LDS.
+// grid = (RED_ROWS / 2 + RED_COLS, batch), block = 128: workgroups < RED_ROWS / 2 do two rows, the others one column.
 template <class C>
-__global__ void SRS_KERNEL_BOUNDS(64, 1)
+__global__ void SRS_KERNEL_BOUNDS(128, 1)
     k_rowcol(const xyzz_t *__restrict__ buckets, const xyzz_t *__restrict__ ping, size_t ping_stride,
              const xyzz_t *__restrict__ pong, size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride,
              xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */) {
     constexpr uint32_t SER = 8;
-    const uint32_t m = blockIdx.y, lane = threadIdx.x;
+    __shared__ xyzz_t half[1];
+    const uint32_t m = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t q = lane & 3u, vl = lane >> 2;                                // quad role, quad index 0..15
     const uint32_t *hdr = plan + (size_t)m * plan_stride + plan_stride - 4;   // [0] levels run, [1] all buckets single
     const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + (size_t)m * ping_stride : pong + (size_t)m * pong_stride)
                              : buckets + (size_t)m * NBUCKET;
     xyzz_t *out = rc + (size_t)m * (RED_ROWS + RED_COLS);
-    if (blockIdx.x < RED_ROWS / 4) {
-        const uint32_t hi = blockIdx.x * 4 + (lane >> 4), sub = lane & 15u;     // 16 lanes x 8 = 128 = RED_COLS
-        const xyzz_t *src = B + (size_t)hi * RED_COLS + sub * SER;
-        xyzz_t acc = src[0];
-        for (uint32_t j = 1; j < SER; ++j) acc = Ec<C>::add(acc, src[j]);
-        for (unsigned d = 8; d >= 1; d >>= 1) {
-            xyzz_t o = shfl_down_point_w(acc, d, 16);
-            if (sub < d) acc = Ec<C>::add(acc, o);
+    const bool is_row = blockIdx.x < RED_ROWS / 2;
+    xyzz_t acc;
+    if (is_row) {
+        const uint32_t hi = blockIdx.x * 2 + wave;                               // 16 quads x 8 = 128 = RED_COLS
+        const xyzz_t *src = B + (size_t)hi * RED_COLS + vl * SER;
+        acc = src[0];
+        xyzz_t nx = src[1];
+        for (uint32_t j = 1; j < SER; ++j) {             // next element is fetched behind the addition
+            xyzz_t cur = nx;
+            if (j + 1 < SER) nx = src[j + 1];
+            acc = Ec<C>::add_quad(acc, cur, q);
         }
-        if (sub == 0) out[hi] = acc;
     } else {
-        const uint32_t lo = (blockIdx.x - RED_ROWS / 4) * 2 + (lane >> 5), sub = lane & 31u;   // 32 lanes x 8 = 256 = RED_ROWS
-        xyzz_t acc = B[(size_t)(sub * SER) * RED_COLS + lo];
-        for (uint32_t j = 1; j < SER; ++j) acc = Ec<C>::add(acc, B[(size_t)(sub * SER + j) * RED_COLS + lo]);
-        for (unsigned d = 16; d >= 1; d >>= 1) {
-            xyzz_t o = shfl_down_point_w(acc, d, 32);
-            if (sub < d) acc = Ec<C>::add(acc, o);
+        const uint32_t lo = blockIdx.x - RED_ROWS / 2, sub = wave * 16 + vl;     // 32 quads x 8 = 256 = RED_ROWS
+        const xyzz_t *src = B + (size_t)(sub * SER) * RED_COLS + lo;
+        acc = src[0];
+        xyzz_t nx = src[RED_COLS];
+        for (uint32_t j = 1; j < SER; ++j) {
+            xyzz_t cur = nx;
+            if (j + 1 < SER) nx = src[(size_t)(j + 1) * RED_COLS];
+            acc = Ec<C>::add_quad(acc, cur, q);
         }
-        if (sub == 0) out[RED_ROWS + lo] = acc;
+    }
+    for (unsigned d = 8; d >= 1; d >>= 1) {
+        xyzz_t o = shfl_down_point_w(acc, 4 * d, 64);
+        if (vl < d) acc = Ec<C>::add_quad(acc, o, q);
+    }
+    if (is_row) {
+        if (lane == 0) out[blockIdx.x * 2 + wave] = acc;
+        return;
+    }
+    if (wave == 1 && lane == 0) half[0] = acc;
+    __syncthreads();
+    if (wave == 0 && vl == 0) {
+        acc = Ec<C>::add_quad(acc, half[0], q);
+        if (q == 0) out[RED_ROWS + (blockIdx.x - RED_ROWS / 2)] = acc;
     }
 }
 
-// sum_j j * X_j = sum_{j>=1} Suffix_j with Suffix_j = sum_{i>=j} X_i: an inclusive suffix scan and a
-// tree sum, both log-depth in LDS.  grid = (2, batch), block = RED_ROWS (256) threads:
-//   block 0: A = sum_hi hi * R_hi        (drop Suffix_0)
-//   block 1: B = sum_lo (lo+1) * C_lo    (keep Suffix_0; 128 real elements)
-// out[2m] = A, out[2m+1] = B;  the host finishes  S = RED_COLS * A + B  (7 doublings + 1 add).
+// sum_j j * X_j = sum_{j>=1} Suffix_j with Suffix_j = sum_{i>=j} X_i: an inclusive suffix scan and a tree sum, both
+// log-depth in LDS, over 128 elements with one QUAD per element (512 threads).  grid = (3, batch):
+//   block 0: A' = sum_a a * (R_2a + R_2a+1)     (the 256 row sums taken in pairs; drop Suffix_0)
+//   block 1: B  = sum_lo (lo+1) * C_lo          (keep Suffix_0)
+//   block 2: Z  = sum_a R_2a+1                  (plain tree sum)
+// since sum_hi hi R_hi = 2 A' + Z, the host finishes  S = RED_COLS * (2 A' + Z) + B.   out[3m + {0,1,2}] = A', B, Z
 template <class C>
-__global__ void SRS_KERNEL_BOUNDS(RED_ROWS, 1)
+__global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
     k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
-    __shared__ xyzz_t v[RED_ROWS];
-    const uint32_t m = blockIdx.y, t = threadIdx.x, which = blockIdx.x;
-    const xyzz_t *src = rc + (size_t)m * (RED_ROWS + RED_COLS) + (which ? RED_ROWS : 0);
-    const uint32_t n = which ? RED_COLS : RED_ROWS;
-    v[t] = t < n ? src[t] : Ec<C>::identity();
-    __syncthreads();
-    for (uint32_t s = 1; s < n; s <<= 1) {             // suffix scan
-        xyzz_t o = (t + s < n) ? v[t + s] : Ec<C>::identity();
+    constexpr uint32_t N = RED_COLS;                       // 128 elements per block
+    __shared__ xyzz_t v[N];
+    const uint32_t m = blockIdx.y, t = threadIdx.x >> 2, q = threadIdx.x & 3u, which = blockIdx.x;
+    const xyzz_t *rows = rc + (size_t)m * (RED_ROWS + RED_COLS), *cols = rows + RED_ROWS;
+    xyzz_t x;
+    if (which == 0) x = Ec<C>::add_quad(rows[2 * t], rows[2 * t + 1], q);
+    else if (which == 1) x = cols[t];
+    else x = rows[2 * t + 1];
+    if (which != 2) {
+        if (q == 0) v[t] = x;
         __syncthreads();
-        if (t < n) v[t] = Ec<C>::add(v[t], o);
+        for (uint32_t s = 1; s < N; s <<= 1) {             // suffix scan
+            const bool has = t + s < N;
+            xyzz_t o = has ? v[t + s] : Ec<C>::identity();
+            __syncthreads();
+            if (has) x = Ec<C>::add_quad(x, o, q);
+            if (q == 0) v[t] = x;
+            __syncthreads();
+        }
+        if (which == 0 && t == 0) x = Ec<C>::identity();
+    }
+    if (q == 0) v[t] = x;
+    __syncthreads();
+    for (uint32_t s = N >> 1; s >= 1; s >>= 1) {           // tree sum
+        if (t < s) {                                       // x == v[t] (kept in registers by all 4 lanes: the quad's own
+            x = Ec<C>::add_quad(x, v[t + s], q);           // slot is never re-read, so lane 0's store cannot race with it)
+            if (q == 0) v[t] = x;
+        }
         __syncthreads();
     }
-    if (which == 0 && t == 0) v[0] = Ec<C>::identity();
-    __syncthreads();
-    lds_tree_sum<C>(v, RED_ROWS);
-    if (t == 0) out[(size_t)m * 2 + which] = v[0];
+    if (threadIdx.x == 0) out[(size_t)m * 3 + which] = v[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -656,7 +712,7 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
     return per * batch + Arena::pad(batch * sizeof(void *)) + Arena::pad(batch * sizeof(uint32_t)) +
-           Arena::pad(2 * batch * sizeof(xyzz_t)) + 4096;
+           Arena::pad(3 * batch * sizeof(xyzz_t)) + 4096;
 }
 
 template <class C>
@@ -679,7 +735,7 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     A.reset();
     const fe_t **d_ptrs = A.take<const fe_t *>(batch);
     uint32_t *d_n = A.take<uint32_t>(batch);
-    xyzz_t *d_out = A.take<xyzz_t>(2 * (size_t)batch);
+    xyzz_t *d_out = A.take<xyzz_t>(3 * (size_t)batch);
     uint16_t *dig = A.take<uint16_t>(M * batch);
     uint32_t *sorted = A.take<uint32_t>(M * batch);
     uint32_t *count = A.take<uint32_t>((size_t)NBUCKET * batch);
@@ -722,7 +778,7 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     uint64_t cap = parts0_cap;
     for (int level = 1; level < levels; ++level) {
         cap = cap / ACC_L1 + NBUCKET + 1;
-        SRS_LAUNCH((k_accum1<C>), (ceil_div(cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, ACC1_QUAD_MAX)), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                    (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, level, nxt, nxt_stride,
                    (uint32_t)ACC_L1);
         std::swap(cur, nxt);
@@ -734,18 +790,18 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap,
                (const uint32_t *)plan, plan_stride, buckets);
-    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 4 + RED_COLS / 2, batch), (64), 0, stream, (const xyzz_t *)buckets,
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, batch), (128), 0, stream, (const xyzz_t *)buckets,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap, (const uint32_t *)plan,
                plan_stride, rc);
-    SRS_LAUNCH((k_reduce_final<C>), (2, batch), (RED_ROWS), 0, stream, (const xyzz_t *)rc, d_out);
-    std::vector<xyzz_t> two(2 * (size_t)batch);
+    SRS_LAUNCH((k_reduce_final<C>), (3, batch), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_out);
+    std::vector<xyzz_t> two(3 * (size_t)batch);
     SRS_HIP_CHECK(hipMemcpyAsync(two.data(), d_out, two.size() * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
     SRS_HIP_CHECK(hipGetLastError());
-    for (uint32_t m = 0; m < batch; ++m) {             // S = RED_COLS * A + B on the host (8 group ops)
-        xyzz_t a = two[2 * m];
+    for (uint32_t m = 0; m < batch; ++m) {             // S = RED_COLS * (2 A' + Z) + B on the host (10 group ops)
+        xyzz_t a = Ec<C>::add(Ec<C>::dbl(two[3 * m]), two[3 * m + 2]);
         for (uint32_t k = 1; k < RED_COLS; k <<= 1) a = Ec<C>::dbl(a);
-        result_host[m] = Ec<C>::add(a, two[2 * m + 1]);
+        result_host[m] = Ec<C>::add(a, two[3 * m + 1]);
     }
     prof::collect();
 }

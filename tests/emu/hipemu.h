@@ -42,7 +42,7 @@ inline dim3 blockDim, gridDim;
 static constexpr int warpSize = 64;
 
 namespace hipemu {
-enum Wait { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+enum Wait { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3, WAIT_QUAD = 4 };
 struct Fiber {
     ucontext_t ctx;
     std::unique_ptr<char[]> stack;
@@ -52,6 +52,8 @@ struct Fiber {
 struct BlockCtx {
     std::vector<Fiber> fibers;
     std::vector<uint64_t> wave_slots;   // 64 x 8-byte exchange slots per wave
+    std::vector<uint32_t> quad_slots;   // 8 dwords per lane: quad exchange of a whole field element
+    std::vector<uint32_t> bulk_slots;   // 32 dwords per lane: wave exchange of a whole XYZZ point
     unsigned nthreads = 0;
     unsigned cur = 0;                   // running fiber
     ucontext_t sched;
@@ -64,6 +66,18 @@ inline constexpr size_t kStack = 512 * 1024;
 
 inline void yield_as(int wait) {
     Fiber &f = g_ctx.fibers[g_ctx.cur];
+    if (wait == WAIT_QUAD) {
+        // last lane of the quad to arrive releases the others and keeps running (no scheduler round needed)
+        unsigned lo = g_ctx.cur & ~3u, hi = std::min(g_ctx.nthreads, lo + 4);
+        bool all = true;
+        for (unsigned t = lo; t < hi; ++t)
+            if (t != g_ctx.cur && g_ctx.fibers[t].state != WAIT_QUAD && g_ctx.fibers[t].state != DONE) all = false;
+        if (all) {
+            for (unsigned t = lo; t < hi; ++t)
+                if (g_ctx.fibers[t].state == WAIT_QUAD) g_ctx.fibers[t].state = RUNNABLE;
+            return;
+        }
+    }
     f.state = wait;
     swapcontext(&f.ctx, &g_ctx.sched);
 }
@@ -86,16 +100,23 @@ inline void run_block() {
     }
     for (;;) {
         unsigned done = 0, progressed = 0;
-        for (unsigned t = 0; t < n; ++t) {
-            Fiber &f = g_ctx.fibers[t];
-            if (f.state == DONE) { ++done; continue; }
-            if (f.state != RUNNABLE) continue;
-            g_ctx.cur = t;
-            t_lin = t;
-            threadIdx = f.tid;
-            swapcontext(&g_ctx.sched, &f.ctx);
-            ++progressed;
+        for (unsigned qb = 0; qb < n; qb += 4) {
+            // run a quad until none of its lanes is runnable: quad exchanges complete here, without global rounds
+            for (bool again = true; again;) {
+                again = false;
+                for (unsigned t = qb; t < std::min(n, qb + 4); ++t) {
+                    Fiber &f = g_ctx.fibers[t];
+                    if (f.state != RUNNABLE) continue;
+                    g_ctx.cur = t;
+                    t_lin = t;
+                    threadIdx = f.tid;
+                    swapcontext(&g_ctx.sched, &f.ctx);
+                    ++progressed;
+                }
+                for (unsigned t = qb; t < std::min(n, qb + 4); ++t) again = again || g_ctx.fibers[t].state == RUNNABLE;
+            }
         }
+        for (unsigned t = 0; t < n; ++t) done += g_ctx.fibers[t].state == DONE;
         if (done == n) break;
         // release barriers whose participants have all arrived
         unsigned live = 0, at_block = 0;
@@ -120,6 +141,24 @@ inline void run_block() {
             if (wl && ww == wl) {
                 for (unsigned t = lo; t < hi; ++t)
                     if (g_ctx.fibers[t].state == WAIT_WAVE) g_ctx.fibers[t].state = RUNNABLE;
+                released = true;
+            }
+        }
+        for (unsigned qd = 0; qd * 4 < n; ++qd) {               // quad exchanges (DPP quad_perm): 4 adjacent lanes
+            unsigned lo = qd * 4, hi = std::min(n, lo + 4), ql = 0, qw = 0;
+            for (unsigned t = lo; t < hi; ++t) {
+                int s = g_ctx.fibers[t].state;
+                if (s != DONE) ++ql;
+                if (s == WAIT_QUAD) ++qw;
+            }
+            // a DPP read involves exactly the lanes executing it: on the device a quad is either wholly inside a
+            // branch or wholly outside (callers keep quads convergent), so "all lanes of the quad that are waiting
+            // at a quad exchange and none runnable" is the release condition
+            bool any_runnable = false;
+            for (unsigned t = lo; t < hi; ++t) any_runnable = any_runnable || g_ctx.fibers[t].state == RUNNABLE;
+            if (qw && !any_runnable && qw == ql) {
+                for (unsigned t = lo; t < hi; ++t)
+                    if (g_ctx.fibers[t].state == WAIT_QUAD) g_ctx.fibers[t].state = RUNNABLE;
                 released = true;
             }
         }
@@ -150,6 +189,40 @@ inline T __emu_wave_exchange(T v, int src_lane) {
     T o;
     std::memcpy(&o, &got, sizeof(T));
     return o;
+}
+// value of lane (quad base + k) for the 4 lanes of a quad; only the quad has to be convergent
+inline uint32_t __emu_quad_bcast(uint32_t v, int k) {
+    using namespace hipemu;
+    unsigned wave = t_lin / 64, lane = t_lin % 64;
+    g_ctx.wave_slots[wave * 64 + lane] = v;
+    yield_as(WAIT_QUAD);
+    uint64_t got = g_ctx.wave_slots[wave * 64 + (lane & ~3u) + (unsigned)k];
+    yield_as(WAIT_QUAD);
+    return (uint32_t)got;
+}
+// __shfl_down of a 128-byte object in one wave barrier pair (32 dword shuffles would cost 64 fiber switches)
+inline void __emu_shfl_down_bulk128(const void *in, void *out, unsigned d, int width) {
+    using namespace hipemu;
+    unsigned wave = t_lin / 64, lane = t_lin % 64;
+    std::memcpy(&g_ctx.bulk_slots[(size_t)t_lin * 32], in, 128);
+    yield_as(WAIT_WAVE);
+    unsigned wave_n = std::min(64u, g_ctx.nthreads - wave * 64);
+    int src = (int)lane + (int)d;
+    if (src / width != (int)lane / width || (unsigned)src >= wave_n) src = (int)lane;
+    uint32_t tmp[32];
+    std::memcpy(tmp, &g_ctx.bulk_slots[(size_t)(wave * 64 + (unsigned)src) * 32], 128);
+    yield_as(WAIT_WAVE);
+    std::memcpy(out, tmp, 128);
+}
+// 8 dwords at once (one field element): a single barrier pair instead of 8
+inline void __emu_quad_bcast8(const uint32_t *v, int k, uint32_t *out) {
+    using namespace hipemu;
+    std::memcpy(&g_ctx.quad_slots[(size_t)t_lin * 8], v, 32);
+    yield_as(WAIT_QUAD);
+    uint32_t tmp[8];
+    std::memcpy(tmp, &g_ctx.quad_slots[(size_t)((t_lin & ~3u) + (unsigned)k) * 8], 32);
+    yield_as(WAIT_QUAD);
+    std::memcpy(out, tmp, 32);
 }
 template <class T>
 inline T __shfl(T v, int lane, int width = 64) {
@@ -276,6 +349,8 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t dyn_smem, A... args) 
         g_ctx.fibers[t].tid.z = t / (block.x * block.y);
     }
     g_ctx.wave_slots.assign((size_t)((nthreads + 63) / 64) * 64, 0);
+    g_ctx.quad_slots.assign((size_t)((nthreads + 63) / 64) * 64 * 8, 0);
+    g_ctx.bulk_slots.assign((size_t)((nthreads + 63) / 64) * 64 * 32, 0);
     auto body = [&]() { kernel(args...); };
     using B = decltype(body);
     g_ctx.entry = [](void *p) { (*static_cast<B *>(p))(); };
