@@ -243,7 +243,8 @@ int srs_is_sat_log_derivative(srs_structure *S, const srs_fe *W, int space, void
 /* ---- RelaxedPlonkWitness::fold (src/nifs/sangria/accumulator.rs:364-404) ----
  * srs_fold_witness: out[i] = w1[i] + r * w2[i]                                   (:366-376)
  * srs_fold_error  : out[i] = e[i] + sum_{k<n_terms} r^(k+1) * T[k][i]            (:380-398)
- * out may alias w1 / e. */
+ * out may alias w1 / e.  With SRS_SPACE_DEVICE operands both calls are STREAM-ORDERED: they return once the kernel is
+ * enqueued on `stream` and the result is valid in stream order (host operands: blocking, as everywhere else). */
 int srs_fold_witness(int field, srs_fe *out, const srs_fe *w1, const srs_fe *w2, const srs_fe *r, size_t n,
                      int space, void *stream);
 int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const *T, size_t n_terms,

@@ -566,7 +566,8 @@ static int cross_terms_impl(srs_structure *S, srs_ck *ck, const srs_fe *W1, cons
         std::vector<fe_t *> dT(d);
         for (size_t k = 0; k < d; ++k) dT[k] = own_T ? S->io.take<fe_t>(rows) : reinterpret_cast<fe_t *>(T_out[k]);
         std::string err;
-        int erc = rowprog::evaluate(s, 0, dW1, dW2, reinterpret_cast<const fe_t *>(challenges), n_challenges, dT.data(), st, err);
+        // with a key, the batched MSM below runs on the same stream and ends with a synchronisation
+        int erc = rowprog::evaluate(s, 0, dW1, dW2, reinterpret_cast<const fe_t *>(challenges), n_challenges, dT.data(), st, err, ck == nullptr);
         if (erc) return fail(erc, "srs_cross_terms: " + err);
         if (ck) {
             std::vector<const srs_fe *> v(d);
@@ -846,8 +847,8 @@ int srs_fold_witness(int field, srs_fe *out, const srs_fe *w1, const srs_fe *w2,
         fe_t rr;
         std::memcpy(&rr, r, 32);
         if (space == SRS_SPACE_DEVICE) {
+            // device-resident operands: stream-ordered (the result is ready in `stream` order, like any library kernel)
             rowprog::fold_w(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *>(w1), reinterpret_cast<const fe_t *>(w2), rr, n, st);
-            SRS_HIP_CHECK(hipStreamSynchronize(st));
         } else {
             fe_t *a = nullptr, *b = nullptr;
             SRS_HIP_CHECK(hipMalloc((void **)&a, n * sizeof(fe_t)));
@@ -881,8 +882,7 @@ int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const 
         if (space == SRS_SPACE_DEVICE) {
             int erc = rowprog::fold_e(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *>(e),
                                       reinterpret_cast<const fe_t *const *>(T), n_terms, rr, n, st, err);
-            if (erc) return fail(erc, "srs_fold_error: " + err);
-            SRS_HIP_CHECK(hipStreamSynchronize(st));
+            if (erc) return fail(erc, "srs_fold_error: " + err);   // stream-ordered, see srs_fold_witness
         } else {
             fe_t *buf = nullptr;
             SRS_HIP_CHECK(hipMalloc((void **)&buf, (n_terms + 1) * n * sizeof(fe_t)));

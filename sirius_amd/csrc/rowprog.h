@@ -35,7 +35,7 @@ int field(const Structure *S);
 // mode 2: homogeneous gate value per row on W1  (challenges = U.ch || U.u)
 // W*, outputs: DEVICE pointers (out_dev_ptrs_host = host array of device pointers).
 int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host, size_t n_ch,
-             fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err);
+             fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err, bool sync = true);
 
 // ---- ProtoGalaxy (Fr only) ----
 struct PgSizes {   // PolyContext, src/nifs/protogalaxy/poly/mod.rs:205-269

@@ -1220,14 +1220,16 @@ const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spe
 // mode 0: cross terms (needs W2), outputs `degree` vectors; mode 1/2: plain evaluation of the
 // compressed / homogeneous expression on W1, one output vector.
 static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host,
-                         size_t n_ch, fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err);
+                         size_t n_ch, fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err, bool sync = true);
+// sync = false: the kernels are only enqueued; the caller synchronises `st` before the next call on this structure
+// (the uniform tables live in the structure's arena).  Used when an MSM over the outputs follows on the same stream.
 int evaluate(Structure *S, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host, size_t n_ch,
-             fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err) {
+             fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err, bool sync) {
     Program &p = mode == 0 ? S->cross : (mode == 1 ? S->plain_compressed : S->plain_homogeneous);
-    return evaluate_prog(S, p, mode, W1_dev, W2_dev, challenges_host, n_ch, out_dev_ptrs_host, st, err);
+    return evaluate_prog(S, p, mode, W1_dev, W2_dev, challenges_host, n_ch, out_dev_ptrs_host, st, err, sync);
 }
 static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev, const fe_t *W2_dev, const fe_t *challenges_host,
-                         size_t n_ch, fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err) {
+                         size_t n_ch, fe_t *const *out_dev_ptrs_host, hipStream_t st, std::string &err, bool sync) {
     FieldOps f{S->field};
     const uint32_t d = mode == 0 ? (uint32_t)S->degree : 0;
     const uint32_t npts = mode == 0 ? d + 1 : 1;
@@ -1270,6 +1272,7 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
         if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
         else if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);
     }
+    if (!sync) return 0;
     SRS_HIP_CHECK(hipStreamSynchronize(st));   // utab / pointer staging lives in the arena
     SRS_HIP_CHECK(hipGetLastError());
     prof::collect();
