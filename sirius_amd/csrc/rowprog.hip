@@ -170,27 +170,27 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
 
 template <class F, int ID>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_rowprog_spec(DevArgs A) {
+    // The point values P(0..d) are parked in LDS (thread-private column, no barrier) and the inverse Vandermonde is
+    // applied after the last point: keeping the d accumulators T_k live across the straight-line program cost 48 VGPRs
+    // and pushed the kernel into scratch spills at 2 waves/SIMD.
+    __shared__ fe_t Pv[(DMAX + 1) * RP_THREADS];
     uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
     const bool live = row < A.ctx.rows;
     if (!live) row = A.ctx.rows - 1;
-    fe_t T[DMAX];
-#pragma unroll
-    for (uint32_t k = 0; k < DMAX; ++k) T[k] = F::zero();
     for (uint32_t pt = 0; pt < A.npts; ++pt) {
         fe_t P = SpecCall<F, ID>::run(A.ctx, row, pt, A.utab + (size_t)pt * A.n_uniform);
         if (A.d == 0) {
             if (live) A.out[0][row] = P;
         } else {
-#pragma unroll
-            for (uint32_t k = 0; k < DMAX; ++k) {
-                if (k < A.d) T[k] = F::add(T[k], F::mul(A.vinv[k * A.npts + pt], P));
-            }
+            Pv[pt * RP_THREADS + threadIdx.x] = P;
         }
     }
     if (A.d && live) {
-#pragma unroll
-        for (uint32_t k = 0; k < DMAX; ++k)
-            if (k < A.d) A.out[k][row] = T[k];
+        for (uint32_t k = 0; k < A.d; ++k) {
+            fe_t T = F::zero();
+            for (uint32_t pt = 0; pt < A.npts; ++pt) T = F::add(T, F::mul(A.vinv[k * A.npts + pt], Pv[pt * RP_THREADS + threadIdx.x]));
+            A.out[k][row] = T;
+        }
     }
 }
 
