@@ -10,8 +10,8 @@
 // MI355X-first schedule (not the reference's bit-reverse + recursive rayon::join):
 //   * n <= 2^10: one workgroup, whole vector in LDS, bit-reversed load + DIT stages.
 //   * larger n: Cooley-Tukey over p = ceil(k/8) digits of <= 8 bits.  Pass j transforms digit j
-//     for a tile of 16 neighbouring columns (512 B contiguous per row -> coalesced HBM traffic),
-//     all 2^r x 16 elements staged in LDS (up to 128 KiB of the CU's 160 KiB), butterflies from an
+//     for a tile of 8 neighbouring columns (256 B contiguous per row -> coalesced HBM traffic),
+//     all 2^r x 8 elements staged in LDS (64 KiB: two workgroups per CU overlap compute and memory), butterflies from an
 //     LDS-resident w_(2^r) table, then ONE multiply by a precomputed inter-digit twiddle that is
 //     read coalesced (same index pattern as the data).  The last pass writes through the digit
 //     reversal so the result lands in natural order; ifft's n^-1 is folded into the first table.
@@ -26,7 +26,9 @@
 namespace srs {
 namespace ntt {
 
-constexpr uint32_t COLS = 16;      // neighbouring columns per tile (512 B rows)
+constexpr uint32_t COLS_LOG = 3;
+constexpr uint32_t COLS = 1u << COLS_LOG;   // neighbouring columns per tile: 256 B rows; a 2^8-row tile is 64 KiB, so TWO
+                                            // workgroups share a CU and one computes while the other loads / stores
 constexpr uint32_t SMALL_LOG = 10; // single-workgroup path up to 2^10 points
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -126,7 +128,7 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     __shared__ fe_t tile[(1u << RBITS) * COLS];
     __shared__ fe_t W[1u << (RBITS - 1)];
     const uint32_t rows = 1u << RBITS;
-    const uint32_t tiles_per_hi = 1u << (pa.lbits - 4);           // lbits >= 4
+    const uint32_t tiles_per_hi = 1u << (pa.lbits - COLS_LOG);    // lbits >= 4 >= COLS_LOG
     const size_t hi = blockIdx.x / tiles_per_hi;
     const uint32_t rest0 = (blockIdx.x % tiles_per_hi) * COLS;
     const size_t base = (hi << (RBITS + pa.lbits)) + rest0;
@@ -330,14 +332,14 @@ void release_plans() {
 template <uint32_t R>
 static void launch_pass(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &pre,
                         hipStream_t st) {
-    uint32_t blocks = 1u << (pa.log_n - R - 4);
+    uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
     SRS_LAUNCH((k_ntt_pass<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
 }
 template <uint32_t R>
 static void launch_last(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &fin,
                         hipStream_t st) {
-    uint32_t blocks = 1u << (pa.log_n - R - 4);
+    uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
     SRS_LAUNCH((k_ntt_last<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
 }
