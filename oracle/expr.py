@@ -68,6 +68,9 @@ def visualize(e):                  # expression.rs:244-285
         l = f"({visualize(e[1])})" if e[1][0] == 'sum' else visualize(e[1])
         r = f"({visualize(e[2])})" if e[2][0] == 'sum' else visualize(e[2])
         return f"{l} * {r}"
+    if k == 'scaled':                  # format!("{:?} * {}", trim_leading_zeros(..), a): the constant is a quoted String
+        c = "0x" + format(e[2], 'x').lstrip('0') if e[2] else "0x"
+        return f'"{c}" * {visualize(e[1])}'
     raise NotImplementedError(k)
 
 
@@ -178,6 +181,31 @@ class GroupedPoly:
             else:
                 out.append(None)
         return GroupedPoly(out)
+
+    def sub(self, rhs):                    # impl_poly_ops!(Sub, sub, Sum, Neg::neg), :166-197
+        out = []
+        for i in range(max(len(self.terms), len(rhs.terms))):
+            l = self.terms[i] if i < len(self.terms) else None
+            r = rhs.terms[i] if i < len(rhs.terms) else None
+            if l is not None and r is not None:
+                out.append(Sum(l, Neg(r)))
+            elif r is not None:
+                out.append(Neg(r))
+            elif l is not None:
+                out.append(l)
+            else:
+                out.append(None)
+        return GroupedPoly(out)
+
+    @staticmethod
+    def from_map(m):                       # From<HashMap<usize, Expression>> (tests, :285-300)
+        terms = [None] * (max(m) + 1)
+        for d, e in m.items():
+            terms[d] = e
+        return GroupedPoly(terms)
+
+    def iter_with_degree(self):            # :140-145
+        return [(d, t) for d, t in enumerate(self.terms) if t is not None]
 
     def mul_scalar(self, k):               # Mul<&F>, :198-214
         return GroupedPoly([None if t is None else Prod(Const(k), t) for t in self.terms])

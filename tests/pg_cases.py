@@ -55,3 +55,64 @@ def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
     assert np.array_equal(PG.fold_witness(0, Ws, m(Lg)), OPG.fold_witness(O, Ws, Lg)), "fold_witness"
     St.close()
     return ctx
+
+
+def direct_eval_case(S, O, k, gate_T, compat, seed=9):
+    """The reference's own ProtoGalaxy tests (src/nifs/protogalaxy/poly/mod.rs:639-760: cmp_with_direct_eval_of_F / _G):
+    the polynomial returned by compute_F / compute_G, evaluated at points of the FFT domain and at random points, equals
+    the direct sum  sum_i pow_i(challenge vector at X) * f_i(witness at X)."""
+    from oracle import expr as OE
+    from oracle import protogalaxy as OPG
+    from oracle import pyref as P
+    from sirius_amd import protogalaxy as PG
+    from workloads import gates_for, rand_fe
+    FR = P.FR
+    rnd = random.Random(seed)
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(gate_T)
+    og, fo, ao = [], 0, 0
+    for T in gate_T:
+        og.append(OE.main_gate_expression(T, 0, fo, ao, nfix)); fo += 2 * T + 5; ao += T + 2
+    rng = np.random.default_rng(seed + k)
+    fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
+    Ws = [rand_fe(rng, nadv * rows) for _ in range(2)]
+    St = S.PlonkStructure(0, k, [], fixed, nadv, gates)
+    ctx = PG.PolyContext(St, 1)
+    oS = OPG.Structure(O, og, k, [], fixed, nadv, 0)
+    n, t = ctx.count_of_evaluation_with_padding, ctx.betas_count
+    m = lambda v: O.ints_to_mont(O.FR, list(v))
+    betas = [rnd.randrange(FR) for _ in range(t)]
+    delta = rnd.randrange(FR)
+
+    def pow_i(i, c):
+        out = 1
+        for b in range(len(c)):
+            if (i >> b) & 1:
+                out = out * c[b] % FR
+        return out
+    # ---- F
+    pF = O.mont_to_ints(O.FR, PG.compute_F(ctx, m(betas), m([delta])[0], Ws[0], reference_compat=compat))
+    f = oS.evaluate_witness_fn(Ws[0], [], compat)
+    leaves = [f(i) for i in range(n)]
+    deltas = [delta]
+    for _ in range(t - 1):
+        deltas.append(deltas[-1] * deltas[-1] % FR)
+    w = P.get_omega_or_inv(ctx.fft_points_count_F.bit_length() - 1, False)
+    pts = [pow(w, j, FR) for j in range(ctx.fft_points_count_F)] + [rnd.randrange(FR) for _ in range(3)]
+    for X in pts:
+        c = [(b + X * d) % FR for b, d in zip(betas, deltas)]
+        direct = sum(pow_i(i, c) * leaves[i] for i in range(n)) % FR
+        assert OPG.poly_eval(pF, X) == direct, "compute_F vs direct evaluation"
+    # ---- G: leaves on the Lagrange-folded witness at X, weights beta' (constant in X)
+    bs = [rnd.randrange(FR) for _ in range(t)]
+    pG = O.mont_to_ints(O.FR, PG.compute_G(ctx, m(bs), Ws, reference_compat=compat))
+    wG = P.get_omega_or_inv(ctx.fft_points_count_G.bit_length() - 1, False)
+    ptsG = [pow(wG, j, FR) for j in range(ctx.fft_points_count_G)][:4] + [rnd.randrange(FR)]
+    W_int = [O.mont_to_ints(O.FR, w_) for w_ in Ws]
+    for X in ptsG:
+        Lx = P.eval_lagrange_poly_for_cyclic_group(X, ctx.lagrange_domain)
+        folded = [(Lx[0] * a + Lx[1] * b) % FR for a, b in zip(*W_int)]
+        fX = oS.evaluate_witness_fn(O.ints_to_mont(O.FR, folded), [], compat)
+        direct = sum(pow_i(i, bs) * fX(i) for i in range(n)) % FR
+        assert OPG.poly_eval(pG, X) == direct, "compute_G vs direct evaluation"
+    St.close()

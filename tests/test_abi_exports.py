@@ -46,6 +46,20 @@ def test_host_only_entries():
         assert np.array_equal(S.point_sum(cid, np.zeros((0, 8), np.uint64)), np.zeros(8, np.uint64))
 
 
+def test_univariate_eval_kats():
+    """UnivariatePoly::eval known answers of the reference (src/polynomial/univariate.rs:197-262) through srs_poly_eval
+    (host code: runs without a device)."""
+    import oracle as O
+    from sirius_amd import protogalaxy as PG
+    m = lambda v: O.ints_to_mont(O.FR, list(v))
+    ev = lambda coeffs, x: O.mont_to_ints(O.FR, PG.poly_eval(m(coeffs) if coeffs else np.zeros((0, 4), np.uint64), m([x])[0]))[0]
+    assert ev([5], 10) == 5                                   # test_constant_polynomial
+    assert ev([3, 2], 4) == 11                                # test_linear_polynomial
+    assert ev([3, 2, 1], 2) == 11                             # test_quadratic_polynomial
+    assert ev([5, 1, 2, 3, 4], 2) == 5 + 2 + 8 + 24 + 64      # test_high_degree_polynomial
+    assert ev([], 1) == 0                                     # test_zero_polynomial
+
+
 def test_no_device_fails_loudly():
     """Without a GPU a compute entry must return SRS_ERR_DEVICE, never a CPU result."""
     import torch

@@ -81,6 +81,12 @@ def test_emu_protogalaxy(emu, oracle):
     run_pg_case(emu, oracle, 4, [2], 3, False)
 
 
+def test_emu_protogalaxy_direct_eval(emu, oracle):
+    from pg_cases import direct_eval_case
+    direct_eval_case(emu, oracle, 4, [3, 2], True)
+    direct_eval_case(emu, oracle, 4, [2], False)
+
+
 def test_emu_key_file_and_deciders(emu, oracle, tmp_path):
     from test_commit_gpu import _key_file_roundtrip
     from test_sangria_gpu import _is_sat_case

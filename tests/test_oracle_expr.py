@@ -4,6 +4,7 @@ string KATs (src/main_gate.rs:893-927) and to the GraphEvaluator property test
 import numpy as np
 
 from oracle import expr as E
+OE = E
 from oracle import pyref as P
 
 
@@ -111,3 +112,49 @@ def test_cross_terms_are_coefficients(oracle):
         lhs = at(x)
         rhs = (at(0) + sum(Ti[kk][row] * pow(x, kk + 1, p) for kk in range(cg.degree))) % p
         assert lhs == rhs
+
+
+# ---- the reference's remaining string KATs of the cross-term derivation
+def _fmt(gp):
+    return [f"{d};{OE.visualize(t)}" for d, t in gp.iter_with_degree()]
+
+
+def test_grouped_poly_kats():              # src/polynomial/grouped_poly.rs:294-461
+    U128 = (1 << 128) - 1
+    a = OE.GroupedPoly.from_map({0: OE.Const(U128), 1: OE.Poly(0), 5: OE.Chal(0)})
+    b = OE.GroupedPoly.from_map({0: OE.Chal(0), 2: OE.Poly(5, -2), 5: OE.Const(1)})
+    assert _fmt(a.add(b)) == ["0;0xffffffffffffffffffffffffffffffff + r_0", "1;Z_0", "2;Z_5[-2]", "5;r_0 + 0x1"]          # simple_add
+    a = OE.GroupedPoly.from_map({0: OE.Const(U128), 1: OE.Poly(0), 5: OE.Const(1)})
+    b = OE.GroupedPoly.from_map({0: OE.Chal(0), 2: OE.Poly(5, -2), 5: OE.Chal(0)})
+    assert _fmt(a.sub(b)) == ["0;0xffffffffffffffffffffffffffffffff - r_0", "1;Z_0", "2;-Z_5[-2]", "5;0x1 - r_0"]         # simple_sub
+    a = OE.GroupedPoly.from_map({9: OE.Sum(OE.Poly(0), OE.Poly(1, 1))})
+    b = OE.GroupedPoly.from_map({9: OE.Prod(OE.Poly(2), OE.Poly(3))})
+    assert _fmt(a.mul(b)) == ["18;Z_2 * Z_3 * (Z_0 + Z_1[+1])"]                                                           # simple_mul
+    a = OE.GroupedPoly.from_map({2: OE.Poly(0), 3: OE.Poly(1), 4: OE.Poly(2)})
+    b = OE.GroupedPoly.from_map({2: OE.Poly(3), 3: OE.Poly(4), 4: OE.Poly(5)})
+    assert _fmt(a.mul(b)) == ["4;Z_3 * Z_0", "5;Z_4 * Z_0 + Z_3 * Z_1", "6;Z_5 * Z_0 + Z_4 * Z_1 + Z_3 * Z_2",
+                              "7;Z_5 * Z_1 + Z_4 * Z_2", "8;Z_5 * Z_2"]                                                  # mul
+
+    def sum_(xs):                                                                                                          # creation
+        return OE.Sum(xs[0], sum_(xs[1:])) if xs else OE.Const(0)
+    va, vb, vc, vd, ve = [OE.Poly(i) for i in range(5)]
+    gp = OE.GroupedPoly.new(OE.Prod(sum_([va, vb, vc]), sum_([vd, ve])), OE.QueryIndexContext(0, 0, 5, 0, 0))
+    assert _fmt(gp) == ["0;(Z_3 + Z_4 + 0x) * (Z_0 + Z_1 + Z_2 + 0x)",
+                        "1;(Z_8 + Z_9) * (Z_0 + Z_1 + Z_2 + 0x) + (Z_3 + Z_4 + 0x) * (Z_5 + Z_6 + Z_7)",
+                        "2;(Z_8 + Z_9) * (Z_5 + Z_6 + Z_7)"]
+
+
+def test_expression_kats():                # src/polynomial/expression.rs:530-606
+    z0 = OE.Poly(0)
+    e1 = OE.Sum(z0, OE.Neg(OE.Const(1)))                       # Z_0 - 1   (Sub = Sum(a, Neg(b)), :497)
+    expr = OE.Sum(OE.Prod(e1, e1), OE.Scaled(z0, 2))
+    assert OE.visualize(expr) == '(Z_0 - 0x1) * (Z_0 - 0x1) + "0x2" * Z_0'                                                # test_expression
+    a, b = OE.Poly(0), OE.Poly(1)
+    e3 = OE.Sum(OE.Sum(a, OE.Const(1)), OE.Prod(a, b))
+    h, _ = OE.homogeneous(e3, OE.QueryIndexContext(0, 0, 2, 0, 0))
+    assert OE.visualize(h) == "(Z_0 + 0x1 * r_0) * r_0 + Z_0 * Z_1"                                                       # test_homogeneous_simple
+    a, b, c, d, e = [OE.Poly(i) for i in range(5)]
+    ex = OE.Sum(OE.Sum(OE.Sum(a, OE.Prod(a, b)), OE.Prod(OE.Prod(a, b), c)), OE.Prod(OE.Prod(OE.Prod(OE.Prod(a, b), c), d), e))
+    h, deg = OE.homogeneous(ex, OE.QueryIndexContext(0, 0, 5, 0, 0))
+    assert deg == 5
+    assert OE.visualize(h) == "((Z_0 * r_0 + Z_0 * Z_1) * r_0 + Z_0 * Z_1 * Z_2) * r_0 * r_0 + Z_0 * Z_1 * Z_2 * Z_3 * Z_4"  # test_homogeneous

@@ -4,7 +4,7 @@ quirks Q1 (row index), Q2 (K domain) and Q3 (betas) reproduced."""
 import numpy as np
 import pytest
 
-from pg_cases import run_pg_case
+from pg_cases import direct_eval_case, run_pg_case
 
 pytestmark = pytest.mark.gpu
 
@@ -116,3 +116,10 @@ def test_protogalaxy_fold_identity(srs, oracle):
     _pg_fold_identity(srs, oracle, 6, (5, 3), True)
     _pg_fold_identity(srs, oracle, 10, (5, 3), False)
     _pg_fold_identity(srs, oracle, 5, (2,), False)
+
+
+def test_cmp_with_direct_eval(srs, oracle):
+    """src/nifs/protogalaxy/poly/mod.rs:639-760 restated on the product."""
+    direct_eval_case(srs, oracle, 5, [5, 3], True)
+    direct_eval_case(srs, oracle, 6, [3, 2], False)
+    direct_eval_case(srs, oracle, 10, [5, 3], False)      # specialised leaf kernel
