@@ -170,3 +170,49 @@ def test_two_host_threads_distinct_handles(srs, oracle):
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs
+
+
+def _degenerate_bases_case(S, O, cid, n):
+    """Keys with REPEATED and NEGATED points: equal points meet in one bucket (mixed add -> doubling), equal partial sums
+    meet in the tail (XYZZ add / quad add -> doubling), P + (-P) cancels to the identity at every level.  The reference's
+    best_multiexp is complete for all of these; so must every addition here be."""
+    from oracle import pyref as P
+    q = P.CURVES[cid].q
+    sf = O.SCALAR_FIELD[cid]
+    pool = O.make_bases(cid, 3, 4)
+    neg = pool.copy()
+    fld = O.BASE_FIELD[cid]
+    neg[:, 4:] = O.fe_sub(fld, np.zeros_like(pool[:, 4:]), pool[:, 4:])          # (x, -y)
+    rng = np.random.default_rng(n + cid)
+    # (a) one point repeated n times, one scalar: every bucket entry is the same point
+    bases = np.repeat(pool[:1], n, axis=0)
+    ck = S.CommitmentKey(cid, bases)
+    for v in (1, 5, 0x10001, q - 1, (1 << 200) + 12345):
+        sc = O.ints_to_mont(sf, [v] * n)
+        assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases)), ("repeat", v)
+    ck.close()
+    # (b) P, -P interleaved with equal scalars: total is the identity, all-zero affine encoding
+    bases = np.empty((n, 8), np.uint64)
+    bases[0::2], bases[1::2] = pool[1], neg[1]
+    ck = S.CommitmentKey(cid, bases)
+    sc = O.ints_to_mont(sf, [0x123456789ABCDEF] * n)
+    got = ck.commit(sc)
+    assert not got.any() and np.array_equal(got, O.msm(cid, sc, bases))
+    ck.close()
+    # (c) random mixture of 4 points and their negatives, few distinct scalars (collisions everywhere), batch of 3
+    idx = rng.integers(0, 8, size=n)
+    bases = np.where((idx < 4)[:, None], pool[idx % 4], neg[idx % 4])
+    ck = S.CommitmentKey(cid, bases)
+    vs = []
+    for j in range(3):
+        vals = [int(x) for x in rng.choice([1, 2, 3, 0xFFFF, 0x10000, q - 2, q - 1, (1 << 128) + 7], size=n)]
+        vs.append(O.ints_to_mont(sf, vals))
+    for g, v in zip(ck.commit_batch(vs), vs):
+        assert np.array_equal(g, O.msm(cid, v, bases))
+    ck.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_commit_degenerate_bases(srs, oracle, cid):
+    _degenerate_bases_case(srs, oracle, cid, 6000)
+    _degenerate_bases_case(srs, oracle, cid, 70000)       # enough entries for several accumulation levels

@@ -125,3 +125,8 @@ def test_emu_deciders(emu, oracle):
     _permutation_case(emu, oracle, 0, 5, 3, 2)
     _general_sparse_case(emu, oracle, 1, 40, 200, 3)
     _witness_commit_case(emu, oracle, 1, 200, 96)
+
+
+def test_emu_commit_degenerate_bases(emu, oracle):
+    from test_commit_gpu import _degenerate_bases_case
+    _degenerate_bases_case(emu, oracle, 1, 200)
