@@ -308,6 +308,77 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_spec(PgArgs A) {
     }
 }
 
+// compute_F as a POLYNOMIAL tree (no evaluation points, no ifft).  F(X) = sum_i f_i prod_{b in bits(i)} (beta_b + X delta_b)
+// has degree t = log2(#leaves); the reference evaluates it at next_pow2(t + 1) points (one weighted tree per point, t'n
+// multiplies) and interpolates.  The same coefficients come out of ONE tree whose nodes are polynomials:
+//   node = left + right * (beta_h + X delta_h)   ->   2 (deg + 1) multiplies per node, ~4 n in total instead of 32 n
+// (exact arithmetic: identical coefficients, the ones above degree t are exactly zero in the reference's ifft too).
+// k_pg_F_leaves: every thread evaluates its 8 leaves (same coalesced mapping as k_pg_leaves) and folds them over the
+// three leaf-index bits it owns into a cubic; nodes are stored coefficient-major nodes[m * n_nodes + node].
+struct PgFLevels {
+    fe_t beta[3], delta[3];      // weights of leaf-index bits TL, TL + 1, TL + 2
+};
+template <class F, uint32_t NSLOT, int ID>
+__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLevels Lv, fe_t *__restrict__ nodes, uint32_t n_nodes) {
+    __shared__ fe_t slots[NSLOT * RP_THREADS];
+    constexpr uint32_t LPT = 8, LPT_LOG = 3;
+    const uint32_t gate = blockIdx.y, tile = blockIdx.x;
+    const GateProg G = A.gates[gate];
+    const uint32_t TL = A.tile_log - LPT_LOG;
+    const uint32_t row0 = (tile << A.tile_log) + threadIdx.x;
+    fe_t v[LPT];
+#pragma unroll
+    for (uint32_t l = 0; l < LPT; ++l) {
+        const uint32_t row = A.compat ? 0u : row0 + (l << TL);
+        if constexpr (ID >= 0) v[l] = PgSpecCall<F, (ID >= 0 ? ID : 0)>::run(gate, A.ctx, row, 0, A.utab + G.utab_off);
+        else v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, row, 0, A.utab + G.utab_off);
+    }
+    (void)slots;
+    fe_t c0[4], c1[4];                                     // bit TL: (v0 + v1 (beta + X delta))
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        c0[j] = F::add(v[2 * j], F::mul(v[2 * j + 1], Lv.beta[0]));
+        c1[j] = F::mul(v[2 * j + 1], Lv.delta[0]);
+    }
+    fe_t e0[2], e1[2], e2[2];                              // bit TL + 1
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {
+        e0[j] = F::add(c0[2 * j], F::mul(c0[2 * j + 1], Lv.beta[1]));
+        e1[j] = F::add(F::add(c1[2 * j], F::mul(c1[2 * j + 1], Lv.beta[1])), F::mul(c0[2 * j + 1], Lv.delta[1]));
+        e2[j] = F::mul(c1[2 * j + 1], Lv.delta[1]);
+    }
+    const uint32_t node = (gate * gridDim.x + tile) * blockDim.x + threadIdx.x;      // bit TL + 2
+    nodes[(size_t)0 * n_nodes + node] = F::add(e0[0], F::mul(e0[1], Lv.beta[2]));
+    nodes[(size_t)1 * n_nodes + node] = F::add(F::add(e1[0], F::mul(e1[1], Lv.beta[2])), F::mul(e0[1], Lv.delta[2]));
+    nodes[(size_t)2 * n_nodes + node] = F::add(F::add(e2[0], F::mul(e2[1], Lv.beta[2])), F::mul(e1[1], Lv.delta[2]));
+    nodes[(size_t)3 * n_nodes + node] = F::mul(e2[1], Lv.delta[2]);
+}
+
+// one level of the polynomial tree: out[i] = in[2i] + in[2i+1] * (beta + X delta); nodes >= m_valid are zero.
+// coefficient-major arrays: in[m * n_in + node] (degree deg_in), out[m * n_out + node] (degree deg_in + 1)
+template <class F>
+__global__ void k_pg_F_level(const fe_t *__restrict__ in, uint32_t n_in, uint32_t m_valid, uint32_t deg_in, fe_t beta, fe_t delta,
+                             fe_t *__restrict__ out, uint32_t n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const bool hasL = 2 * i < m_valid, hasR = 2 * i + 1 < m_valid;
+    fe_t prevR = F::zero();
+    for (uint32_t m = 0; m <= deg_in + 1; ++m) {
+        fe_t acc = F::zero();
+        fe_t r = F::zero();
+        if (m <= deg_in) {
+            if (hasL) acc = in[(size_t)m * n_in + 2 * i];
+            if (hasR) {
+                r = in[(size_t)m * n_in + 2 * i + 1];
+                acc = F::add(acc, F::mul(r, beta));
+            }
+        }
+        if (m >= 1 && hasR) acc = F::add(acc, F::mul(prevR, delta));
+        out[(size_t)m * n_out + i] = acc;
+        prevR = r;
+    }
+}
+
 #define SRS_SPEC_PART 2
 #include "rowprog_spec.inc"
 #undef SRS_SPEC_PART
@@ -1437,6 +1508,77 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     const uint32_t tile = (1u << tile_log) / lpt, tiles_per_gate = (uint32_t)(S->rows >> tile_log);
     const size_t n_tiles_valid = (size_t)n_gates * tiles_per_gate;
     const size_t n_tiles_padded = sz.count_with_padding >> tile_log;
+    // ---- compute_F with >= 1024 rows per gate: polynomial tree (see k_pg_F_leaves); the evaluate-and-interpolate route
+    //      below stays for small tables and as the cross-check (SRS_PG_F_EVAL=1)
+    if (mode == 0 && lpt == 8 && !std::getenv("SRS_PG_F_EVAL")) {
+        const uint32_t TL = tile_log - 3, T = tile;
+        const size_t n0 = n_tiles_padded * T;
+        Arena &A = S->arena;
+        A.reserve(2 * Arena::pad((4 * n0 + 64) * sizeof(fe_t)) + Arena::pad((utab.size() + 1) * sizeof(fe_t)) +
+                  Arena::pad(gp.size() * sizeof(GateProg)) + 4096);
+        A.reset();
+        fe_t *d_utab = A.take<fe_t>(utab.size() + 1);
+        GateProg *d_gp = A.take<GateProg>(gp.size());
+        fe_t *cur = A.take<fe_t>(4 * n0 + 64), *nxt = A.take<fe_t>(4 * n0 + 64);
+        SRS_HIP_CHECK(hipMemcpyAsync(d_utab, utab.data(), utab.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
+        SRS_HIP_CHECK(hipMemcpyAsync(d_gp, gp.data(), gp.size() * sizeof(GateProg), hipMemcpyHostToDevice, st));
+        std::vector<fe_t> deltas(levels);
+        {
+            fe_t d = *delta;                                   // deltas: delta^(2^b)  (:97-99)
+            for (uint32_t b = 0; b < levels; ++b) { deltas[b] = d; d = Fr::sqr(d); }
+        }
+        PgArgs a;
+        a.gates = d_gp;
+        a.n_gates = n_gates;
+        a.log_rows = S->k;
+        a.ctx.rows = (uint32_t)S->rows;
+        a.ctx.sel = S->d_sel_ptrs;
+        a.ctx.fix = S->d_fix_ptrs;
+        for (uint32_t j = 0; j < JMAX; ++j) a.ctx.W[j] = j < 1 ? W_dev[j] : nullptr;
+        a.ctx.J = 1;
+        a.ctx.wcoef = nullptr;
+        a.compat = compat;
+        a.leaf_pts = 1;
+        a.P = 1;
+        a.utab = d_utab;
+        a.weights = nullptr;
+        a.wpts = 1;
+        a.tile_log = tile_log;
+        a.partial = nullptr;
+        PgFLevels lv;
+        for (uint32_t j = 0; j < 3; ++j) { lv.beta[j] = weights_in[TL + j]; lv.delta[j] = deltas[TL + j]; }
+        {
+            prof::Scope ps("pg_F_leaves", st, S->rows * n_gates);
+            if (S->pg_spec_id == 0) SRS_LAUNCH((k_pg_F_leaves<Fr, 1, 0>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+            else if (max_slots <= 8) SRS_LAUNCH((k_pg_F_leaves<Fr, 8, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+            else if (max_slots <= 16) SRS_LAUNCH((k_pg_F_leaves<Fr, 16, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+            else SRS_LAUNCH((k_pg_F_leaves<Fr, 32, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+        }
+        // remaining leaf-index bits, in the order adjacent nodes differ: thread bits 0 .. TL-1, then tile / gate bits TL+3 ..
+        std::vector<uint32_t> order;
+        for (uint32_t b = 0; b < TL; ++b) order.push_back(b);
+        for (uint32_t b = TL + 3; b < levels; ++b) order.push_back(b);
+        size_t n_in = n0, m_valid = n_tiles_valid * T;
+        uint32_t deg = 3;
+        for (uint32_t b : order) {
+            const size_t n_out = n_in / 2;
+            SRS_LAUNCH((k_pg_F_level<Fr>), ((uint32_t)((n_out + 127) / 128)), (128), 0, st, (const fe_t *)cur, (uint32_t)n_in,
+                       (uint32_t)m_valid, deg, weights_in[b], deltas[b], nxt, (uint32_t)n_out);
+            n_in = n_out;
+            m_valid = (m_valid + 1) / 2;
+            ++deg;
+            std::swap(cur, nxt);
+        }
+        // n_in == 1: cur[m] = coefficient m, m <= deg = levels; the reference's vector has fft_points_count_F entries
+        std::vector<fe_t> coef(deg + 1);
+        SRS_HIP_CHECK(hipMemcpyAsync(coef.data(), cur, coef.size() * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+        SRS_HIP_CHECK(hipStreamSynchronize(st));
+        SRS_HIP_CHECK(hipGetLastError());
+        prof::collect();
+        for (uint32_t m = 0; m < P; ++m) out_host[m] = m < coef.size() ? coef[m] : Fr::zero();
+        *n_out = P;
+        return 0;
+    }
     // ---- device staging
     Arena &A = S->arena;
     size_t need = Arena::pad(weights.size() * sizeof(fe_t)) + Arena::pad((wcoef.size() + 1) * sizeof(fe_t)) +

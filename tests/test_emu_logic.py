@@ -81,6 +81,13 @@ def test_emu_protogalaxy(emu, oracle):
     run_pg_case(emu, oracle, 4, [2], 3, False)
 
 
+def test_emu_protogalaxy_polynomial_tree_F(emu, oracle):
+    """k >= 10: compute_F runs the polynomial tree (k_pg_F_leaves / k_pg_F_level), interpreter and specialised leaves."""
+    from pg_cases import run_pg_case
+    run_pg_case(emu, oracle, 10, [2], 1, False)
+    run_pg_case(emu, oracle, 10, [5, 3], 1, True)
+
+
 def test_emu_protogalaxy_direct_eval(emu, oracle):
     from pg_cases import direct_eval_case
     direct_eval_case(emu, oracle, 4, [3, 2], True)
