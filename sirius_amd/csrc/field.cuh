@@ -108,6 +108,22 @@ struct Fp {
         for (int i = 0; i < 8; ++i) o.v[i] = borrow ? a.v[i] : d.v[i];
         return o;
     }
+    // a / 2 mod p: (a + (a odd ? p : 0)) >> 1.  Same on Montgomery representatives ((aR)/2 = (a/2)R).
+    SRS_HD static fe_t halve(const fe_t &a) {
+        const uint32_t mask = 0u - (a.v[0] & 1u);
+        fe_t s;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint64_t t = (uint64_t)a.v[i] + (P::p(i) & mask) + c;
+            s.v[i] = (uint32_t)t;
+            c = (uint32_t)(t >> 32);
+        }
+        fe_t o;                                   // a + p < 2p < 2^255: no carry out of limb 7
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = (s.v[i] >> 1) | (i < 7 ? (s.v[i + 1] << 31) : 0u);
+        return o;
+    }
     SRS_HD static fe_t add(const fe_t &a, const fe_t &b) {
         fe_t s;
         uint32_t c = 0;
