@@ -64,7 +64,7 @@ SRS_D fe_t quad_bcast(const fe_t &x) {
 }
 // operand of the lane's role: value selects limb by limb on by-value arguments.  (A nested ?: over references, or
 // reference parameters here, make the compiler select POINTERS and park the points in scratch memory -- measured:
-// 144-336 B of scratch per lane and no latency gain at all; tools/scratch/quad_probe.hip.)
+// 144-336 B of scratch per lane and no latency gain at all; tools/quad_probe.hip.)
 SRS_D fe_t quad_select(uint32_t q, fe_t a0, fe_t a1, fe_t a2, fe_t a3) {   // BY VALUE, see below
     fe_t o;
 #pragma unroll

@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../../sirius_amd/csrc/curve.cuh"
+#include "../sirius_amd/csrc/curve.cuh"
 using namespace srs;
 __device__ __forceinline__ fe_t qsel(uint32_t q, fe_t a0, fe_t a1, fe_t a2, fe_t a3) {
     fe_t o;
