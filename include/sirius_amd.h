@@ -173,7 +173,8 @@ size_t srs_structure_num_witness_columns(const srs_structure *S);   /* num_advic
 size_t srs_structure_num_cross_terms(const srs_structure *S);   /* d = grouped().len() - 1 */
 size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructure::num_challenges */
 /* Developer hook: the straight-line C++ of a compiled row program (which: 0 cross terms, 1 compressed,
- * 2 homogeneous), its fingerprint and the ahead-of-time specialised kernel it maps to (-1 = interpreter).
+ * 2 homogeneous), its fingerprint and the kernel it runs on: >= 0 ahead-of-time specialised kernel, -1 interpreter,
+ * -2 straight-line kernel compiled at structure creation with hiprtc (structures of >= 2^14 rows without an ahead-of-time kernel).
  * Returns the source length (truncated to cap-1).  Used by tools/gen_rowprog_spec.py. */
 size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id);
 

@@ -6,13 +6,10 @@
 
 #include "devrt.h"
 #include "field.cuh"
+#include "rowprog_dev.cuh"
 
 namespace srs {
 namespace rowprog {
-
-struct Insn {   // 16 bytes, read wave-uniformly
-    uint32_t op, dst, a, b;
-};
 
 struct Structure;
 

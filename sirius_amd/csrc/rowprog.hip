@@ -20,6 +20,9 @@
 #include "rowprog.h"
 #include "ntt.h"
 #include "prof.h"
+#if !defined(SRS_EMU)
+#include "jit.h"
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -31,81 +34,7 @@
 namespace srs {
 namespace rowprog {
 
-// ---------------------------------------------------------------------------------------------
-// device program
-// ---------------------------------------------------------------------------------------------
-enum : uint32_t { I_LD_SEL = 0, I_LD_FIX, I_LD_ADV, I_ADD, I_SUB, I_MUL, I_SQR, I_DBL, I_NEG };
-constexpr uint32_t UNIFORM_BIT = 0x80000000u;
-constexpr uint32_t RP_THREADS = 128;
-constexpr uint32_t DMAX = 8;   // cross terms kept in VGPRs per pass; higher degrees take ceil(d / 8) passes over the points
-constexpr uint32_t DEGREE_LIMIT = 255;   // evaluation points 0..d must stay < 2^8 (small_times)
-
-constexpr uint32_t JMAX = 4;   // witnesses combined by one advice load (cross terms: 2; ProtoGalaxy G: L + 1 <= 4)
-
-// everything a row needs besides the program
-struct RowCtx {
-    uint32_t rows;
-    const uint8_t *const *sel;
-    const fe_t *const *fix;
-    const fe_t *W[JMAX];      // column-major [num_advice][rows] each
-    uint32_t J;               // number of witnesses
-    const fe_t *wcoef;        // [npts][J] combination coefficients, or nullptr:
-                              //   J == 1: W[0];  J == 2: W[0] + pt * W[1]  (cross-term points X = pt)
-    uint32_t half;            // J == 2, wcoef == nullptr: (W[0] + W[1]) / 2 + pt * (W[0] - W[1]) / 2, i.e. the Lagrange fold
-                              //   L_0(X) W[0] + L_1(X) W[1] over the domain {1, -1} at the integer point X = pt (compute_G, L = 1)
-};
-
-struct DevArgs {
-    const Insn *prog;
-    uint32_t n_insn;
-    uint32_t result;          // operand code of the expression value
-    RowCtx ctx;
-    const fe_t *utab;         // [npts][n_uniform]
-    uint32_t n_uniform;
-    uint32_t npts;            // d + 1 (interpolate) or 1 (plain evaluation)
-    uint32_t d;               // number of outputs in interpolate mode
-    const fe_t *vinv;         // [d][npts]: T_k = sum_j vinv[(k-1)*npts + j] * P(j)
-    fe_t *const *out;         // d (interpolate) or 1 (plain) output vectors of `rows`
-};
-
-template <class F>
-__device__ __forceinline__ fe_t small_times(const fe_t &x, uint32_t j) {   // j * x for a tiny j
-    fe_t acc = F::zero();
-    bool any = false;
-    for (int b = j < 32u ? 4 : 7; b >= 0; --b) {
-        if (any) acc = F::dbl(acc);
-        if ((j >> b) & 1u) {
-            acc = any ? F::add(acc, x) : x;
-            any = true;
-        }
-    }
-    return acc;
-}
-
-// column loads (PlonkEvalDomain::eval_column_var / eval_advice_var, src/plonk/eval.rs:57-69,153-228)
-template <class F>
-__device__ __forceinline__ fe_t ld_sel(const RowCtx &C, uint32_t col, uint32_t rr) { return C.sel[col][rr] ? F::one() : F::zero(); }
-template <class F>
-__device__ __forceinline__ fe_t ld_fix(const RowCtx &C, uint32_t col, uint32_t rr) { return C.fix[col][rr]; }
-template <class F>
-__device__ __forceinline__ fe_t ld_adv(const RowCtx &C, uint32_t col, uint32_t rr, uint32_t pt) {
-    size_t idx = (size_t)col * C.rows + rr;
-    if (C.wcoef == nullptr) {
-        fe_t r = C.W[0][idx];
-        if (C.J == 2 && C.half) {
-            const fe_t w1 = C.W[1][idx];
-            const fe_t a = F::halve(F::add(r, w1)), b = F::halve(F::sub(r, w1));
-            return pt ? F::add(a, small_times<F>(b, pt)) : a;
-        }
-        if (C.J == 2 && pt) r = F::add(r, small_times<F>(C.W[1][idx], pt));
-        return r;
-    }
-    const fe_t *cf = C.wcoef + (size_t)pt * C.J;
-    fe_t r = F::mul(cf[0], C.W[0][idx]);
-    for (uint32_t j = 1; j < C.J; ++j) r = F::add(r, F::mul(cf[j], C.W[j][idx]));
-    return r;
-}
-
+// device-side definitions (RowCtx, DevArgs, column loads, specialised-kernel body): rowprog_dev.cuh
 // interpret one row program at evaluation point `pt`; registers = LDS slots [slot][thread]
 template <class F>
 __device__ __forceinline__ fe_t interp(fe_t *slots, const Insn *__restrict__ prog, uint32_t n_insn, uint32_t result,
@@ -177,28 +106,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
 
 template <class F, int ID>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_rowprog_spec(DevArgs A) {
-    // The point values P(0..d) are parked in LDS (thread-private column, no barrier) and the inverse Vandermonde is
-    // applied after the last point: keeping the d accumulators T_k live across the straight-line program cost 48 VGPRs
-    // and pushed the kernel into scratch spills at 2 waves/SIMD.
-    __shared__ fe_t Pv[(DMAX + 1) * RP_THREADS];
-    uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
-    const bool live = row < A.ctx.rows;
-    if (!live) row = A.ctx.rows - 1;
-    for (uint32_t pt = 0; pt < A.npts; ++pt) {
-        fe_t P = SpecCall<F, ID>::run(A.ctx, row, pt, A.utab + (size_t)pt * A.n_uniform);
-        if (A.d == 0) {
-            if (live) A.out[0][row] = P;
-        } else {
-            Pv[pt * RP_THREADS + threadIdx.x] = P;
-        }
-    }
-    if (A.d && live) {
-        for (uint32_t k = 0; k < A.d; ++k) {
-            fe_t T = F::zero();
-            for (uint32_t pt = 0; pt < A.npts; ++pt) T = F::add(T, F::mul(A.vinv[k * A.npts + pt], Pv[pt * RP_THREADS + threadIdx.x]));
-            A.out[k][row] = T;
-        }
-    }
+    spec_kernel_body<F>(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return SpecCall<F, ID>::run(C, row, pt, U); });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1013,6 +921,9 @@ struct Program {
     int result_vreg = -1;
     uint64_t fingerprint = 0;       // FNV-1a of the SSA program
     int spec_id = -1;               // index into the ahead-of-time specialised kernels, or -1
+#if !defined(SRS_EMU)
+    jit::Kernel jit;                // straight-line kernel compiled at structure creation (jit.hip), or empty
+#endif
 };
 
 static uint64_t fingerprint_of(const Program &p) {
@@ -1197,6 +1108,23 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         for (size_t i = 0; i < lroots.size(); ++i)
             if (!build_program(ast, lroots[i], f, lctx, false, S->lookup_progs[i], err)) { rc = 7; return nullptr; }
     }
+#if !defined(SRS_EMU)
+    // ---- no ahead-of-time kernel for this gate set: compile the cross-term program now (jit.hip).  Worth it from 2^14
+    //      rows on (one hiprtc compile ~ a second); single-pass degrees only (the kernel body parks d + 1 <= 9 points).
+    if (S->cross.spec_id < 0 && S->degree >= 1 && S->degree <= DMAX && !S->cross.insns.empty() && jit::enabled() &&
+        (k >= 14 || std::getenv("SRS_JIT_ALWAYS"))) {
+        std::string src = "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" + emit_spec_source(S->cross, "jit_fn");
+        const char *fname = field == 0 ? "Fr" : "Fq";
+        src += std::string("extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n") +
+               "    spec_kernel_body<" + fname + ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname +
+               ">(C, row, pt, U); });\n}\n}\n}\n";
+        std::string log;
+        if (!jit::compile(src, "srs_jit_rowprog", S->cross.jit, log) && std::getenv("SRS_DEBUG_ROWPROG"))
+            std::fprintf(stderr, "rowprog: hiprtc compile failed, staying on the interpreter:\n%s\n", log.c_str());
+        else if (std::getenv("SRS_DEBUG_ROWPROG"))
+            std::fprintf(stderr, "rowprog: cross-term program compiled at run time in %.2f s\n", S->cross.jit.compile_seconds);
+    }
+#endif
     // ---- device residency: programs, fixed columns, selectors
     rc = 5;
     for (auto &lp : S->lookup_progs) upload_program(lp, *S);
@@ -1234,6 +1162,9 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
 
 void destroy(Structure *S) {
     if (!S) return;
+#if !defined(SRS_EMU)
+    jit::release(S->cross.jit);
+#endif
     for (void *p : S->owned) (void)hipFree(p);
     S->arena.release();
     delete S;
@@ -1292,6 +1223,9 @@ const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spe
     buf = emit_spec_source(p, "spec_fn");
     if (fingerprint) *fingerprint = p.fingerprint;
     if (spec_id) *spec_id = p.spec_id;
+#if !defined(SRS_EMU)
+    if (spec_id && p.spec_id < 0 && p.jit.function) *spec_id = -2;      // compiled at run time
+#endif
     return buf.c_str();
 }
 
@@ -1349,6 +1283,11 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
         a.out = d_out + k0;
         prof::Scope ps(mode == 0 ? "rowprog_cross_terms" : "rowprog_eval", st, S->rows);
         if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
+#if !defined(SRS_EMU)
+        else if (p.jit.function) {
+            if (!jit::launch(p.jit, (a.ctx.rows + RP_THREADS - 1) / RP_THREADS, RP_THREADS, &a, st)) { err = "launch of the run-time compiled row program failed"; return 5; }
+        }
+#endif
         else if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);
     }
     if (!sync) return 0;

@@ -1,0 +1,116 @@
+// rowprog_dev.cuh -- device-side definitions shared by the ahead-of-time kernels in rowprog.hip and by the row programs
+// compiled at run time with hiprtc (jit.hip embeds this file verbatim: keep it free of host-only includes).
+#pragma once
+#include "field.cuh"
+#if defined(SRS_EMU)
+#include "hipemu.h"   // CPU logic emulator (tests/emu)
+#endif
+
+namespace srs {
+namespace rowprog {
+
+struct Insn {   // 16 bytes, read wave-uniformly
+    uint32_t op, dst, a, b;
+};
+
+enum : uint32_t { I_LD_SEL = 0, I_LD_FIX, I_LD_ADV, I_ADD, I_SUB, I_MUL, I_SQR, I_DBL, I_NEG };
+constexpr uint32_t UNIFORM_BIT = 0x80000000u;
+constexpr uint32_t RP_THREADS = 128;
+constexpr uint32_t DMAX = 8;   // cross terms kept in VGPRs per pass; higher degrees take ceil(d / 8) passes over the points
+constexpr uint32_t DEGREE_LIMIT = 255;   // evaluation points 0..d must stay < 2^8 (small_times)
+
+constexpr uint32_t JMAX = 4;   // witnesses combined by one advice load (cross terms: 2; ProtoGalaxy G: L + 1 <= 4)
+
+// everything a row needs besides the program
+struct RowCtx {
+    uint32_t rows;
+    const uint8_t *const *sel;
+    const fe_t *const *fix;
+    const fe_t *W[JMAX];      // column-major [num_advice][rows] each
+    uint32_t J;               // number of witnesses
+    const fe_t *wcoef;        // [npts][J] combination coefficients, or nullptr:
+                              //   J == 1: W[0];  J == 2: W[0] + pt * W[1]  (cross-term points X = pt)
+    uint32_t half;            // J == 2, wcoef == nullptr: (W[0] + W[1]) / 2 + pt * (W[0] - W[1]) / 2, i.e. the Lagrange fold
+                              //   L_0(X) W[0] + L_1(X) W[1] over the domain {1, -1} at the integer point X = pt (compute_G, L = 1)
+};
+
+struct DevArgs {
+    const Insn *prog;
+    uint32_t n_insn;
+    uint32_t result;          // operand code of the expression value
+    RowCtx ctx;
+    const fe_t *utab;         // [npts][n_uniform]
+    uint32_t n_uniform;
+    uint32_t npts;            // d + 1 (interpolate) or 1 (plain evaluation)
+    uint32_t d;               // number of outputs in interpolate mode
+    const fe_t *vinv;         // [d][npts]: T_k = sum_j vinv[(k-1)*npts + j] * P(j)
+    fe_t *const *out;         // d (interpolate) or 1 (plain) output vectors of `rows`
+};
+
+template <class F>
+__device__ __forceinline__ fe_t small_times(const fe_t &x, uint32_t j) {   // j * x for a tiny j
+    fe_t acc = F::zero();
+    bool any = false;
+    for (int b = j < 32u ? 4 : 7; b >= 0; --b) {
+        if (any) acc = F::dbl(acc);
+        if ((j >> b) & 1u) {
+            acc = any ? F::add(acc, x) : x;
+            any = true;
+        }
+    }
+    return acc;
+}
+
+// column loads (PlonkEvalDomain::eval_column_var / eval_advice_var, src/plonk/eval.rs:57-69,153-228)
+template <class F>
+__device__ __forceinline__ fe_t ld_sel(const RowCtx &C, uint32_t col, uint32_t rr) { return C.sel[col][rr] ? F::one() : F::zero(); }
+template <class F>
+__device__ __forceinline__ fe_t ld_fix(const RowCtx &C, uint32_t col, uint32_t rr) { return C.fix[col][rr]; }
+template <class F>
+__device__ __forceinline__ fe_t ld_adv(const RowCtx &C, uint32_t col, uint32_t rr, uint32_t pt) {
+    size_t idx = (size_t)col * C.rows + rr;
+    if (C.wcoef == nullptr) {
+        fe_t r = C.W[0][idx];
+        if (C.J == 2 && C.half) {
+            const fe_t w1 = C.W[1][idx];
+            const fe_t a = F::halve(F::add(r, w1)), b = F::halve(F::sub(r, w1));
+            return pt ? F::add(a, small_times<F>(b, pt)) : a;
+        }
+        if (C.J == 2 && pt) r = F::add(r, small_times<F>(C.W[1][idx], pt));
+        return r;
+    }
+    const fe_t *cf = C.wcoef + (size_t)pt * C.J;
+    fe_t r = F::mul(cf[0], C.W[0][idx]);
+    for (uint32_t j = 1; j < C.J; ++j) r = F::add(r, F::mul(cf[j], C.W[j][idx]));
+    return r;
+}
+
+// Body of a straight-line ("specialised") row-program kernel: `eval(ctx, row, pt, U)` is the compiled program.
+// The point values P(0..d) are parked in LDS (thread-private column, no barrier) and the inverse Vandermonde is
+// applied after the last point: keeping the d accumulators T_k live across the straight-line program cost 48 VGPRs
+// and pushed the kernel into scratch spills at 2 waves/SIMD.
+template <class F, class Eval>
+__device__ __forceinline__ void spec_kernel_body(const DevArgs &A, Eval eval) {
+    __shared__ fe_t Pv[(DMAX + 1) * RP_THREADS];
+    uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
+    const bool live = row < A.ctx.rows;
+    if (!live) row = A.ctx.rows - 1;
+    for (uint32_t pt = 0; pt < A.npts; ++pt) {
+        fe_t P = eval(A.ctx, row, pt, A.utab + (size_t)pt * A.n_uniform);
+        if (A.d == 0) {
+            if (live) A.out[0][row] = P;
+        } else {
+            Pv[pt * RP_THREADS + threadIdx.x] = P;
+        }
+    }
+    if (A.d && live) {
+        for (uint32_t k = 0; k < A.d; ++k) {
+            fe_t T = F::zero();
+            for (uint32_t pt = 0; pt < A.npts; ++pt) T = F::add(T, F::mul(A.vinv[k * A.npts + pt], Pv[pt * RP_THREADS + threadIdx.x]));
+            A.out[k][row] = T;
+        }
+    }
+}
+
+}  // namespace rowprog
+}  // namespace srs
