@@ -17,6 +17,9 @@
 
 namespace srs {
 static thread_local std::string g_err;
+// device scratch of the handle-less entry points (folds, lookup h/g) when they are given HOST operands: grow-only, one
+// per calling thread, so that a fold does not pay a hipMalloc + hipFree (an implicit device synchronisation) per call
+static thread_local srs::Arena g_scratch;
 void set_error(const std::string &msg) { g_err = msg; }
 const char *get_error() { return g_err.c_str(); }
 }  // namespace srs
@@ -850,18 +853,14 @@ int srs_fold_witness(int field, srs_fe *out, const srs_fe *w1, const srs_fe *w2,
             // device-resident operands: stream-ordered (the result is ready in `stream` order, like any library kernel)
             rowprog::fold_w(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *>(w1), reinterpret_cast<const fe_t *>(w2), rr, n, st);
         } else {
-            fe_t *a = nullptr, *b = nullptr;
-            SRS_HIP_CHECK(hipMalloc((void **)&a, n * sizeof(fe_t)));
-            if (hipMalloc((void **)&b, n * sizeof(fe_t)) != hipSuccess) { (void)hipFree(a); return fail(SRS_ERR_DEVICE, "hipMalloc failed"); }
-            try {
-                SRS_HIP_CHECK(hipMemcpyAsync(a, w1, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
-                SRS_HIP_CHECK(hipMemcpyAsync(b, w2, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
-                rowprog::fold_w(field, a, a, b, rr, n, st);
-                SRS_HIP_CHECK(hipMemcpyAsync(out, a, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
-                SRS_HIP_CHECK(hipStreamSynchronize(st));
-            } catch (...) { (void)hipFree(a); (void)hipFree(b); throw; }
-            (void)hipFree(a);
-            (void)hipFree(b);
+            g_scratch.reserve(2 * Arena::pad(n * sizeof(fe_t)) + 256);
+            g_scratch.reset();
+            fe_t *a = g_scratch.take<fe_t>(n), *b = g_scratch.take<fe_t>(n);
+            SRS_HIP_CHECK(hipMemcpyAsync(a, w1, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            SRS_HIP_CHECK(hipMemcpyAsync(b, w2, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            rowprog::fold_w(field, a, a, b, rr, n, st);
+            SRS_HIP_CHECK(hipMemcpyAsync(out, a, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
         }
         SRS_HIP_CHECK(hipGetLastError());
         return SRS_OK;
@@ -884,21 +883,20 @@ int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const 
                                       reinterpret_cast<const fe_t *const *>(T), n_terms, rr, n, st, err);
             if (erc) return fail(erc, "srs_fold_error: " + err);   // stream-ordered, see srs_fold_witness
         } else {
-            fe_t *buf = nullptr;
-            SRS_HIP_CHECK(hipMalloc((void **)&buf, (n_terms + 1) * n * sizeof(fe_t)));
-            try {
-                SRS_HIP_CHECK(hipMemcpyAsync(buf, e, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
-                std::vector<const fe_t *> tp(n_terms);
-                for (size_t k = 0; k < n_terms; ++k) {
-                    SRS_HIP_CHECK(hipMemcpyAsync(buf + (k + 1) * n, T[k], n * sizeof(fe_t), hipMemcpyHostToDevice, st));
-                    tp[k] = buf + (k + 1) * n;
-                }
-                int erc = rowprog::fold_e(field, buf, buf, tp.data(), n_terms, rr, n, st, err);
-                if (erc) { (void)hipFree(buf); return fail(erc, "srs_fold_error: " + err); }
-                SRS_HIP_CHECK(hipMemcpyAsync(out, buf, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
-                SRS_HIP_CHECK(hipStreamSynchronize(st));
-            } catch (...) { (void)hipFree(buf); throw; }
-            (void)hipFree(buf);
+            g_scratch.reserve((n_terms + 1) * Arena::pad(n * sizeof(fe_t)) + 256);
+            g_scratch.reset();
+            fe_t *buf = g_scratch.take<fe_t>(n);
+            SRS_HIP_CHECK(hipMemcpyAsync(buf, e, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            std::vector<const fe_t *> tp(n_terms);
+            for (size_t k = 0; k < n_terms; ++k) {
+                fe_t *t = g_scratch.take<fe_t>(n);
+                SRS_HIP_CHECK(hipMemcpyAsync(t, T[k], n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                tp[k] = t;
+            }
+            int erc = rowprog::fold_e(field, buf, buf, tp.data(), n_terms, rr, n, st, err);
+            if (erc) return fail(erc, "srs_fold_error: " + err);
+            SRS_HIP_CHECK(hipMemcpyAsync(out, buf, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
         }
         SRS_HIP_CHECK(hipGetLastError());
         return SRS_OK;
