@@ -216,3 +216,33 @@ def _degenerate_bases_case(S, O, cid, n):
 def test_commit_degenerate_bases(srs, oracle, cid):
     _degenerate_bases_case(srs, oracle, cid, 6000)
     _degenerate_bases_case(srs, oracle, cid, 70000)       # enough entries for several accumulation levels
+
+
+@pytest.mark.parametrize("cid,n", [(0, 1 << 24), (1, 12 << 20)])
+def test_commit_full_size_properties(srs, oracle, cid, n):
+    """BASELINE configs 5 (2^24-point MSM) and 3 (12 * 2^20 witness commit) at FULL size, through size-independent
+    properties: additivity over a split of the vector, commit(2 v) = 2 commit(v) (the scalar doubling done by the fold
+    kernel), and unit vectors hitting single bases."""
+    import torch
+    O = oracle
+    sf = O.SCALAR_FIELD[cid]
+    ck = srs.CommitmentKey.setup_synthetic(cid, n, seed=11 + cid)
+    g = torch.Generator(device="cuda").manual_seed(5 + cid)
+    v = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    v[:, 3] &= (1 << 60) - 1                                       # < 2^252: a valid residue of either field
+    v[torch.rand(n, device="cuda", generator=g) < 0.5] = 0         # trace-like: half the scalars are zero
+    C = ck.commit(v)
+    assert C.any()
+    lo, hi = v.clone(), v.clone()
+    lo[n // 2:] = 0
+    hi[: n // 2] = 0
+    assert np.array_equal(srs.point_sum(cid, np.stack([ck.commit(lo), ck.commit(hi)])), C)
+    one = O.ints_to_mont(sf, [1])[0]
+    v2 = srs.RelaxedPlonkWitness(sf, [v], v[:1]).fold([v], [], one).W[0]         # v + 1 * v
+    assert np.array_equal(ck.commit(v2), srs.point_sum(cid, np.stack([C, C])))
+    bases = ck.bases()
+    for j in (0, 1, n // 3, n - 1):
+        e = torch.zeros_like(v)
+        e[j] = torch.from_numpy(one.view(np.int64))
+        assert np.array_equal(ck.commit(e), bases[j])
+    ck.close()
