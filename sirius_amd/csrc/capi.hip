@@ -4,6 +4,10 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -44,6 +48,79 @@ struct srs_structure {
 };
 
 namespace {
+
+// Persistent host workers for the few independent scalar multiplications of an instance fold (srs_point_lincomb):
+// spawning a std::thread per point cost ~30 us each, more than the 80 us scalar multiplication it ran.
+class HostPool {
+public:
+    static HostPool &get() {
+        static HostPool *p = new HostPool();      // never destroyed: workers are detached and outlive static teardown
+        return *p;
+    }
+    // runs fn(0..n-1); the caller takes part; returns when all are done
+    void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+        if (n <= 1 || workers_ == 0) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::unique_lock<std::mutex> call(call_mu_);     // one parallel_for at a time
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            total_ = n;
+            next_ = 0;
+            pending_ = n;
+            ++generation_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+        total_ = next_ = 0;
+    }
+
+private:
+    HostPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        workers_ = hw > 1 ? std::min(7u, hw - 1) : 0;
+        for (unsigned i = 0; i < workers_; ++i) std::thread([this] { loop(); }).detach();
+    }
+    // every index is claimed under the mutex (a handful of items per call: contention is irrelevant, and a worker that
+    // wakes up late can never take an index of the wrong call)
+    void drain() {
+        for (;;) {
+            const std::function<void(size_t)> *fn;
+            size_t i;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (next_ >= total_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_cv_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+            }
+            drain();
+        }
+    }
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t total_ = 0, next_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    unsigned workers_ = 0;
+};
 
 int fail(int rc, const std::string &msg) {
     set_error(msg);
@@ -445,14 +522,7 @@ int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points
             if (repr == SRS_REPR_MONT) s = C::S::from_mont(s);
             part[i] = Ec<C>::mul_canon(s.v, P);
         };
-        if (n > 1) {                                   // the d scalar-muls are independent
-            std::vector<std::thread> th;
-            for (size_t i = 1; i < n; ++i) th.emplace_back(work, i);
-            work(0);
-            for (auto &t : th) t.join();
-        } else if (n == 1) {
-            work(0);
-        }
+        HostPool::get().parallel_for(n, work);           // the d scalar-muls are independent
         xyzz_t a = Ec<C>::identity();
         if (acc) {
             affine_t A;
