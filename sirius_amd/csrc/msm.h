@@ -25,6 +25,7 @@ constexpr uint32_t RED_ROWS = 256;        // bucket index = hi * RED_COLS + lo
 constexpr uint32_t RED_COLS = NBUCKET / RED_ROWS;
 constexpr uint32_t RED_THREADS = 4 * RED_COLS;   // k_reduce_final: one quad per element, 128 elements
 constexpr uint32_t ACC1_QUAD_MAX = 1u << 16;     // k_accum1 runs one quad per output when a level has at most this many outputs (x batch)
+constexpr uint32_t BATCH_ARGS = 16;    // MSMs per set of launches (batch descriptor = kernel argument); larger batches are chunked
 constexpr uint32_t NORM_G = 16;           // points per inversion in the key-expansion normalise
 
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");

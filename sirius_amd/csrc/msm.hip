@@ -151,15 +151,20 @@ __global__ void k_on_curve(const affine_t *__restrict__ pts, uint32_t n, uint32_
 // 1. scalars -> signed 16-bit digits
 // dig[w * n + i] = 0xFFFF (zero digit) | (|d|-1) | sign << 15
 // ---------------------------------------------------------------------------------------------
+// the batch descriptor travels as a kernel argument (no host-to-device copies of pointer / length arrays per call)
+struct BatchDesc {
+    const fe_t *ptr[BATCH_ARGS];
+    uint32_t n[BATCH_ARGS];
+};
+
 template <class C>
-__global__ void k_digits(const fe_t *const *__restrict__ scalars_batch, const uint32_t *__restrict__ n_batch,
-                         uint16_t *__restrict__ dig, size_t dig_stride, int is_mont, uint32_t rank, uint32_t world) {
+__global__ void k_digits(BatchDesc bd, uint16_t *__restrict__ dig, size_t dig_stride, int is_mont, uint32_t rank, uint32_t world) {
     using S = typename C::S;
     uint32_t m = blockIdx.y;
-    uint32_t n = n_batch[m];
+    uint32_t n = bd.n[m];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fe_t s = scalars_batch[m][shard_global_index(i, rank, world)];
+    fe_t s = bd.ptr[m][shard_global_index(i, rank, world)];
     if (is_mont) s = S::from_mont(s);
     uint16_t *d = dig + (size_t)m * dig_stride;
     uint32_t carry = 0;
@@ -194,11 +199,11 @@ __device__ __forceinline__ void tile_histogram(uint32_t *h, const uint16_t *__re
 }
 
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
-    k_hist(const uint16_t *__restrict__ dig, size_t dig_stride, const uint32_t *__restrict__ n_batch,
+    k_hist(const uint16_t *__restrict__ dig, size_t dig_stride, BatchDesc bd,
            uint32_t *__restrict__ count /* [batch][NBUCKET] */, uint32_t SORT_TILE) {
     __shared__ uint32_t h[NBUCKET];
     uint32_t m = blockIdx.z, w = blockIdx.y;
-    uint32_t n = n_batch[m];
+    uint32_t n = bd.n[m];
     uint32_t lo = blockIdx.x * SORT_TILE;
     if (lo >= n) return;
     uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
@@ -212,12 +217,12 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
 }
 
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
-    k_scatter(const uint16_t *__restrict__ dig, size_t dig_stride, const uint32_t *__restrict__ n_batch,
+    k_scatter(const uint16_t *__restrict__ dig, size_t dig_stride, BatchDesc bd,
               uint32_t *__restrict__ cursor /* [batch][NBUCKET] */, uint32_t *__restrict__ sorted,
               size_t sorted_stride, uint32_t table_stride, uint32_t SORT_TILE) {
     __shared__ uint32_t h[NBUCKET];
     uint32_t m = blockIdx.z, w = blockIdx.y;
-    uint32_t n = n_batch[m];
+    uint32_t n = bd.n[m];
     uint32_t lo = blockIdx.x * SORT_TILE;
     if (lo >= n) return;
     uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
@@ -711,8 +716,7 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     per += Arena::pad(parts1 * sizeof(xyzz_t));              // pong
     per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
-    return per * batch + Arena::pad(batch * sizeof(void *)) + Arena::pad(batch * sizeof(uint32_t)) +
-           Arena::pad(3 * batch * sizeof(xyzz_t)) + 4096;
+    return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 4096;
 }
 
 template <class C>
@@ -733,8 +737,6 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     Arena &A = k.arena;
     A.reserve(workspace_bytes(n_max, batch));
     A.reset();
-    const fe_t **d_ptrs = A.take<const fe_t *>(batch);
-    uint32_t *d_n = A.take<uint32_t>(batch);
     xyzz_t *d_out = A.take<xyzz_t>(3 * (size_t)batch);
     uint16_t *dig = A.take<uint16_t>(M * batch);
     uint32_t *sorted = A.take<uint32_t>(M * batch);
@@ -746,12 +748,14 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     xyzz_t *buckets = A.take<xyzz_t>((size_t)NBUCKET * batch);
     xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
 
-    SRS_HIP_CHECK(hipMemcpyAsync(d_ptrs, scalars_dev, batch * sizeof(void *), hipMemcpyHostToDevice, stream));
-    SRS_HIP_CHECK(hipMemcpyAsync(d_n, n_host, batch * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    BatchDesc bd;
+    for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
+        bd.ptr[m] = m < batch ? scalars_dev[m] : nullptr;
+        bd.n[m] = m < batch ? n_host[m] : 0;
+    }
     SRS_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)NBUCKET * batch * sizeof(uint32_t), stream));
 
-    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, (const fe_t *const *)d_ptrs,
-               (const uint32_t *)d_n, dig, (size_t)M, is_mont, k.rank, k.world);
+    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont, k.rank, k.world);
     // tile = digits per workgroup: large enough that the fixed 2^15-bin zero/scan of the LDS histogram is
     // amortised, small enough to give ~SORT_TARGET_BLOCKS workgroups (one per CU, 128 KiB LDS each)
     uint32_t tile = (uint32_t)(((uint64_t)n_max * NWIN * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
@@ -759,11 +763,11 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
     const uint32_t tiles = ceil_div(n_max, tile);
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
-               (const uint32_t *)d_n, count, tile);
+               bd, count, tile);
     SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
                levels, (uint32_t)ACC_L0_LOG, (uint32_t)ACC_L1_LOG);
     SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
-               (const uint32_t *)d_n, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
+               bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
 
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
@@ -808,8 +812,11 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
 
 void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch, int is_mont,
          hipStream_t stream, xyzz_t *result_host) {
-    if (k.curve == 0) run_t<Bn256>(k, scalars_dev, n_host, batch, is_mont, stream, result_host);
-    else run_t<Grumpkin>(k, scalars_dev, n_host, batch, is_mont, stream, result_host);
+    for (uint32_t at = 0; at < batch; at += BATCH_ARGS) {          // the batch descriptor is a kernel argument of BATCH_ARGS slots
+        const uint32_t b = std::min<uint32_t>(BATCH_ARGS, batch - at);
+        if (k.curve == 0) run_t<Bn256>(k, scalars_dev + at, n_host + at, b, is_mont, stream, result_host + at);
+        else run_t<Grumpkin>(k, scalars_dev + at, n_host + at, b, is_mont, stream, result_host + at);
+    }
 }
 
 }  // namespace msm

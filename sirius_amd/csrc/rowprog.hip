@@ -988,6 +988,7 @@ struct Structure {
     std::vector<void *> owned;
     fe_t *d_vinv = nullptr;
     Arena arena;
+    std::vector<uint8_t> host_stage;   // source of the per-call staging copy (must outlive the asynchronous copy)
 };
 
 static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx &ctx, bool fold_mode, Program &p,
@@ -1252,13 +1253,19 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
     std::vector<fe_t> utab(nu * npts);
     for (uint32_t pt = 0; pt < npts; ++pt)
         if (!eval_uniform(p, f, challenges_host, n_ch, S->h_num_challenges, mode == 0, pt, utab.data() + (size_t)pt * nu, err)) return 7;
+    // uniform tables and output pointers travel in ONE host-to-device copy (each small pageable copy costs ~50 us of
+    // host time, during which the GPU idles)
     Arena &A = S->arena;
-    A.reserve(Arena::pad(utab.size() * sizeof(fe_t)) + Arena::pad(nout * sizeof(void *)) + 1024);
+    const size_t utab_bytes = utab.size() * sizeof(fe_t), stage_bytes = utab_bytes + nout * sizeof(void *);
+    A.reserve(Arena::pad(stage_bytes) + 1024);
     A.reset();
-    fe_t *d_utab = A.take<fe_t>(utab.size());
-    fe_t **d_out = A.take<fe_t *>(nout);
-    SRS_HIP_CHECK(hipMemcpyAsync(d_utab, utab.data(), utab.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
-    SRS_HIP_CHECK(hipMemcpyAsync(d_out, out_dev_ptrs_host, nout * sizeof(void *), hipMemcpyHostToDevice, st));
+    uint8_t *d_stage = A.take<uint8_t>(stage_bytes);
+    fe_t *d_utab = reinterpret_cast<fe_t *>(d_stage);
+    fe_t **d_out = reinterpret_cast<fe_t **>(d_stage + utab_bytes);
+    S->host_stage.resize(stage_bytes);
+    std::memcpy(S->host_stage.data(), utab.data(), utab_bytes);
+    std::memcpy(S->host_stage.data() + utab_bytes, out_dev_ptrs_host, nout * sizeof(void *));
+    SRS_HIP_CHECK(hipMemcpyAsync(d_stage, S->host_stage.data(), stage_bytes, hipMemcpyHostToDevice, st));
     DevArgs a;
     a.prog = p.d_insns;
     a.n_insn = (uint32_t)p.insns.size();
