@@ -68,6 +68,8 @@ class Side:
         self.w = w
         self.field, self.curve, self.rows = w["field"], w["curve"], w["rows"]
         self.S = S.PlonkStructure(self.field, k, [], w["fixed"], w["num_advice"], w["gates"])
+        if world > 1:      # cross terms only on the rows of this rank's key stripes (the rows its partial MSMs read)
+            self.S.set_shard(rank, world)
         assert (w["num_advice"] * self.rows) <= (1 << log_key)
         self.ck = S.CommitmentKey.setup_synthetic(self.curve, 1 << log_key, seed=42 + self.curve, rank=rank, world=world)
         up = lambda a: torch.from_numpy(a.view(np.int64)).to(dev)

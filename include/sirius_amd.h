@@ -169,6 +169,11 @@ int srs_structure_create_lookup(int field, uint32_t k, size_t num_selectors, siz
                                 size_t num_lookups, int has_vector_lookup,
                                 const uint64_t *lookup_exprs, size_t lookup_words, srs_structure **out);
 void srs_structure_free(srs_structure *S);
+/* Multi-GPU (one process per GPU, keys from srs_ck_create_sharded): with a shard set, srs_cross_terms /
+ * srs_commit_cross_terms evaluate the cross terms only on the rows of THIS rank's block-cyclic stripes (2^10 rows each, the
+ * stripes of the sharded key) -- the only rows the rank's partial commitment and its part of the error fold read.  Rows of
+ * T_out outside those stripes are left untouched (device buffers) / returned as zero (host buffers).  The deciders (srs_eval_gates, srs_is_sat_gates) always cover every row. */
+int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world);
 size_t srs_structure_num_witness_columns(const srs_structure *S);   /* num_advice + 5 * num_lookups */
 size_t srs_structure_num_cross_terms(const srs_structure *S);   /* d = grouped().len() - 1 */
 size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructure::num_challenges */

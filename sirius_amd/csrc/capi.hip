@@ -592,6 +592,11 @@ void srs_structure_free(srs_structure *S) {
     S->io.release();
     delete S;
 }
+int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world) {
+    if (!S || world == 0 || rank >= world) return fail(SRS_ERR_INVALID, "srs_structure_set_shard: bad argument");
+    rowprog::set_shard(S->s, rank, world);
+    return SRS_OK;
+}
 size_t srs_structure_num_cross_terms(const srs_structure *S) { return S ? rowprog::degree(S->s) : 0; }
 size_t srs_structure_num_challenges(const srs_structure *S) { return S ? rowprog::num_challenges(S->s) : 0; }
 size_t srs_structure_num_witness_columns(const srs_structure *S) { return S ? rowprog::num_witness_columns(S->s) : 0; }
@@ -638,6 +643,8 @@ static int cross_terms_impl(srs_structure *S, srs_ck *ck, const srs_fe *W1, cons
         }
         std::vector<fe_t *> dT(d);
         for (size_t k = 0; k < d; ++k) dT[k] = own_T ? S->io.take<fe_t>(rows) : reinterpret_cast<fe_t *>(T_out[k]);
+        if (own_T && rowprog::shard_world(s) > 1)        // rows of the other ranks' stripes are not evaluated: hand back zeros, not stale staging
+            for (size_t k = 0; k < d; ++k) SRS_HIP_CHECK(hipMemsetAsync(dT[k], 0, rows * sizeof(fe_t), st));
         std::string err;
         // with a key, the batched MSM below runs on the same stream and ends with a synchronisation
         int erc = rowprog::evaluate(s, 0, dW1, dW2, reinterpret_cast<const fe_t *>(challenges), n_challenges, dT.data(), st, err, ck == nullptr);

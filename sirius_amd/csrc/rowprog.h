@@ -19,6 +19,9 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
                   const uint64_t *gates, size_t gates_words, size_t num_gates, size_t num_lookups, bool has_vector_lookup,
                   const uint64_t *lookup_exprs, size_t lookup_words, int &rc, std::string &err);
 void destroy(Structure *S);
+// multi-GPU: cross terms (mode 0 of evaluate) are computed only on the rows of this rank's block-cyclic stripes
+void set_shard(Structure *S, uint32_t rank, uint32_t world);
+uint32_t shard_world(const Structure *S);
 size_t degree(const Structure *S);            // homogeneous degree d = number of cross terms
 size_t num_challenges(const Structure *S);    // PlonkStructure::num_challenges
 size_t num_advice(const Structure *S);

@@ -69,9 +69,8 @@ __device__ __forceinline__ fe_t interp(fe_t *slots, const Insn *__restrict__ pro
 template <class F, uint32_t NSLOT>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
     __shared__ fe_t slots[NSLOT * RP_THREADS];
-    uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
-    const bool live = row < A.ctx.rows;
-    if (!live) row = A.ctx.rows - 1;
+    bool live;
+    const uint32_t row = shard_row(A.ctx, blockIdx.x * RP_THREADS + threadIdx.x, live);
     fe_t T[DMAX];
 #pragma unroll
     for (uint32_t k = 0; k < DMAX; ++k) T[k] = F::zero();
@@ -989,6 +988,7 @@ struct Structure {
     fe_t *d_vinv = nullptr;
     Arena arena;
     std::vector<uint8_t> host_stage;   // source of the per-call staging copy (must outlive the asynchronous copy)
+    uint32_t shard_rank = 0, shard_world = 1;   // cross terms: evaluate only this rank's row stripes (set_shard)
 };
 
 static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx &ctx, bool fold_mode, Program &p,
@@ -1171,6 +1171,19 @@ void destroy(Structure *S) {
     delete S;
 }
 
+static uint32_t shard_local_rows(size_t rows, uint32_t rank, uint32_t world) {     // rows of this rank's block-cyclic stripes
+    if (world <= 1) return (uint32_t)rows;
+    const size_t Sz = (size_t)1 << ROW_STRIPE_LOG, full = rows >> ROW_STRIPE_LOG, rem = rows & (Sz - 1);
+    size_t cnt = (full / world) * Sz;
+    if (rank < full % world) cnt += Sz;
+    if (rank == full % world) cnt += rem;
+    return (uint32_t)cnt;
+}
+void set_shard(Structure *S, uint32_t rank, uint32_t world) {
+    S->shard_rank = rank;
+    S->shard_world = world ? world : 1;
+}
+uint32_t shard_world(const Structure *S) { return S->shard_world; }
 size_t degree(const Structure *S) { return S->degree; }
 size_t num_challenges(const Structure *S) { return S->s_num_challenges; }
 size_t num_advice(const Structure *S) { return S->num_advice; }
@@ -1209,7 +1222,7 @@ static bool eval_uniform(const Program &p, const FieldOps &f, const fe_t *ch, si
 
 template <class F>
 static void launch_rowprog(const DevArgs &A, uint32_t nslots, hipStream_t st) {
-    uint32_t blocks = (A.ctx.rows + RP_THREADS - 1) / RP_THREADS;
+    uint32_t blocks = (A.ctx.local_rows + RP_THREADS - 1) / RP_THREADS;
     if (nslots <= 8) SRS_LAUNCH((k_rowprog<F, 8>), (blocks), (RP_THREADS), 0, st, A);
     else if (nslots <= 10) SRS_LAUNCH((k_rowprog<F, 10>), (blocks), (RP_THREADS), 0, st, A);
     else if (nslots <= 12) SRS_LAUNCH((k_rowprog<F, 12>), (blocks), (RP_THREADS), 0, st, A);
@@ -1279,6 +1292,11 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
     a.ctx.J = mode == 0 ? 2 : 1;
     a.ctx.wcoef = nullptr;
     a.ctx.half = 0;
+    // only the cross terms are sharded (their consumers, the sharded MSM and the error fold, touch this rank's stripes
+    // only); the deciders' plain evaluations always cover every row
+    a.ctx.shard_rank = mode == 0 ? S->shard_rank : 0;
+    a.ctx.shard_world = mode == 0 ? S->shard_world : 1;
+    a.ctx.local_rows = shard_local_rows(S->rows, a.ctx.shard_rank, a.ctx.shard_world);
     a.utab = d_utab;
     a.n_uniform = (uint32_t)nu;
     a.npts = npts;
@@ -1292,7 +1310,7 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
         if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
 #if !defined(SRS_EMU)
         else if (p.jit.function) {
-            if (!jit::launch(p.jit, (a.ctx.rows + RP_THREADS - 1) / RP_THREADS, RP_THREADS, &a, st)) { err = "launch of the run-time compiled row program failed"; return 5; }
+            if (!jit::launch(p.jit, (a.ctx.local_rows + RP_THREADS - 1) / RP_THREADS, RP_THREADS, &a, st)) { err = "launch of the run-time compiled row program failed"; return 5; }
         }
 #endif
         else if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);
@@ -1502,6 +1520,9 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         a.ctx.J = 1;
         a.ctx.wcoef = nullptr;
         a.ctx.half = 0;
+        a.ctx.shard_rank = 0;
+        a.ctx.shard_world = 1;
+        a.ctx.local_rows = a.ctx.rows;
         a.compat = compat;
         a.leaf_pts = 1;
         a.P = 1;
@@ -1572,6 +1593,9 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     a.ctx.J = (uint32_t)(mode == 1 ? J : 1);
     a.ctx.wcoef = (mode == 1 && !g_int) ? d_coef : nullptr;
     a.ctx.half = g_int ? 1u : 0u;
+    a.ctx.shard_rank = 0;
+    a.ctx.shard_world = 1;
+    a.ctx.local_rows = a.ctx.rows;
     a.compat = compat;
     a.leaf_pts = leaf_pts;
     a.P = P;

@@ -30,6 +30,8 @@ struct RowCtx {
     uint32_t J;               // number of witnesses
     const fe_t *wcoef;        // [npts][J] combination coefficients, or nullptr:
                               //   J == 1: W[0];  J == 2: W[0] + pt * W[1]  (cross-term points X = pt)
+    uint32_t shard_rank, shard_world, local_rows;   // multi-GPU: this rank evaluates only the rows of ITS block-cyclic stripes
+                              //   (2^ROW_STRIPE_LOG rows each, the stripes of the sharded commitment key); world == 1: all rows
     uint32_t half;            // J == 2, wcoef == nullptr: (W[0] + W[1]) / 2 + pt * (W[0] - W[1]) / 2, i.e. the Lagrange fold
                               //   L_0(X) W[0] + L_1(X) W[1] over the domain {1, -1} at the integer point X = pt (compute_G, L = 1)
 };
@@ -85,6 +87,22 @@ __device__ __forceinline__ fe_t ld_adv(const RowCtx &C, uint32_t col, uint32_t r
     return r;
 }
 
+constexpr uint32_t ROW_STRIPE_LOG = 10;   // == msm::STRIPE_LOG: rows and key entries are sharded alike
+
+// thread index -> (row to evaluate, whether it exists).  Under sharding thread t is the t-th row of this rank's stripes.
+__device__ __forceinline__ uint32_t shard_row(const RowCtx &C, uint32_t t, bool &live) {
+    if (C.shard_world <= 1) {
+        live = t < C.rows;
+        return live ? t : C.rows - 1;
+    }
+    live = t < C.local_rows;
+    if (!live) t = C.local_rows ? C.local_rows - 1 : 0;
+    const uint32_t s = t >> ROW_STRIPE_LOG, o = t & ((1u << ROW_STRIPE_LOG) - 1);
+    const uint32_t row = ((s * C.shard_world + C.shard_rank) << ROW_STRIPE_LOG) + o;
+    if (row >= C.rows) { live = false; return C.rows - 1; }
+    return row;
+}
+
 // Body of a straight-line ("specialised") row-program kernel: `eval(ctx, row, pt, U)` is the compiled program.
 // The point values P(0..d) are parked in LDS (thread-private column, no barrier) and the inverse Vandermonde is
 // applied after the last point: keeping the d accumulators T_k live across the straight-line program cost 48 VGPRs
@@ -92,9 +110,8 @@ __device__ __forceinline__ fe_t ld_adv(const RowCtx &C, uint32_t col, uint32_t r
 template <class F, class Eval>
 __device__ __forceinline__ void spec_kernel_body(const DevArgs &A, Eval eval) {
     __shared__ fe_t Pv[(DMAX + 1) * RP_THREADS];
-    uint32_t row = blockIdx.x * RP_THREADS + threadIdx.x;
-    const bool live = row < A.ctx.rows;
-    if (!live) row = A.ctx.rows - 1;
+    bool live;
+    const uint32_t row = shard_row(A.ctx, blockIdx.x * RP_THREADS + threadIdx.x, live);
     for (uint32_t pt = 0; pt < A.npts; ++pt) {
         fe_t P = eval(A.ctx, row, pt, A.utab + (size_t)pt * A.n_uniform);
         if (A.d == 0) {

@@ -82,6 +82,10 @@ class PlonkStructure:
     def rows(self):
         return 1 << self.k
 
+    def set_shard(self, rank, world):
+        """Multi-GPU: cross terms only on the rows of this rank's key stripes (srs_structure_set_shard)."""
+        L.check(L.lib().srs_structure_set_shard(self._h, rank, world))
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib().srs_structure_free(self._h)

@@ -137,3 +137,9 @@ def test_emu_deciders(emu, oracle):
 def test_emu_commit_degenerate_bases(emu, oracle):
     from test_commit_gpu import _degenerate_bases_case
     _degenerate_bases_case(emu, oracle, 1, 200)
+
+
+def test_emu_row_sharded_cross_terms(emu, oracle):
+    from test_sangria_gpu import _row_shard_case
+    _row_shard_case(emu, oracle, 1, 1, 12, (2,), 2, with_commit=False)
+    _row_shard_case(emu, oracle, 0, 0, 12, (5, 3), 3, with_commit=False)

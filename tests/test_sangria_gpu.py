@@ -326,3 +326,53 @@ def _high_degree_props(S, O, field, k, n_gates):
     # the last term is P_hom(W2, ch2) itself (coefficient of X^d)
     assert np.array_equal(terms[-1], St.eval_gates(W2, ch2, homogeneous=True))
     St.close()
+
+
+def _row_shard_case(S, O, field, curve, k, gate_T, world=2, with_commit=True):
+    """Multi-GPU row sharding (srs_structure_set_shard): every rank evaluates the cross terms on the rows of its own
+    block-cyclic stripes only; together with the sharded key the partial commitments still add up to commit(T_k)."""
+    from workloads import rand_fe
+    gate_T = list(gate_T)
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(gate_T)
+    rng = np.random.default_rng(k + world)
+    fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
+    W1, W2 = rand_fe(rng, nadv * rows), rand_fe(rng, nadv * rows)
+    St = S.PlonkStructure(field, k, [], fixed, nadv, gates)
+    nch = St.num_challenges
+    u1c, u1u, u2c = rand_fe(rng, nch), rand_fe(rng, 1)[0], rand_fe(rng, nch)
+    full, _ = S.VanillaFS.commit_cross_terms(None, St, u1c, u1u, W1, u2c, W2)
+    ch = S.VanillaFS.cross_term_challenges(u1c, u1u, u2c, field)
+    _, exp = OE.cross_terms_oracle(O, field, _oracle_gates(gate_T), 0, nfix, nadv, [], fixed, W1, W2, ch)
+    for a, b in zip(full, exp):
+        assert np.array_equal(a, b)
+    bases = O.make_bases(curve, 9, rows) if with_commit else None
+    ck_full = S.CommitmentKey(curve, bases) if with_commit else None
+    want = np.stack([ck_full.commit(t) for t in full]) if with_commit else None
+    stripe = np.arange(rows) >> 10
+    partials = []
+    for rank in range(world):
+        St.set_shard(rank, world)
+        ck = S.CommitmentKey(curve, bases, rank=rank, world=world) if with_commit else None
+        terms, commits = S.VanillaFS.commit_cross_terms(ck, St, u1c, u1u, W1, u2c, W2)
+        mine = (stripe % world) == rank
+        for t, e in zip(terms, exp):
+            assert np.array_equal(t[mine], e[mine])              # local stripes: the reference's values
+            assert not t[~mine].any()                            # (freshly zeroed buffers) the other stripes were not written
+        partials.append(commits)
+        if ck is not None:
+            ck.close()
+    St.set_shard(0, 1)
+    again, _ = S.VanillaFS.commit_cross_terms(None, St, u1c, u1u, W1, u2c, W2)       # unsharded again: every row
+    assert all(np.array_equal(a, b) for a, b in zip(again, exp))
+    if with_commit:
+        for j in range(len(full)):
+            assert np.array_equal(S.point_sum(curve, np.stack([p[j] for p in partials])), want[j])
+        ck_full.close()
+    St.close()
+
+
+def test_row_sharded_cross_terms(srs, oracle):
+    _row_shard_case(srs, oracle, 0, 0, 13, (5, 3), 2)       # ahead-of-time kernel
+    _row_shard_case(srs, oracle, 1, 1, 12, (3, 2), 3)       # interpreter, world not a power of two
+    _row_shard_case(srs, oracle, 1, 1, 14, (2, 2), 4)       # run-time compiled kernel
