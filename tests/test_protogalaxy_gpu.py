@@ -123,3 +123,39 @@ def test_cmp_with_direct_eval(srs, oracle):
     direct_eval_case(srs, oracle, 5, [5, 3], True)
     direct_eval_case(srs, oracle, 6, [3, 2], False)
     direct_eval_case(srs, oracle, 10, [5, 3], False)      # specialised leaf kernel
+
+
+def test_fast_paths_equal_general_paths(srs, oracle):
+    """compute_F polynomial tree == evaluate-and-interpolate, compute_G integer points == roots of unity + ifft (k = 13,
+    both leaf modes): the fast paths are algebraic rewrites, the coefficient vectors must be identical."""
+    import os
+    import random
+    from oracle import pyref as P
+    from sirius_amd import protogalaxy as PG
+    from workloads import gates_for, rand_fe
+    O = oracle
+    k, gate_T = 13, [5, 3]
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(gate_T)
+    rng = np.random.default_rng(3)
+    fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
+    Ws = [rand_fe(rng, nadv * rows) for _ in range(2)]
+    St = srs.PlonkStructure(0, k, [], fixed, nadv, gates)
+    ctx = PG.PolyContext(St, 1)
+    rnd = random.Random(1)
+    m = lambda v: O.ints_to_mont(O.FR, list(v))
+    betas = m([rnd.randrange(P.FR) for _ in range(ctx.betas_count)])
+    delta = m([rnd.randrange(P.FR)])[0]
+    for compat in (True, False):
+        fast_F = PG.compute_F(ctx, betas, delta, Ws[0], reference_compat=compat)
+        fast_G = PG.compute_G(ctx, betas, Ws, reference_compat=compat)
+        os.environ["SRS_PG_F_EVAL"] = "1"
+        os.environ["SRS_PG_G_FFT"] = "1"
+        try:
+            gen_F = PG.compute_F(ctx, betas, delta, Ws[0], reference_compat=compat)
+            gen_G = PG.compute_G(ctx, betas, Ws, reference_compat=compat)
+        finally:
+            del os.environ["SRS_PG_F_EVAL"], os.environ["SRS_PG_G_FFT"]
+        assert np.array_equal(fast_F, gen_F) and np.array_equal(fast_G, gen_G)
+        assert fast_F[ctx.betas_count + 1:].any() == False      # degree t polynomial: higher coefficients are exactly zero
+    St.close()
