@@ -245,6 +245,12 @@ int srs_lookup_coeff_1(srs_structure *S, const srs_fe *advice, const srs_fe *r, 
 int srs_lookup_coeff_2(int field, const srs_fe *l, const srs_fe *t, const srs_fe *m, const srs_fe *r, size_t n,
                        int space, void *stream, srs_fe *h, srs_fe *g);
 int srs_is_sat_log_derivative(srs_structure *S, const srs_fe *W, int space, void *stream, size_t *mismatch_count);
+/* batch_invert_assigned (src/util/mod.rs:119-153) for ONE column of halo2 `Assigned<F>` cells flattened by the caller:
+ *   Zero -> (0, no denominator), Trivial(x) -> (x, no denominator), Rational(n, d) -> (n, d)
+ * out[i] = numerators[i] * (has_denominator[i] ? denominators[i]^-1 : 1), a zero denominator giving 0 (ff::BatchInvert skips
+ * zeros).  has_denominator == NULL: every cell is Rational.  One Fermat inversion per 8 cells (Montgomery's trick). */
+int srs_batch_invert_assigned(int field, const srs_fe *numerators, const srs_fe *denominators, const uint8_t *has_denominator,
+                              size_t n, int space, void *stream, srs_fe *out);
 
 /* ---- RelaxedPlonkWitness::fold (src/nifs/sangria/accumulator.rs:364-404) ----
  * srs_fold_witness: out[i] = w1[i] + r * w2[i]                                   (:366-376)

@@ -13,7 +13,7 @@ from ._lib import (CURVE_BN256, CURVE_GRUMPKIN, FIELD_FQ, FIELD_FR, SiriusAmdErr
 from .commitment import CommitmentKey, TooLongInput, point_lincomb, point_mul, point_sum  # noqa: F401
 from . import fft  # noqa: F401,E402
 from . import distributed, expression, field, plonk, protogalaxy  # noqa: F401,E402
-from .plonk import PlonkStructure, RelaxedPlonkWitness, SparseMatrix, VanillaFS  # noqa: F401,E402
+from .plonk import PlonkStructure, RelaxedPlonkWitness, SparseMatrix, VanillaFS, batch_invert_assigned  # noqa: F401,E402
 
 
 def profile_enable(on=True):

@@ -64,6 +64,7 @@ def _prototypes():
         "srs_is_sat_permutation": (i32, [vp, vp, i32, vp, C.POINTER(sz)]),
         "srs_is_sat_witness_commit": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, vp, vp, sz, vp, i32, vp, C.POINTER(sz), C.POINTER(i32)]),
         "srs_structure_set_shard": (i32, [vp, u32, u32]),
+        "srs_batch_invert_assigned": (i32, [i32, vp, vp, vp, sz, i32, vp, vp]),
         "srs_structure_free": (None, [vp]),
         "srs_structure_num_cross_terms": (sz, [vp]),
         "srs_structure_num_challenges": (sz, [vp]),

@@ -895,6 +895,39 @@ int srs_lookup_coeff_2(int field, const srs_fe *l, const srs_fe *t, const srs_fe
     });
 }
 
+int srs_batch_invert_assigned(int field, const srs_fe *numerators, const srs_fe *denominators, const uint8_t *has_denominator,
+                              size_t n, int space, void *stream, srs_fe *out) {
+    if (!valid_field(field) || n > 0xFFFFFFFFull || (n && (!numerators || !denominators || !out)))
+        return fail(SRS_ERR_INVALID, "srs_batch_invert_assigned: bad argument");
+    if (!n) return SRS_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        if (space == SRS_SPACE_DEVICE) {
+            rowprog::assigned_invert(field, reinterpret_cast<const fe_t *>(numerators), reinterpret_cast<const fe_t *>(denominators),
+                                     has_denominator, n, reinterpret_cast<fe_t *>(out), st);
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        } else {
+            g_scratch.reserve(3 * Arena::pad(n * sizeof(fe_t)) + Arena::pad(n) + 256);
+            g_scratch.reset();
+            fe_t *a = g_scratch.take<fe_t>(n), *b = g_scratch.take<fe_t>(n), *o = g_scratch.take<fe_t>(n);
+            uint8_t *h = nullptr;
+            SRS_HIP_CHECK(hipMemcpyAsync(a, numerators, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            SRS_HIP_CHECK(hipMemcpyAsync(b, denominators, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            if (has_denominator) {
+                h = g_scratch.take<uint8_t>(n);
+                SRS_HIP_CHECK(hipMemcpyAsync(h, has_denominator, n, hipMemcpyHostToDevice, st));
+            }
+            rowprog::assigned_invert(field, a, b, h, n, o, st);
+            SRS_HIP_CHECK(hipMemcpyAsync(out, o, n * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+            SRS_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        SRS_HIP_CHECK(hipGetLastError());
+        return SRS_OK;
+    });
+}
+
 int srs_is_sat_log_derivative(srs_structure *S, const srs_fe *W, int space, void *stream, size_t *mismatch_count) {
     if (!S || !W || !mismatch_count) return fail(SRS_ERR_INVALID, "srs_is_sat_log_derivative: bad argument");
     int rc = ensure_device();

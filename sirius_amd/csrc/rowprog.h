@@ -61,6 +61,8 @@ int lookup_coeff_1(Structure *S, const fe_t *advice_dev, const fe_t &r, fe_t *co
                    hipStream_t st, std::string &err);
 void lookup_coeff_2(int field, const fe_t *l, const fe_t *t, const fe_t *m, const fe_t &r, size_t n, fe_t *h, fe_t *g, hipStream_t st);
 size_t log_derivative_mismatches(Structure *S, const fe_t *W_dev, hipStream_t st);
+// batch_invert_assigned (src/util/mod.rs:119-153); has_den may be nullptr (every element has a denominator)
+void assigned_invert(int field, const fe_t *num, const fe_t *den, const uint8_t *has_den, size_t n, fe_t *out, hipStream_t st);
 
 size_t count_mismatch(const fe_t *a_dev, const fe_t *b_dev /* or nullptr: compare with 0 */, size_t n, hipStream_t st);
 

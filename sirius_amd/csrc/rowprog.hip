@@ -442,6 +442,45 @@ k_lookup_hg(const fe_t *__restrict__ l, const fe_t *__restrict__ t, const fe_t *
     }
 }
 
+// batch_invert_assigned (src/util/mod.rs:119-153): out[i] = num[i] * (has_den[i] ? den[i]^-1 : 1), with 0^-1 := 0
+// (ff::BatchInvert leaves zero denominators at zero).  Same chunked Montgomery trick and access pattern as k_lookup_hg.
+template <class F>
+__global__ void SRS_KERNEL_BOUNDS(HG_THREADS, 1)
+k_assigned_invert(const fe_t *__restrict__ num, const fe_t *__restrict__ den, const uint8_t *__restrict__ has_den, uint32_t n,
+                  fe_t *__restrict__ out) {
+    const uint32_t base = blockIdx.x * HG_THREADS * HG_CHUNK + threadIdx.x;
+    fe_t v[HG_CHUNK], pref[HG_CHUNK];
+    uint32_t zero_mask = 0, triv_mask = 0;
+    fe_t acc = F::one();
+#pragma unroll
+    for (uint32_t j = 0; j < HG_CHUNK; ++j) {
+        uint32_t idx = base + j * HG_THREADS;
+        fe_t x = F::one();
+        if (idx < n && (!has_den || has_den[idx])) {
+            x = den[idx];
+            if (F::is_zero(x)) { zero_mask |= 1u << j; x = F::one(); }
+        } else {
+            triv_mask |= 1u << j;
+        }
+        v[j] = x;
+        pref[j] = acc;
+        acc = F::mul(acc, x);
+    }
+    fe_t inv = F::inv(acc);
+#pragma unroll
+    for (int j = (int)HG_CHUNK - 1; j >= 0; --j) {
+        uint32_t idx = base + (uint32_t)j * HG_THREADS;
+        fe_t o = F::mul(inv, pref[j]);
+        inv = F::mul(inv, v[j]);
+        if (idx < n) {
+            fe_t a = num[idx];
+            if ((zero_mask >> j) & 1u) a = F::zero();
+            else if (!((triv_mask >> j) & 1u)) a = F::mul(a, o);
+            out[idx] = a;
+        }
+    }
+}
+
 // partial sums of a[i] - b[i] (is_sat_log_derivative, src/plonk/mod.rs:366-378): one value per workgroup
 template <class F>
 __global__ void k_sum_diff(const fe_t *__restrict__ a, const fe_t *__restrict__ b, uint32_t n, fe_t *__restrict__ partial) {
@@ -1740,6 +1779,13 @@ void lookup_coeff_2(int field, const fe_t *l, const fe_t *t, const fe_t *m, cons
     const uint32_t gx = (uint32_t)((n + HG_THREADS * HG_CHUNK - 1) / (HG_THREADS * HG_CHUNK));
     if (field == 0) SRS_LAUNCH((k_lookup_hg<Fr>), (gx, 2), (HG_THREADS), 0, st, l, t, m, r, (uint32_t)n, h, g);
     else SRS_LAUNCH((k_lookup_hg<Fq>), (gx, 2), (HG_THREADS), 0, st, l, t, m, r, (uint32_t)n, h, g);
+}
+
+void assigned_invert(int field, const fe_t *num, const fe_t *den, const uint8_t *has_den, size_t n, fe_t *out, hipStream_t st) {
+    if (!n) return;
+    const uint32_t gx = (uint32_t)((n + HG_THREADS * HG_CHUNK - 1) / (HG_THREADS * HG_CHUNK));
+    if (field == 0) SRS_LAUNCH((k_assigned_invert<Fr>), (gx), (HG_THREADS), 0, st, num, den, has_den, (uint32_t)n, out);
+    else SRS_LAUNCH((k_assigned_invert<Fq>), (gx), (HG_THREADS), 0, st, num, den, has_den, (uint32_t)n, out);
 }
 
 // PlonkStructure::is_sat_log_derivative (src/plonk/mod.rs:366-398) on the concatenated witness:

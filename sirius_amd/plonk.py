@@ -166,6 +166,28 @@ class PlonkStructure:
         return cnt.value
 
 
+def batch_invert_assigned(field, numerators, denominators, has_denominator=None):
+    """`util::batch_invert_assigned` (src/util/mod.rs:119-153) for one flattened column of `Assigned<F>` cells:
+    numerators[i] * denominators[i]^-1 where has_denominator[i] (all cells when None), numerators[i] otherwise; 1/0 := 0."""
+    an, space, n, _ = _buf(numerators, 4)
+    ad, s2, n2, _ = _buf(denominators, 4)
+    assert space == s2 and n == n2
+    out = _alloc_like(numerators, n)
+    hp, keep = None, None
+    if has_denominator is not None:
+        if _is_torch(has_denominator):
+            assert has_denominator.dtype.itemsize == 1 and has_denominator.numel() == n
+            keep = has_denominator.contiguous()
+            hp = keep.data_ptr()
+        else:
+            keep = np.ascontiguousarray(has_denominator, dtype=np.uint8)
+            assert keep.shape == (n,)
+            hp = keep.ctypes.data
+    L.check(L.lib().srs_batch_invert_assigned(field, an, ad, hp, n, space, _stream(),
+                                              out.data_ptr() if _is_torch(out) else out.ctypes.data))
+    return out
+
+
 class SparseMatrix:
     """`SparseMatrix<F>` = Vec<(row, col, value)> of an n x n matrix (src/polynomial/sparse.rs:5), device resident.
     The reference builds it from the copy constraints (PermutationData::matrix, src/plonk/permutation.rs)."""

@@ -143,3 +143,9 @@ def test_emu_row_sharded_cross_terms(emu, oracle):
     from test_sangria_gpu import _row_shard_case
     _row_shard_case(emu, oracle, 1, 1, 12, (2,), 2, with_commit=False)
     _row_shard_case(emu, oracle, 0, 0, 12, (5, 3), 3, with_commit=False)
+
+
+def test_emu_batch_invert_assigned(emu, oracle):
+    from test_lookup_gpu import _assigned_case
+    _assigned_case(emu, oracle, 0, 300)
+    _assigned_case(emu, oracle, 1, 1)

@@ -56,3 +56,29 @@ def test_lookup_coefficients_device_resident_k16(srs, oracle):
     W = [torch.cat([dev(adv)] + ls + ts + ms), torch.cat(hs + gs)]
     assert St.is_sat_log_derivative(W) == 0
     St.close()
+
+
+def _assigned_case(S, O, field, n, seed=1):
+    """batch_invert_assigned (src/util/mod.rs:119-153): Zero / Trivial / Rational cells incl. zero denominators."""
+    from oracle import pyref as P
+    p = P.MODULI[field]
+    rng = np.random.default_rng(seed + n)
+    num = [int(rng.integers(0, 1 << 62)) * int(rng.integers(1, 1 << 62)) % p for _ in range(n)]
+    den = [int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % p for _ in range(n)]
+    has = rng.integers(0, 2, size=n).astype(np.uint8)
+    for i in range(0, n, 7):
+        den[i] = 0                                              # Rational(n, 0) -> 0
+    for i in range(3, n, 11):
+        num[i] = 0
+        has[i] = 0                                              # Assigned::Zero
+    exp = [(a * pow(d, p - 2, p) % p if d else 0) if h else a for a, d, h in zip(num, den, has)]
+    got = S.batch_invert_assigned(field, O.ints_to_mont(field, num), O.ints_to_mont(field, den), has)
+    assert O.mont_to_ints(field, got) == exp
+    exp_all = [a * pow(d, p - 2, p) % p if d else 0 for a, d in zip(num, den)]
+    assert O.mont_to_ints(field, S.batch_invert_assigned(field, O.ints_to_mont(field, num), O.ints_to_mont(field, den))) == exp_all
+
+
+def test_batch_invert_assigned(srs, oracle):
+    _assigned_case(srs, oracle, 0, 5000)
+    _assigned_case(srs, oracle, 1, 1)
+    _assigned_case(srs, oracle, 1, 1025)
