@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--k", type=int, default=17, help="log2 rows (BASELINE configs[1]: 17)")
     ap.add_argument("--log-key", type=int, default=21, help="log2 commitment-key length per curve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ro-challenge", action="store_true",
+                    help="derive the folding challenge r of every prove from the off-circuit Poseidon oracle over the commitments "
+                         "(T=5, RATE=4, R_F=R_P=10 as benches/sangria_poseidon.rs:80-116) instead of a seeded constant")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU exchange; lets 2 ranks share one GPU in tests)")
     return ap.parse_args()
@@ -84,9 +87,12 @@ class Side:
         self.rpows = ints_to_mont(sf, [pow(rv, i + 1, MODULUS[sf]) for i in range(self.d)])
         self.accCW = np.zeros(8, dtype=np.uint64)
         self.accCE = np.zeros(8, dtype=np.uint64)
+        # random oracle over the base field of this side's curve (its points are what gets absorbed)
+        self.ro = S.PoseidonHash(1 if self.curve == 0 else 0, 5, 4, 10, 10)
 
 
 COUNT_NONZERO = False
+RO_CHALLENGE = False
 
 
 def combine(S, side, partial, dist, world, dev):
@@ -103,6 +109,17 @@ def prove(S, side, dist, world, dev):
     if COUNT_NONZERO:     # untimed warm-up only: mixed additions issued = 16 windows x non-zero scalars (ALU roofline)
         side.nz_terms = sum(int((t != 0).any(dim=1).sum().item()) for t in terms)
     commits = combine(S, side, commits, dist, world, dev)
+    if RO_CHALLENGE:      # VanillaFS::generate_challenge (src/nifs/sangria/mod.rs:162-179): absorb U1, U2, the cross-term commits
+        from sirius_amd.field import MODULUS, from_mont, ints_to_mont
+        ro = side.ro.reset()
+        for pt in (side.accCW, side.accCE, side.inC):
+            ro.absorb_point(side.curve, pt)
+        for pt in commits:
+            ro.absorb_point(side.curve, pt)
+        sf = 0 if side.curve == 0 else 1
+        side.r = ro.squeeze(128, sf)
+        rv = from_mont(sf, side.r)
+        side.rpows = ints_to_mont(sf, [pow(rv, i + 1, MODULUS[sf]) for i in range(side.d)])
     # generate_challenge: Poseidon RO on the CPU in the reference -> seeded constant r here.
     # Both folds depend only on r: the instance fold (host scalar-muls, accumulator.rs:201-264:
     # W' = W1 + r*W2 ; E' = E + sum r^k T_k) runs on host threads while the GPU folds the witness.
@@ -206,7 +223,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    global COUNT_NONZERO
+    global COUNT_NONZERO, RO_CHALLENGE
+    RO_CHALLENGE = bool(args.ro_challenge)
     COUNT_NONZERO = True
     fold_step(S, pri, sec, dist, world, dev)          # extra untimed step that also counts non-zero scalars
     COUNT_NONZERO = False

@@ -209,6 +209,22 @@ int srs_eval_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs
 int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const srs_fe *challenges, size_t n_challenges,
                      const srs_fe *E, int space, void *stream, size_t *mismatch_count);
 
+/* ---- off-circuit Poseidon random oracle (src/poseidon/poseidon_hash.rs:16-237) -- host code, no device ----
+ * srs_poseidon_new        = PoseidonHash::new(Spec::new(r_f, r_p)) over `field` (ROConstantsTrait::new, :99-106); RATE == T - 1.
+ *                           Constants: the construction of the PSE `poseidon` crate the reference depends on (Grain LFSR,
+ *                           Cauchy MDS), pinned by the reference's known answer poseidon_hash.rs:248-266 (tests/test_poseidon.py).
+ * srs_poseidon_absorb_field / _absorb_point = ROTrait::absorb_field / absorb_point (:118-141): a point contributes (x, y),
+ *                           the identity (0, 0); the oracle's field must be the curve's base field.
+ * srs_poseidon_squeeze     = ROTrait::squeeze::<D>(num_bits) (:149-152, output :190-212): the low num_bits bits of state[1] as
+ *                           an element of `out_field` (Montgomery).  As in the reference the absorbed buffer is KEPT. */
+typedef struct srs_poseidon srs_poseidon;
+int srs_poseidon_new(int field, size_t t, size_t rate, size_t r_f, size_t r_p, srs_poseidon **out);
+void srs_poseidon_free(srs_poseidon *H);
+void srs_poseidon_reset(srs_poseidon *H);   /* forget everything absorbed (a fresh oracle with the same constants) */
+int srs_poseidon_absorb_field(srs_poseidon *H, const srs_fe *v, size_t n);
+int srs_poseidon_absorb_point(srs_poseidon *H, int curve, const srs_affine *p);
+int srs_poseidon_squeeze(srs_poseidon *H, size_t num_bits, int out_field, srs_fe *out);
+
 /* ---- deciders: permutation (copy-constraint) check and witness-commitment check ----
  * srs_sparse = the reference's SparseMatrix<F> = Vec<(row, col, value)> (src/polynomial/sparse.rs:5) of an n x n matrix,
  * kept on the device in CSR form.  A column index >= n is the reference's panic "invalid matrix multiply" (:15-17) and is

@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import (CURVE_BN256, CURVE_GRUMPKIN, FIELD_FQ, FIELD_FR, SiriusAmdError)  # noqa: F401
 from .commitment import CommitmentKey, TooLongInput, point_lincomb, point_mul, point_sum  # noqa: F401
 from . import fft  # noqa: F401,E402
-from . import distributed, expression, field, plonk, protogalaxy  # noqa: F401,E402
+from . import distributed, expression, field, plonk, poseidon, protogalaxy  # noqa: F401,E402
+from .poseidon import PoseidonHash  # noqa: F401,E402
 from .plonk import PlonkStructure, RelaxedPlonkWitness, SparseMatrix, VanillaFS, batch_invert_assigned  # noqa: F401,E402
 
 

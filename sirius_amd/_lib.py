@@ -64,6 +64,12 @@ def _prototypes():
         "srs_is_sat_permutation": (i32, [vp, vp, i32, vp, C.POINTER(sz)]),
         "srs_is_sat_witness_commit": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, vp, vp, sz, vp, i32, vp, C.POINTER(sz), C.POINTER(i32)]),
         "srs_structure_set_shard": (i32, [vp, u32, u32]),
+        "srs_poseidon_new": (i32, [i32, sz, sz, sz, sz, C.POINTER(vp)]),
+        "srs_poseidon_free": (None, [vp]),
+        "srs_poseidon_reset": (None, [vp]),
+        "srs_poseidon_absorb_field": (i32, [vp, vp, sz]),
+        "srs_poseidon_absorb_point": (i32, [vp, i32, vp]),
+        "srs_poseidon_squeeze": (i32, [vp, sz, i32, vp]),
         "srs_batch_invert_assigned": (i32, [i32, vp, vp, vp, sz, i32, vp, vp]),
         "srs_structure_free": (None, [vp]),
         "srs_structure_num_cross_terms": (sz, [vp]),

@@ -16,6 +16,7 @@
 #include "devrt.h"
 #include "msm.h"
 #include "ntt.h"
+#include "poseidon.h"
 #include "prof.h"
 #include "rowprog.h"
 
@@ -35,6 +36,10 @@ static_assert(sizeof(srs_fe) == sizeof(fe_t) && sizeof(srs_affine) == sizeof(aff
 struct srs_ck {
     msm::Key key;
     Arena staging;      // H2D staging of host scalars
+};
+
+struct srs_poseidon {
+    poseidon::Hash *h = nullptr;
 };
 
 struct srs_sparse {
@@ -737,6 +742,56 @@ int srs_is_sat_gates(srs_structure *S, int homogeneous, const srs_fe *W, const s
         int erc = rowprog::evaluate(s, homogeneous ? 2 : 1, dW, nullptr, reinterpret_cast<const fe_t *>(challenges), n_challenges, outs, st, err);
         if (erc) return fail(erc, "srs_is_sat_gates: " + err);
         *mismatch_count = rowprog::count_mismatch(vals, dE, rows, st);
+        return SRS_OK;
+    });
+}
+
+// ------------------------------------------------------------------ off-circuit random oracle (host code)
+int srs_poseidon_new(int field, size_t t, size_t rate, size_t r_f, size_t r_p, srs_poseidon **out) {
+    if (!valid_field(field) || !out) return fail(SRS_ERR_INVALID, "srs_poseidon_new: bad argument");
+    return guarded([&]() -> int {
+        std::string err;
+        poseidon::Hash *h = poseidon::create(field, t, rate, r_f, r_p, err);
+        if (!h) return fail(SRS_ERR_INVALID, "srs_poseidon_new: " + err);
+        srs_poseidon *H = new srs_poseidon();
+        H->h = h;
+        *out = H;
+        return SRS_OK;
+    });
+}
+void srs_poseidon_free(srs_poseidon *H) {
+    if (!H) return;
+    delete H->h;
+    delete H;
+}
+void srs_poseidon_reset(srs_poseidon *H) {
+    if (H) H->h->buf.clear();
+}
+int srs_poseidon_absorb_field(srs_poseidon *H, const srs_fe *v, size_t n) {
+    if (!H || (n && !v)) return fail(SRS_ERR_INVALID, "srs_poseidon_absorb_field: bad argument");
+    return guarded([&]() -> int {
+        poseidon::absorb(*H->h, reinterpret_cast<const fe_t *>(v), n);
+        return SRS_OK;
+    });
+}
+int srs_poseidon_absorb_point(srs_poseidon *H, int curve, const srs_affine *p) {
+    if (!H || !valid_curve(curve) || !p) return fail(SRS_ERR_INVALID, "srs_poseidon_absorb_point: bad argument");
+    // coordinates live in the curve's base field: bn256 -> Fq (1), grumpkin -> Fr (0); util::fe_to_fe between different
+    // fields (poseidon_hash.rs:130-133) is not provided
+    if (H->h->field != (curve == SRS_CURVE_BN256 ? SRS_FIELD_FQ : SRS_FIELD_FR))
+        return fail(SRS_ERR_INVALID, "srs_poseidon_absorb_point: the oracle's field is not the curve's base field");
+    return guarded([&]() -> int {
+        poseidon::absorb(*H->h, reinterpret_cast<const fe_t *>(p), 2);       // (x, y); the identity is (0, 0) (:137-139)
+        return SRS_OK;
+    });
+}
+int srs_poseidon_squeeze(srs_poseidon *H, size_t num_bits, int out_field, srs_fe *out) {
+    if (!H || !out || !valid_field(out_field)) return fail(SRS_ERR_INVALID, "srs_poseidon_squeeze: bad argument");
+    return guarded([&]() -> int {
+        std::string err;
+        fe_t o;
+        if (!poseidon::squeeze(*H->h, num_bits, out_field, o, err)) return fail(SRS_ERR_INVALID, "srs_poseidon_squeeze: " + err);
+        std::memcpy(out, &o, 32);
         return SRS_OK;
     });
 }

@@ -1,0 +1,150 @@
+// poseidon.hip -- the reference's off-circuit random oracle (src/poseidon/poseidon_hash.rs:16-237), host code.
+//
+// Why it is here although it is not data-parallel: between `commit_cross_terms` and the folds the
+// reference squeezes the challenge r out of this sponge; with the oracle inside the library a shim (or bench.py) derives r
+// without going back to its own field arithmetic, and the challenge in the benchmark is a real function of the commitments.
+// One permutation is ~60 field multiplications: the CPU does it in microseconds, a GPU launch would only add latency.
+//
+// Parameters: `Spec::new(r_f, r_p)` comes from the third-party crate privacy-scaling-explorations/poseidon @ 807f8f55
+// (Cargo.toml:40-42), which is not part of the reference tree; its published construction is restated: Grain LFSR of the
+// Poseidon paper -> round constants (rejection sampling, MSB first) -> Cauchy MDS 1 / (x_i + y_j) (x, y without rejection);
+// initial state (2^64, 0, ...).  oracle/poseidon.py holds the same restatement in Python and is pinned by the reference's
+// known answer (poseidon_hash.rs:248-266); tests/test_poseidon.py compares the two on both fields.
+#include "poseidon.h"
+
+#include <cstring>
+
+namespace srs {
+namespace poseidon {
+namespace {
+
+struct Grain {
+    bool s[80];
+    int head = 0;                        // ring buffer: s[(head + i) % 80] is bit i
+    bool at(int i) const { return s[(head + i) % 80]; }
+    bool new_bit() {
+        bool b = at(62) ^ at(51) ^ at(38) ^ at(23) ^ at(13) ^ at(0);
+        s[head] = b;                     // drop bit 0, append b
+        head = (head + 1) % 80;
+        return b;
+    }
+    bool next() {                        // self-shrinking output
+        bool b = new_bit();
+        while (!b) {
+            new_bit();
+            b = new_bit();
+        }
+        return new_bit();
+    }
+    Grain(uint32_t num_bits, uint32_t t, uint32_t r_f, uint32_t r_p) {
+        int n = 0;
+        auto app = [&](int bits, uint64_t v) { for (int i = bits - 1; i >= 0; --i) s[n++] = (v >> i) & 1u; };
+        app(2, 1); app(4, 0); app(12, num_bits); app(12, t); app(10, r_f); app(10, r_p); app(30, (1u << 30) - 1);
+        for (int i = 0; i < 160; ++i) new_bit();
+    }
+    // `num_bits` bits, first one most significant, as 8 little-endian u32 limbs (canonical integer, NOT Montgomery)
+    fe_t bits(uint32_t num_bits) {
+        fe_t v;
+        std::memset(&v, 0, sizeof v);
+        for (uint32_t i = 0; i < num_bits; ++i) {
+            uint32_t pos = num_bits - 1 - i;
+            if (next()) v.v[pos >> 5] |= 1u << (pos & 31);
+        }
+        return v;
+    }
+};
+
+template <class F, class PP>
+bool less_than_p(const fe_t &a) {
+    for (int i = 7; i >= 0; --i) {
+        if (a.v[i] < PP::p(i)) return true;
+        if (a.v[i] > PP::p(i)) return false;
+    }
+    return false;
+}
+
+template <class F, class PP>
+void build(Hash &h) {
+    const uint32_t nbits = 254;          // F::NUM_BITS of both bn256 fields
+    Grain g(nbits, (uint32_t)h.t, (uint32_t)h.r_f, (uint32_t)h.r_p);
+    h.rc.resize((h.r_f + h.r_p) * h.t);
+    for (auto &c : h.rc) {
+        fe_t v;
+        do { v = g.bits(nbits); } while (!less_than_p<F, PP>(v));
+        c = F::to_mont(v);
+    }
+    std::vector<fe_t> xs(h.t), ys(h.t);
+    for (auto &x : xs) x = F::to_mont(F::reduce_once(g.bits(nbits)));        // < 2^254 < 2p: one conditional subtraction
+    for (auto &y : ys) y = F::to_mont(F::reduce_once(g.bits(nbits)));
+    h.mds.resize(h.t * h.t);
+    for (size_t i = 0; i < h.t; ++i)
+        for (size_t j = 0; j < h.t; ++j) h.mds[i * h.t + j] = F::inv(F::add(xs[i], ys[j]));
+}
+
+template <class F>
+void permute(const Hash &h, std::vector<fe_t> &st) {
+    const size_t t = h.t, half = h.r_f / 2;
+    std::vector<fe_t> nx(t);
+    auto pow5 = [](const fe_t &x) { fe_t x2 = F::sqr(x); return F::mul(F::sqr(x2), x); };
+    for (size_t r = 0; r < h.r_f + h.r_p; ++r) {
+        for (size_t i = 0; i < t; ++i) st[i] = F::add(st[i], h.rc[r * t + i]);
+        if (r < half || r >= half + h.r_p) {
+            for (size_t i = 0; i < t; ++i) st[i] = pow5(st[i]);
+        } else {
+            st[0] = pow5(st[0]);
+        }
+        for (size_t i = 0; i < t; ++i) {
+            fe_t acc = F::zero();
+            for (size_t j = 0; j < t; ++j) acc = F::add(acc, F::mul(h.mds[i * t + j], st[j]));
+            nx[i] = acc;
+        }
+        st.swap(nx);
+    }
+}
+
+template <class F>
+fe_t run(const Hash &h) {
+    std::vector<fe_t> st(h.t, F::zero());
+    fe_t cap;
+    std::memset(&cap, 0, sizeof cap);
+    cap.v[2] = 1;                                            // 2^64  (poseidon::State::default())
+    st[0] = F::to_mont(cap);
+    const size_t n = h.buf.size();
+    for (size_t at = 0; at <= n; at += h.rate) {
+        const size_t len = n - at < h.rate ? n - at : h.rate;
+        if (at == n && n % h.rate != 0) break;               // the empty chunk exists only when the buffer is exact
+        for (size_t i = 0; i < len; ++i) st[1 + i] = F::add(st[1 + i], h.buf[at + i]);
+        if (len < h.rate) st[1 + len] = F::add(st[1 + len], F::one());      // pre_round padding, :52-64
+        permute<F>(h, st);
+        if (len < h.rate) break;
+    }
+    return F::from_mont(st[1]);
+}
+
+}  // namespace
+
+Hash *create(int field, size_t t, size_t rate, size_t r_f, size_t r_p, std::string &err) {
+    if (t < 2 || t > 16 || rate != t - 1) { err = "RATE must be T - 1 (poseidon_hash.rs:41), 2 <= T <= 16"; return nullptr; }
+    if (r_f == 0 || (r_f & 1) || r_f >= 1024 || r_p >= 1024) { err = "R_F must be even and positive; R_F, R_P < 1024"; return nullptr; }
+    Hash *h = new Hash();
+    h->field = field;
+    h->t = t;
+    h->rate = rate;
+    h->r_f = r_f;
+    h->r_p = r_p;
+    if (field == 0) build<Fr, FrP>(*h); else build<Fq, FqP>(*h);
+    return h;
+}
+
+void absorb(Hash &h, const fe_t *v, size_t n) { h.buf.insert(h.buf.end(), v, v + n); }
+
+bool squeeze(Hash &h, size_t num_bits, int out_field, fe_t &out, std::string &err) {
+    if (num_bits == 0 || num_bits > 253) { err = "num_bits must be in 1..253"; return false; }
+    fe_t canon = h.field == 0 ? run<Fr>(h) : run<Fq>(h);
+    for (size_t b = num_bits; b < 256; ++b) canon.v[b >> 5] &= ~(1u << (b & 31));     // bits[..num_bits] (little endian)
+    out = out_field == 0 ? Fr::to_mont(canon) : Fq::to_mont(canon);                    // < 2^253 < both moduli
+    return true;
+}
+
+}  // namespace poseidon
+}  // namespace srs
