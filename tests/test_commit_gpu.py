@@ -67,6 +67,9 @@ def test_commit_batch_and_errors(srs, oracle, cid):
     got = ck.commit_batch(vs)
     for g, v in zip(got, vs):
         assert np.array_equal(g, O.msm(cid, v, bases[: len(v)]))
+    many = [seeded_scalars(O, cid, 100 + 7 * i, 40 + i, "uniform") for i in range(21)]       # more than one batch descriptor (16)
+    for g, v in zip(ck.commit_batch(many), many):
+        assert np.array_equal(g, O.msm(cid, v, bases[: len(v)]))
     assert np.array_equal(ck.commit(np.zeros((0, 4), np.uint64)), np.zeros(8, np.uint64))   # n == 0 -> identity
     with pytest.raises(srs.TooLongInput):                                                    # src/commitment.rs:82-88
         ck.commit(np.zeros((3001, 4), np.uint64))
