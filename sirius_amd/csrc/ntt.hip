@@ -84,6 +84,47 @@ __device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rb
     }
 }
 
+// two DIT stages (s, s + 1) in one LDS round trip: a thread owns the 4 elements base + {0, 1, 2, 3} * 2^s of a radix-4
+// group -- the same 4 twiddle multiplications as two radix-2 stages, half the LDS traffic and half the barriers
+template <uint32_t NCOLS>
+__device__ __forceinline__ void lds_stage2(fe_t *tile, const fe_t *W, uint32_t rbits, uint32_t s) {
+    const uint32_t h = 1u << s;
+    const uint32_t groups = (1u << (rbits - 2)) * NCOLS;
+    for (uint32_t p = threadIdx.x; p < groups; p += blockDim.x) {
+        const uint32_t c = p % NCOLS, g = p / NCOLS;
+        const uint32_t j = g & (h - 1);
+        const uint32_t base = ((g >> s) << (s + 2)) | j;
+        fe_t e0 = tile[base * NCOLS + c], e1 = tile[(base + h) * NCOLS + c];
+        fe_t e2 = tile[(base + 2 * h) * NCOLS + c], e3 = tile[(base + 3 * h) * NCOLS + c];
+        if (j) {                                                   // stage s: pairs (0,1) and (2,3), twiddle w^(j 2^(r-1-s))
+            const fe_t t1 = W[j << (rbits - 1 - s)];
+            e1 = Fr::mul(e1, t1);
+            e3 = Fr::mul(e3, t1);
+        }
+        fe_t a0 = Fr::add(e0, e1), a1 = Fr::sub(e0, e1), a2 = Fr::add(e2, e3), a3 = Fr::sub(e2, e3);
+        if (j) a2 = Fr::mul(a2, W[j << (rbits - 2 - s)]);          // stage s + 1: pairs (0,2) and (1,3)
+        a3 = Fr::mul(a3, W[(j + h) << (rbits - 2 - s)]);
+        tile[base * NCOLS + c] = Fr::add(a0, a2);
+        tile[(base + 2 * h) * NCOLS + c] = Fr::sub(a0, a2);
+        tile[(base + h) * NCOLS + c] = Fr::add(a1, a3);
+        tile[(base + 3 * h) * NCOLS + c] = Fr::sub(a1, a3);
+    }
+}
+
+// all `rbits` stages of a tile
+template <uint32_t NCOLS>
+__device__ __forceinline__ void lds_stages(fe_t *tile, const fe_t *W, uint32_t rbits) {
+    uint32_t s = 0;
+    for (; s + 1 < rbits; s += 2) {
+        lds_stage2<NCOLS>(tile, W, rbits, s);
+        __syncthreads();
+    }
+    if (s < rbits) {
+        lds_stage<NCOLS>(tile, W, rbits, s);
+        __syncthreads();
+    }
+}
+
 // ---- single-workgroup transform, n = 2^k <= 2^SMALL_LOG; grid.x = batch of independent vectors
 __global__ void SRS_KERNEL_BOUNDS(512, 1)
     k_ntt_small(fe_t *__restrict__ a, size_t stride, uint32_t k, const fe_t *__restrict__ Wg, fe_t post, int has_post,
@@ -99,10 +140,7 @@ __global__ void SRS_KERNEL_BOUNDS(512, 1)
     }
     for (uint32_t i = threadIdx.x; i < (n >> 1); i += blockDim.x) W[i] = Wg[i];
     __syncthreads();
-    for (uint32_t s = 0; s < k; ++s) {
-        lds_stage<1>(tile, W, k, s);
-        __syncthreads();
-    }
+    lds_stages<1>(tile, W, k);
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         fe_t x = tile[i];
         if (has_post) x = Fr::mul(x, post);
@@ -141,10 +179,7 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     }
     for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
     __syncthreads();
-    for (uint32_t s = 0; s < RBITS; ++s) {
-        lds_stage<COLS>(tile, W, RBITS, s);
-        __syncthreads();
-    }
+    lds_stages<COLS>(tile, W, RBITS);
     for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
         uint32_t kd = e / COLS, c = e % COLS;
         size_t tidx = ((size_t)kd << pa.lbits) + rest0 + c;      // T[k_j][rest]
@@ -193,10 +228,7 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     }
     for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
     __syncthreads();
-    for (uint32_t s = 0; s < RBITS; ++s) {
-        lds_stage<COLS>(tile, W, RBITS, s);
-        __syncthreads();
-    }
+    lds_stages<COLS>(tile, W, RBITS);
     for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
         uint32_t kp = e / COLS, c = e % COLS;
         size_t oidx = (size_t)(k1_0 + c) + ((size_t)out_mid << r1) + ((size_t)kp << (pa.log_n - RBITS));
