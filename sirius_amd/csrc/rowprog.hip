@@ -1696,27 +1696,61 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
                 hipStream_t st, fe_t *out_host, std::string &err) {
     if (log_domain_K > ntt::FR_S) { err = "k=" + std::to_string(log_domain_K) + " should no larger than F::S=28"; return 3; }   // fft.rs:13
     const size_t count = (size_t)1 << log_domain_K;
-    fe_t *d_g = nullptr, *d_out = nullptr;
-    int *d_err = nullptr;
-    SRS_HIP_CHECK(hipMalloc((void **)&d_g, (nG + 1) * sizeof(fe_t)));
-    SRS_HIP_CHECK(hipMalloc((void **)&d_out, count * sizeof(fe_t)));
-    SRS_HIP_CHECK(hipMalloc((void **)&d_err, sizeof(int)));
+    static thread_local Arena scratch;                         // grow-only: no hipMalloc / hipFree (implicit sync) per call
+    scratch.reserve(Arena::pad((nG + 1) * sizeof(fe_t)) + Arena::pad(count * sizeof(fe_t)) + Arena::pad(sizeof(int)) + 256);
+    scratch.reset();
+    fe_t *d_g = scratch.take<fe_t>(nG + 1), *d_out = scratch.take<fe_t>(count);
+    int *d_err = scratch.take<int>(1);
     int herr = 0;
-    try {
-        SRS_HIP_CHECK(hipMemcpyAsync(d_g, polyG_host, nG * sizeof(fe_t), hipMemcpyHostToDevice, st));
-        SRS_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int), st));
-        fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
-        SRS_LAUNCH(k_pg_K_points, ((uint32_t)((count + 63) / 64)), (64), 0, st, (const fe_t *)d_g, (uint32_t)nG, f_alpha,
-                   ntt::zeta(), ntt::omega(log_domain_K, false), inv_n, (uint32_t)instances_to_fold, (uint32_t)count, d_out, d_err);
+    if (count <= 4096) {
+        // The K domain is tiny (256 points in every configuration, quirk Q2): the points are computed on the host with ONE
+        // inversion for all denominators (Montgomery's trick).  A GPU thread per point spends two Fermat inversions =
+        // 760 dependent multiplications = 0.6 ms of pure latency on it.
+        const fe_t zeta = ntt::zeta(), omega = ntt::omega(log_domain_K, false), one = Fr::one();
+        const fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
+        std::vector<fe_t> g(count), xn1(count), xm1(count), pref(2 * count);
+        fe_t X = zeta, acc = one;
+        for (size_t i = 0; i < count; ++i) {
+            fe_t gi = Fr::zero(), xp = one;
+            for (size_t k = 0; k < nG; ++k) {                  // UnivariatePoly::eval (univariate.rs:67-75)
+                gi = Fr::add(gi, Fr::mul(xp, polyG_host[k]));
+                xp = Fr::mul(xp, X);
+            }
+            g[i] = gi;
+            xn1[i] = Fr::sub(Fr::pow_u64(X, instances_to_fold), one);
+            xm1[i] = Fr::sub(X, one);
+            if (Fr::is_zero(xn1[i])) { err = "Z(X) must be not equal to 0"; return 4; }     // X = 1 included (then X - 1 = 0 too)
+            pref[2 * i] = acc;
+            acc = Fr::mul(acc, xn1[i]);
+            pref[2 * i + 1] = acc;
+            acc = Fr::mul(acc, xm1[i]);
+            X = Fr::mul(X, omega);
+        }
+        fe_t inv = Fr::inv(acc);
+        std::vector<fe_t> kp(count);
+        for (size_t i = count; i-- > 0;) {
+            const fe_t inv_xm1 = Fr::mul(inv, pref[2 * i + 1]);
+            inv = Fr::mul(inv, xm1[i]);
+            const fe_t inv_xn1 = Fr::mul(inv, pref[2 * i]);
+            inv = Fr::mul(inv, xn1[i]);
+            const fe_t l0 = Fr::mul(inv_n, Fr::mul(xn1[i], inv_xm1));                        // lagrange.rs:50-75
+            kp[i] = Fr::mul(Fr::sub(g[i], Fr::mul(f_alpha, l0)), inv_xn1);
+        }
+        SRS_HIP_CHECK(hipMemcpyAsync(d_out, kp.data(), count * sizeof(fe_t), hipMemcpyHostToDevice, st));
         ntt::run(d_out, log_domain_K, count, 1, true, true, st);     // UnivariatePoly::coset_ifft
         SRS_HIP_CHECK(hipMemcpyAsync(out_host, d_out, count * sizeof(fe_t), hipMemcpyDeviceToHost, st));
-        SRS_HIP_CHECK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
         SRS_HIP_CHECK(hipStreamSynchronize(st));
-    } catch (...) {
-        (void)hipFree(d_g); (void)hipFree(d_out); (void)hipFree(d_err);
-        throw;
+        return 0;
     }
-    (void)hipFree(d_g); (void)hipFree(d_out); (void)hipFree(d_err);
+    SRS_HIP_CHECK(hipMemcpyAsync(d_g, polyG_host, nG * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    SRS_HIP_CHECK(hipMemsetAsync(d_err, 0, sizeof(int), st));
+    fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
+    SRS_LAUNCH(k_pg_K_points, ((uint32_t)((count + 63) / 64)), (64), 0, st, (const fe_t *)d_g, (uint32_t)nG, f_alpha,
+               ntt::zeta(), ntt::omega(log_domain_K, false), inv_n, (uint32_t)instances_to_fold, (uint32_t)count, d_out, d_err);
+    ntt::run(d_out, log_domain_K, count, 1, true, true, st);     // UnivariatePoly::coset_ifft
+    SRS_HIP_CHECK(hipMemcpyAsync(out_host, d_out, count * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+    SRS_HIP_CHECK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    SRS_HIP_CHECK(hipStreamSynchronize(st));
     if (herr) { err = "Z(X) must be not equal to 0"; return 4; }
     return 0;
 }
