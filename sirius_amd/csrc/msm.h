@@ -14,6 +14,9 @@ constexpr uint32_t STRIPE_LOG = 10;       // multi-GPU block-cyclic stripe (entr
 constexpr uint32_t SORT_THREADS = 1024;   // one workgroup per CU: 128 KiB LDS histogram
 constexpr uint32_t SORT_TILE_MIN = 8192;       // digits per workgroup (lower bound)
 constexpr uint32_t SORT_TARGET_BLOCKS = 256;   // ~one 128-KiB-LDS workgroup per CU
+constexpr uint32_t SEG = 128, SEG_BUCKETS = NBUCKET / SEG;   // two-pass scatter: segments of 256 consecutive buckets
+constexpr uint32_t SORT_TILE2 = 65536;          // entries per workgroup of the second pass
+constexpr uint64_t TWO_PASS_MIN_SLOTS = 1ull << 28;   // digit slots (16 n x batch) from which the two-pass scatter wins (measured: 2^24-point MSMs)
 constexpr uint32_t PLAN_THREADS = 1024;
 constexpr uint32_t ACC_THREADS = 128;
 constexpr uint32_t ACC_L0_LOG = 4, ACC_L0 = 1u << ACC_L0_LOG;   // gathered mixed adds per level-0 thread

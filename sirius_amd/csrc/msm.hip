@@ -29,6 +29,7 @@
 #include "prof.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace srs {
@@ -191,24 +192,49 @@ __global__ void k_digits(BatchDesc bd, uint16_t *__restrict__ dig, size_t dig_st
 // 2. counting sort by bucket, LDS histogram per workgroup
 // grid = (tiles, NWIN, batch), block = SORT_THREADS
 // ---------------------------------------------------------------------------------------------
+// fn(i, code) for every digit slot i in [lo, hi): 8 digits per 16-byte load once the pointer is aligned (a 2-byte load per
+// lane uses 1/8 of the load width: the digit streams are read by k_hist, k_scatter and k_group)
+template <class Fn>
+__device__ __forceinline__ void for_each_digit(const uint16_t *__restrict__ d, uint32_t lo, uint32_t hi, Fn fn) {
+    uint32_t head = lo;
+    while (head < hi && (reinterpret_cast<uintptr_t>(d + head) & 15u)) ++head;      // at most 7 unaligned slots
+    for (uint32_t i = lo + threadIdx.x; i < head; i += blockDim.x) fn(i, (uint32_t)d[i]);
+    const uint32_t nvec = (hi - head) / 8;
+    const uint4 *v = reinterpret_cast<const uint4 *>(d + head);
+    for (uint32_t q = threadIdx.x; q < nvec; q += blockDim.x) {
+        const uint4 x = v[q];
+        const uint32_t i0 = head + q * 8;
+        fn(i0 + 0, x.x & 0xFFFFu); fn(i0 + 1, x.x >> 16);
+        fn(i0 + 2, x.y & 0xFFFFu); fn(i0 + 3, x.y >> 16);
+        fn(i0 + 4, x.z & 0xFFFFu); fn(i0 + 5, x.z >> 16);
+        fn(i0 + 6, x.w & 0xFFFFu); fn(i0 + 7, x.w >> 16);
+    }
+    for (uint32_t i = head + nvec * 8 + threadIdx.x; i < hi; i += blockDim.x) fn(i, (uint32_t)d[i]);
+}
+
 __device__ __forceinline__ void tile_histogram(uint32_t *h, const uint16_t *__restrict__ d, uint32_t lo, uint32_t hi) {
     for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) h[b] = 0;
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t code = d[i];
+    for_each_digit(d, lo, hi, [&](uint32_t, uint32_t code) {
         if (code != 0xFFFFu) atomicAdd(&h[code & 0x7FFFu], 1u);
-    }
+    });
     __syncthreads();
 }
 
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     k_hist(const uint16_t *__restrict__ dig, size_t dig_stride, BatchDesc bd,
-           uint32_t *__restrict__ count /* [batch][NBUCKET] */, uint32_t SORT_TILE) {
+           uint32_t *__restrict__ count /* [batch][NBUCKET] */, uint32_t SORT_TILE,
+           uint32_t *__restrict__ tile_hist /* two-pass sort: [batch][SEG][tiles * NWIN], or nullptr */) {
     __shared__ uint32_t h[NBUCKET];
     uint32_t m = blockIdx.z, w = blockIdx.y;
     uint32_t n = bd.n[m];
     uint32_t lo = blockIdx.x * SORT_TILE;
-    if (lo >= n) return;
+    const uint32_t T1 = gridDim.x * NWIN, t1 = w * gridDim.x + blockIdx.x;
+    if (lo >= n) {
+        if (tile_hist)
+            for (uint32_t sgm = threadIdx.x; sgm < SEG; sgm += blockDim.x) tile_hist[((size_t)m * SEG + sgm) * T1 + t1] = 0;
+        return;
+    }
     uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
     const uint16_t *d = dig + (size_t)m * dig_stride + (size_t)w * n;
     tile_histogram(h, d, lo, hi);
@@ -216,6 +242,100 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) {
         uint32_t c = h[b];
         if (c) atomicAdd(&cnt[b], c);
+    }
+    if (tile_hist) {                       // entries of this tile per segment (= SEG_BUCKETS consecutive buckets)
+        for (uint32_t sgm = threadIdx.x; sgm < SEG; sgm += blockDim.x) {
+            uint32_t c = 0;
+            for (uint32_t b = 0; b < SEG_BUCKETS; ++b) c += h[sgm * SEG_BUCKETS + ((b + sgm) & (SEG_BUCKETS - 1))];   // skewed: no bank conflicts
+            tile_hist[((size_t)m * SEG + sgm) * T1 + t1] = c;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t *total);   // defined with k_plan
+
+// ---- two-pass (MSD) variant of the scatter, for large MSMs -----------------------------------------------------------
+// The single-pass k_scatter writes every 4-byte entry to a random place of the whole sorted array (one bucket out of
+// 2^15 per entry: a tile holds < 1 entry per bucket, so nothing coalesces and every (tile, bucket) pair costs a global
+// atomic) -- 15 % of a 12 * 2^20 witness commit.  Two passes instead:
+//   A  k_group   : entries -> SEG = 128 segments of 256 consecutive buckets.  A tile contributes thousands of entries to
+//                  each segment, at offsets known from the per-tile segment counts (k_hist) scanned by k_scan_seg: the
+//                  writes are long coalesced runs, no global atomics.
+//   B  k_scatter2: tiles of the GROUPED array do the bucket-level counting sort.  A tile now touches 1-2 segments, i.e.
+//                  a few hundred buckets inside a ~MB region that lives in L2: the random 4-byte writes merge there and
+//                  the number of global reservations drops ~40x.
+// Within a bucket the order of entries is irrelevant (exact group arithmetic), so neither pass needs to be stable.
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_scan_seg(uint32_t *__restrict__ tile_hist, uint32_t T1, const uint32_t *__restrict__ plan, size_t plan_stride) {
+    // grid = (SEG, batch): exclusive scan of the T1 per-tile counts of one segment, offset by the segment's start off[seg * 256]
+    __shared__ uint32_t lds[64];
+    const uint32_t sgm = blockIdx.x, m = blockIdx.y;
+    uint32_t *row = tile_hist + ((size_t)m * SEG + sgm) * T1;
+    const uint32_t base = plan[(size_t)m * plan_stride + (size_t)sgm * SEG_BUCKETS];        // plan[0][b] = entry offset of bucket b
+    uint32_t carry = 0;
+    for (uint32_t at = 0; at < T1; at += blockDim.x) {
+        const uint32_t i = at + threadIdx.x;
+        const uint32_t v = i < T1 ? row[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, lds, &total);
+        if (i < T1) row[i] = base + carry + ex;
+        carry += total;
+    }
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_group(const uint16_t *__restrict__ dig, size_t dig_stride, BatchDesc bd, const uint32_t *__restrict__ tile_hist,
+            uint16_t *__restrict__ gkey, uint32_t *__restrict__ gpay, size_t g_stride, uint32_t table_stride, uint32_t SORT_TILE) {
+    __shared__ uint32_t cur[SEG];
+    uint32_t m = blockIdx.z, w = blockIdx.y;
+    uint32_t n = bd.n[m];
+    uint32_t lo = blockIdx.x * SORT_TILE;
+    if (lo >= n) return;
+    uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    const uint32_t T1 = gridDim.x * NWIN, t1 = w * gridDim.x + blockIdx.x;
+    for (uint32_t sgm = threadIdx.x; sgm < SEG; sgm += blockDim.x) cur[sgm] = tile_hist[((size_t)m * SEG + sgm) * T1 + t1];
+    __syncthreads();
+    const uint16_t *d = dig + (size_t)m * dig_stride + (size_t)w * n;
+    uint16_t *ok = gkey + (size_t)m * g_stride;
+    uint32_t *op = gpay + (size_t)m * g_stride;
+    for_each_digit(d, lo, hi, [&](uint32_t i, uint32_t code) {
+        if (code != 0xFFFFu) {
+            uint32_t pos = atomicAdd(&cur[(code & 0x7FFFu) / SEG_BUCKETS], 1u);
+            ok[pos] = (uint16_t)(code & 0x7FFFu);
+            op[pos] = (w * table_stride + i) | ((code & 0x8000u) << 16);
+        }
+    });
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_scatter2(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ gpay, size_t g_stride,
+               const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t *__restrict__ cursor /* [batch][NBUCKET] */,
+               uint32_t *__restrict__ sorted, size_t sorted_stride, uint32_t TILE2) {
+    __shared__ uint32_t h[NBUCKET];
+    const uint32_t m = blockIdx.y;
+    const uint32_t total = plan[(size_t)m * plan_stride + NBUCKET];        // number of non-zero digits of this MSM
+    const uint32_t lo = blockIdx.x * TILE2;
+    if (lo >= total) return;
+    const uint32_t hi = lo + TILE2 < total ? lo + TILE2 : total;
+    const uint16_t *key = gkey + (size_t)m * g_stride;
+    const uint32_t *pay = gpay + (size_t)m * g_stride;
+    // the grouped array is ordered by segment: this tile only holds buckets of segments seg(first) .. seg(last)
+    const uint32_t b_lo = ((uint32_t)key[lo] / SEG_BUCKETS) * SEG_BUCKETS;
+    const uint32_t b_hi = ((uint32_t)key[hi - 1] / SEG_BUCKETS + 1) * SEG_BUCKETS;
+    for (uint32_t b = b_lo + threadIdx.x; b < b_hi; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[key[i]], 1u);
+    __syncthreads();
+    uint32_t *cur = cursor + (size_t)m * NBUCKET;
+    for (uint32_t b = b_lo + threadIdx.x; b < b_hi; b += blockDim.x) {
+        uint32_t c = h[b];
+        if (c) h[b] = atomicAdd(&cur[b], c);                               // reserve [base, base + c)
+    }
+    __syncthreads();
+    uint32_t *out = sorted + (size_t)m * sorted_stride;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t pos = atomicAdd(&h[key[i]], 1u);
+        out[pos] = pay[i];
     }
 }
 
@@ -243,13 +363,12 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     }
     __syncthreads();
     uint32_t *out = sorted + (size_t)m * sorted_stride;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t code = d[i];
+    for_each_digit(d, lo, hi, [&](uint32_t i, uint32_t code) {
         if (code != 0xFFFFu) {
             uint32_t pos = atomicAdd(&h[code & 0x7FFFu], 1u);
             out[pos] = (w * table_stride + i) | ((code & 0x8000u) << 16);
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,6 +823,14 @@ static int levels_for(uint64_t max_entries) {
     return levels;
 }
 
+// large MSMs take the two-pass scatter (k_group + k_scatter2); SRS_MSM_SORT=1 / 2 forces the single- / two-pass path
+static bool use_two_pass(uint64_t M, uint32_t batch) {
+    static const int forced = [] { const char *e = std::getenv("SRS_MSM_SORT"); return e ? std::atoi(e) : 0; }();
+    if (forced == 1) return false;
+    if (forced == 2) return true;
+    return M * batch >= TWO_PASS_MIN_SLOTS;
+}
+
 size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     uint64_t M = (uint64_t)n_max * NWIN;
     int levels = levels_for(M);
@@ -719,6 +846,10 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     per += Arena::pad(parts1 * sizeof(xyzz_t));              // pong
     per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
+    if (use_two_pass(M, batch)) {
+        per += Arena::pad(M * sizeof(uint16_t)) + Arena::pad(M * sizeof(uint32_t));                     // grouped keys / payloads
+        per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));            // per-tile segment counts
+    }
     return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 4096;
 }
 
@@ -750,6 +881,10 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     xyzz_t *pong = A.take<xyzz_t>(parts1_cap * batch);
     xyzz_t *buckets = A.take<xyzz_t>((size_t)NBUCKET * batch);
     xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
+    const bool two_pass = use_two_pass(M, batch);
+    uint16_t *gkey = two_pass ? A.take<uint16_t>(M * batch) : nullptr;
+    uint32_t *gpay = two_pass ? A.take<uint32_t>(M * batch) : nullptr;
+    uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
 
     BatchDesc bd;
     for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
@@ -766,11 +901,21 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
     const uint32_t tiles = ceil_div(n_max, tile);
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
-               bd, count, tile);
+               bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
     SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
                levels, (uint32_t)ACC_L0_LOG, (uint32_t)ACC_L1_LOG);
-    SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
-               bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
+    if (two_pass) {
+        const uint32_t T1 = tiles * NWIN;
+        SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, plan_stride);
+        SRS_LAUNCH(k_group, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M, bd,
+                   (const uint32_t *)tile_hist, gkey, gpay, (size_t)M, (uint32_t)k.len, tile);
+        SRS_LAUNCH(k_scatter2, (ceil_div(M, SORT_TILE2), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
+                   (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, plan_stride, cursor, sorted, (size_t)M,
+                   (uint32_t)SORT_TILE2);
+    } else {
+        SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
+                   bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
+    }
 
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];

@@ -249,3 +249,25 @@ def test_commit_full_size_properties(srs, oracle, cid, n):
         e[j] = torch.from_numpy(one.view(np.int64))
         assert np.array_equal(ck.commit(e), bases[j])
     ck.close()
+
+
+def test_two_pass_scatter_matches_single_pass(srs, oracle):
+    """The MSD two-pass scatter (k_group + k_scatter2, used from 2^24-point MSMs on) against the single-pass one and the
+    oracle on sizes the oracle can do: forced through SRS_MSM_SORT (read once per process -> subprocesses)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O, sirius_amd as S\n"
+        "from conftest import seeded_scalars\n"
+        "for cid, n, kind in ((0, 70000, 'uniform'), (1, 33333, 'trace'), (0, 5, 'uniform')):\n"
+        "    bases = O.make_bases(cid, 4, n); ck = S.CommitmentKey(cid, bases)\n"
+        "    vs = [seeded_scalars(O, cid, n, 9 + j, kind) for j in range(3)]\n"
+        "    for g, v in zip(ck.commit_batch(vs), vs): assert np.array_equal(g, O.msm(cid, v, bases))\n"
+        "print('ok')\n")
+    from conftest import ROOT
+    for mode in ("1", "2"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT=mode), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
