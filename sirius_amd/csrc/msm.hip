@@ -917,7 +917,8 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
         SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, plan_stride);
         SRS_LAUNCH(k_group, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M, bd,
                    (const uint32_t *)tile_hist, gkey, gpay, (size_t)M, (uint32_t)k.len, tile);
-        SRS_LAUNCH(k_scatter2, (ceil_div(M, SORT_TILE2), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
+        // 8 x ceil(tiles / 8) workgroups: the XCD-aware mapping of k_scatter2 needs every (XCD, slot) pair to exist
+        SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
                    (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, plan_stride, cursor, sorted, (size_t)M,
                    (uint32_t)SORT_TILE2);
     } else {

@@ -149,3 +149,22 @@ def test_emu_batch_invert_assigned(emu, oracle):
     from test_lookup_gpu import _assigned_case
     _assigned_case(emu, oracle, 0, 300)
     _assigned_case(emu, oracle, 1, 1)
+
+
+def test_emu_two_pass_scatter():
+    """SRS_MSM_SORT=2 (two-pass scatter incl. the XCD-aware tile mapping) on the emulator; the switch is read once per process."""
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O\n"
+        "from sirius_amd import _lib; _lib.load('tests/emu/libsirius_emu.so')\n"
+        "import sirius_amd as S\n"
+        "from conftest import seeded_scalars\n"
+        "bases = O.make_bases(1, 4, 9000); ck = S.CommitmentKey(1, bases)\n"
+        "for n in (9000, 4097, 3):\n"
+        "    v = seeded_scalars(O, 1, n, n, 'uniform')\n"
+        "    assert np.array_equal(ck.commit(v), O.msm(1, v, bases[:n]))\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT="2"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
