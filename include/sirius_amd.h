@@ -17,8 +17,9 @@
  * used when witnesses already live in HBM).  Small outputs (commitments) are always written to
  * host memory.  Outputs are written only when the call returns SRS_OK.
  *
- * Calls are synchronous from the caller's point of view and thread-compatible (distinct handles
- * may be used from distinct threads).  Errors: int return code + srs_last_error() (thread-local).
+ * Calls are synchronous from the caller's point of view (the two streaming folds on device-resident
+ * operands are stream-ordered instead, see srs_fold_witness) and thread-compatible (distinct handles
+ * may be used from distinct threads; the library rebinds the calling thread to the process's GPU).  Errors: int return code + srs_last_error() (thread-local).
  * There is NO CPU fallback: without a gfx950 device every compute entry returns SRS_ERR_DEVICE.
  */
 #ifndef SIRIUS_AMD_H
