@@ -85,6 +85,7 @@ class Side:
         self.rpows = ints_to_mont(sf, [pow(rv, i + 1, MODULUS[sf]) for i in range(self.d)])
         self.accCW = np.zeros(8, dtype=np.uint64)
         self.accCE = np.zeros(8, dtype=np.uint64)
+        self.pending = None      # instance fold of the previous step, still running on the host workers
         # random oracle over the base field of this side's curve (its points are what gets absorbed)
         self.ro = S.PoseidonHash(1 if self.curve == 0 else 0, 5, 4, 10, 10)
 
@@ -101,8 +102,16 @@ def combine(S, side, partial, dist, world, dev):
     return all_gather_commitments(side.curve, partial, device=dev if dist.get_backend() == "nccl" else None)
 
 
+def settle(side):
+    """Joins the instance fold of the previous step (its result is this step's accumulator instance)."""
+    if side.pending is not None:
+        side.accCE, side.accCW = side.pending[0].wait(), side.pending[1].wait()
+        side.pending = None
+
+
 def prove(S, side, dist, world, dev):
     """VanillaFS::prove hot path (src/nifs/sangria/mod.rs:253-277)."""
+    settle(side)
     terms, commits = S.VanillaFS.commit_cross_terms(side.ck, side.S, side.u1c, side.u1u, side.accW, side.u2c, side.inW)
     if COUNT_NONZERO:     # untimed warm-up only: mixed additions issued = 16 windows x non-zero scalars (ALU roofline)
         side.nz_terms = sum(int((t != 0).any(dim=1).sum().item()) for t in terms)
@@ -121,12 +130,13 @@ def prove(S, side, dist, world, dev):
     # generate_challenge: Poseidon RO on the CPU in the reference -> seeded constant r here.
     # Both folds depend only on r: the instance fold (host scalar-muls, accumulator.rs:201-264:
     # W' = W1 + r*W2 ; E' = E + sum r^k T_k) runs on the host while the GPU folds the witness.
-    # The witness fold is stream-ordered (device-resident operands): both kernels are enqueued first, then this thread does
-    # the instance fold while the GPU works (the d scalar multiplications of E run on the library's worker pool).
+    # The witness fold is stream-ordered (device-resident operands): both kernels are enqueued first; the instance fold (d + 1
+    # host scalar multiplications) is handed to the library's host workers and joined when this side's accumulator instance is
+    # next needed (settle) -- nothing on the device waits for it, so the next commitment is enqueued meanwhile.
     acc = S.RelaxedPlonkWitness(side.field, [side.accW], side.accE).fold([side.inW], terms, side.r)
     side.accW, side.accE = acc.W[0], acc.E
-    side.accCE = S.point_lincomb(side.curve, side.accCE, commits, side.rpows)
-    side.accCW = S.point_lincomb(side.curve, side.accCW, side.inC.reshape(1, 8), side.r.reshape(1, 4))
+    side.pending = (S.point_lincomb_async(side.curve, side.accCE, commits, side.rpows),
+                    S.point_lincomb_async(side.curve, side.accCW, side.inC.reshape(1, 8), side.r.reshape(1, 4)))
     return commits
 
 
@@ -235,6 +245,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fold_step(S, pri, sec, dist, world, dev)
+    settle(pri); settle(sec)     # the last step's instance folds belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
     S.profile_enable(False)
@@ -261,6 +272,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(rsteps):
             fold_step(S, rp, rs, None, 1, dev)
+        settle(rp); settle(rs)
         barrier()
         rdt = time.perf_counter() - t1
         tt = torch.tensor([rdt], dtype=torch.float64, device=red_dev)

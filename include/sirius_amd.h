@@ -109,6 +109,14 @@ int srs_point_mul(int curve, const srs_fe *scalar, int repr, const srs_affine *p
  * RelaxedPlonkInstance::fold -- W_commitments (n = 1) and E_commitment (n = d) -- src/nifs/sangria/accumulator.rs:201-264. */
 int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n,
                       int repr, srs_affine *out);
+/* The same fold, off the caller's thread: nothing on the device waits for the folded instance, so a prover enqueues its next
+ * commitment while this runs on the library's host workers (jobs complete in submission order).  acc / points / scalars are
+ * copied before the call returns; `out` is written by the job and must stay valid until srs_job_wait(*job) returns.
+ * srs_job_wait: 0 once the job has finished (its output is then visible to the caller); SRS_ERR_INVALID for an unknown or
+ * already waited-for job. */
+int srs_point_lincomb_async(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n,
+                            int repr, srs_affine *out, uint64_t *job);
+int srs_job_wait(uint64_t job);
 
 /* ---- per-kernel timing (HIP events on the launch stream), used by bench.py's roofline leg ----
  * names: "msm_accum0" (units = scalars), "rowprog_cross_terms" (rows), "rowprog_eval" (rows), "ntt_transform" (elements) */

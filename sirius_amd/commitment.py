@@ -172,6 +172,39 @@ def point_lincomb(curve, acc, points, scalars, repr=L.REPR_MONT):
     return out
 
 
+class PendingPoint:
+    """Result of point_lincomb_async: .wait() -> the (8,) affine point (blocks until the host workers are done)."""
+
+    def __init__(self, job, out):
+        self._job, self._out = job, out
+
+    def wait(self):
+        if self._job is not None:
+            L.check(L.lib().srs_job_wait(self._job))
+            self._job = None
+        return self._out
+
+    def __del__(self):       # never leave a job writing into freed memory
+        try:
+            if self._job is not None:
+                L.lib().srs_job_wait(self._job)
+        except Exception:
+            pass
+
+
+def point_lincomb_async(curve, acc, points, scalars, repr=L.REPR_MONT):
+    """point_lincomb on the library's host workers, off the calling thread (the instance fold overlaps the next commitment)."""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    assert pts.shape[0] == sc.shape[0]
+    a = None if acc is None else np.ascontiguousarray(acc, dtype=np.uint64).reshape(8)
+    out = np.zeros(8, dtype=np.uint64)
+    job = C.c_uint64()
+    L.check(L.lib().srs_point_lincomb_async(curve, None if a is None else a.ctypes.data, pts.ctypes.data, sc.ctypes.data,
+                                            pts.shape[0], repr, out.ctypes.data, C.byref(job)))
+    return PendingPoint(job.value, out)
+
+
 def point_mul(curve, scalar, p, repr=L.REPR_MONT):
     s = np.ascontiguousarray(scalar, dtype=np.uint64).reshape(4)
     q = np.ascontiguousarray(p, dtype=np.uint64).reshape(8)

@@ -3,6 +3,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <set>
 #include <thread>
 #include <condition_variable>
 #include <functional>
@@ -513,9 +516,9 @@ int srs_ntt(int field, srs_fe *a, size_t n, int inverse, int coset, int space, v
     return srs_ntt_batch(field, a, n, n, 1, inverse, coset, space, stream);
 }
 
-int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n, int repr,
-                      srs_affine *out) {
-    if (!valid_curve(curve) || !out || (n && (!points || !scalars))) return fail(SRS_ERR_INVALID, "srs_point_lincomb: bad argument");
+// acc + sum scalars[i] * points[i]; inputs already validated
+static void point_lincomb_impl(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n, int repr,
+                               srs_affine *out) {
     auto go = [&](auto tag) {
         using C = decltype(tag);
         std::vector<xyzz_t> part(n);
@@ -539,6 +542,91 @@ int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points
         std::memcpy(out, &r, sizeof(r));
     };
     if (curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
+}
+
+int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n, int repr,
+                      srs_affine *out) {
+    if (!valid_curve(curve) || !out || (n && (!points || !scalars))) return fail(SRS_ERR_INVALID, "srs_point_lincomb: bad argument");
+    point_lincomb_impl(curve, acc, points, scalars, n, repr, out);
+    return SRS_OK;
+}
+
+// The instance fold is host work that nothing on the device waits for: run behind the caller's back on one background
+// thread (FIFO; it borrows the HostPool for the independent scalar multiplications) while the caller enqueues the next
+// commitment.  Inputs are copied at submission; only `out` has to stay valid until srs_job_wait.
+namespace {
+class AsyncJobs {
+public:
+    static AsyncJobs &get() {
+        static AsyncJobs *q = new AsyncJobs();    // never destroyed (detached worker)
+        return *q;
+    }
+    uint64_t submit(std::function<void()> fn) {
+        std::lock_guard<std::mutex> lk(mu_);
+        const uint64_t id = ++last_id_;
+        queue_.emplace_back(id, std::move(fn));
+        open_.insert(id);
+        cv_.notify_one();
+        return id;
+    }
+    // false: unknown (or already waited-for) job
+    bool wait(uint64_t id) {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (!open_.count(id)) return false;
+        done_cv_.wait(lk, [&] { return done_.count(id) != 0; });
+        done_.erase(id);
+        open_.erase(id);
+        return true;
+    }
+
+private:
+    AsyncJobs() { std::thread([this] { loop(); }).detach(); }
+    void loop() {
+        for (;;) {
+            std::pair<uint64_t, std::function<void()>> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !queue_.empty(); });
+                job = std::move(queue_.front());
+                queue_.pop_front();
+            }
+            job.second();
+            std::lock_guard<std::mutex> lk(mu_);
+            done_.insert(job.first);
+            done_cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<std::pair<uint64_t, std::function<void()>>> queue_;
+    std::set<uint64_t> open_, done_;
+    uint64_t last_id_ = 0;
+};
+}  // namespace
+
+int srs_point_lincomb_async(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n, int repr,
+                            srs_affine *out, uint64_t *job) {
+    if (!valid_curve(curve) || !out || !job || (n && (!points || !scalars)))
+        return fail(SRS_ERR_INVALID, "srs_point_lincomb_async: bad argument");
+    struct Args {
+        bool has_acc;
+        srs_affine acc;
+        std::vector<srs_affine> points;
+        std::vector<srs_fe> scalars;
+    };
+    auto a = std::make_shared<Args>();
+    a->has_acc = acc != nullptr;
+    if (acc) a->acc = *acc;
+    a->points.assign(points, points + n);
+    a->scalars.assign(scalars, scalars + n);
+    *job = AsyncJobs::get().submit([=] {
+        point_lincomb_impl(curve, a->has_acc ? &a->acc : nullptr, a->points.data(), a->scalars.data(), n, repr, out);
+    });
+    return SRS_OK;
+}
+
+int srs_job_wait(uint64_t job) {
+    if (!AsyncJobs::get().wait(job)) return fail(SRS_ERR_INVALID, "srs_job_wait: unknown job");
     return SRS_OK;
 }
 

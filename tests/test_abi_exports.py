@@ -46,6 +46,41 @@ def test_host_only_entries():
         assert np.array_equal(S.point_sum(cid, np.zeros((0, 8), np.uint64)), np.zeros(8, np.uint64))
 
 
+def test_async_instance_fold_matches_the_blocking_one():
+    """srs_point_lincomb_async / srs_job_wait (host workers): same points as srs_point_lincomb, any wait order, inputs may be
+    released right after submission, a job can be waited for once."""
+    import pytest
+    import sirius_amd as S
+    from sirius_amd import _lib
+    import oracle as O
+    from oracle import pyref as P
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for cid in (0, 1):
+        sf = O.SCALAR_FIELD[cid]
+        b = O.make_bases(cid, 9, 12)
+        jobs, expect = [], []
+        for n in (0, 1, 6, 11):
+            sc = O.ints_to_mont(sf, [int(rng.integers(1, 1 << 62)) ** 4 % P.MODULI[sf] for _ in range(n)]) if n else np.zeros((0, 4), np.uint64)
+            acc = None if n == 1 else b[11]
+            pts = b[:n].copy()
+            expect.append(S.point_lincomb(cid, acc, pts, sc))
+            jobs.append(S.point_lincomb_async(cid, acc, pts, sc))
+            pts[:] = 0; sc[:] = 0          # inputs were copied at submission
+        for j in (2, 0, 3, 1):             # any order
+            assert np.array_equal(jobs[j].wait(), expect[j])
+            assert np.array_equal(jobs[j].wait(), expect[j])       # the python handle is idempotent ...
+        # n = 6 against the oracle's msm as an independent check
+        sc = O.ints_to_mont(sf, list(range(3, 9)))
+        assert np.array_equal(S.point_lincomb_async(cid, None, b[:6], sc).wait(), O.msm(cid, sc, b[:6]))
+    out, job = np.zeros(8, np.uint64), ctypes.c_uint64()
+    assert lib.srs_point_lincomb_async(0, None, None, None, 0, 1, out.ctypes.data, ctypes.byref(job)) == 0
+    assert lib.srs_job_wait(job.value) == 0
+    assert lib.srs_job_wait(job.value) == _lib.ERR_INVALID     # ... the C job is not
+    assert lib.srs_job_wait(1 << 60) == _lib.ERR_INVALID
+    assert lib.srs_point_lincomb_async(0, None, None, None, 0, 1, None, ctypes.byref(job)) == _lib.ERR_INVALID
+
+
 def test_univariate_eval_kats():
     """UnivariatePoly::eval known answers of the reference (src/polynomial/univariate.rs:197-262) through srs_poly_eval
     (host code: runs without a device)."""
