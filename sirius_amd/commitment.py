@@ -29,14 +29,21 @@ def _buf(x, last):
     return a.ctypes.data, L.SPACE_HOST, a.size // last, a
 
 
+_torch_cuda = None      # torch.cuda once it is known to be usable (is_available() costs ~50-90 us per call on ROCm)
+
+
 def _stream():
-    try:
-        import torch
-        if torch.cuda.is_available():
-            return torch.cuda.current_stream().cuda_stream
-    except Exception:
-        pass
-    return None
+    """The caller's current torch stream (the kernels are enqueued behind the caller's own work), or the default stream."""
+    global _torch_cuda
+    if _torch_cuda is None:
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return None
+            _torch_cuda = torch.cuda
+        except Exception:
+            return None
+    return _torch_cuda.current_stream().cuda_stream
 
 
 class CommitmentKey:
