@@ -381,6 +381,7 @@ int srs_ck_create(int curve, const srs_affine *bases, size_t len, int space, srs
 void srs_ck_free(srs_ck *ck) {
     if (!ck) return;
     if (ck->key.table) (void)hipFree(ck->key.table);
+    if (ck->key.h_result) (void)hipHostFree(ck->key.h_result);
     ck->key.arena.release();
     ck->staging.release();
     delete ck;

@@ -42,6 +42,7 @@ struct Key {
     uint32_t rank = 0, world = 1;
     affine_t *table = nullptr;
     Arena arena;              // per-key scratch (grow-only)
+    void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
 };
 
 // fills table[len .. 16*len) from table[0 .. len)

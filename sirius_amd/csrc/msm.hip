@@ -955,8 +955,9 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap, (const uint32_t *)plan,
                plan_stride, rc);
     SRS_LAUNCH((k_reduce_final<C>), (3, batch), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_out);
-    std::vector<xyzz_t> two(3 * (size_t)batch);
-    SRS_HIP_CHECK(hipMemcpyAsync(two.data(), d_out, two.size() * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
+    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * sizeof(xyzz_t)));
+    xyzz_t *two = static_cast<xyzz_t *>(k.h_result);
+    SRS_HIP_CHECK(hipMemcpyAsync(two, d_out, 3 * (size_t)batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
     SRS_HIP_CHECK(hipGetLastError());
     for (uint32_t m = 0; m < batch; ++m) {             // S = RED_COLS * (2 A' + Z) + B on the host (10 group ops)
