@@ -47,3 +47,68 @@ def test_sharded_commit_world2_gloo(tmp_path, oracle):
            "--master-port", "29591", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+PROVE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SRS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SRS_ROOT"], "tests"))
+import torch, torch.distributed as dist
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+import sirius_amd._lib as L
+L.load(os.path.join(os.environ["SRS_ROOT"], "tests", "emu", "libsirius_emu.so"))
+import sirius_amd as S
+import oracle as O
+from oracle import expr as OE
+from sirius_amd.distributed import all_gather_commitments
+from test_sangria_gpu import _oracle_gates
+from workloads import gates_for, rand_fe
+field, curve, k, gate_T = 1, 1, 11, [2]
+rows = 1 << k
+gates, nfix, nadv = gates_for(gate_T)
+rng = np.random.default_rng(77)                       # same stream on every rank: identical inputs
+fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
+W1, W2, E = rand_fe(rng, nadv * rows), rand_fe(rng, nadv * rows), rand_fe(rng, rows)
+St = S.PlonkStructure(field, k, [], fixed, nadv, gates)
+St.set_shard(rank, world)
+nch = St.num_challenges
+u1c, u1u, u2c, r = rand_fe(rng, nch), rand_fe(rng, 1)[0], rand_fe(rng, nch), rand_fe(rng, 1)[0]
+bases = O.make_bases(curve, 9, rows)
+ck = S.CommitmentKey(curve, bases, rank=rank, world=world)
+# VanillaFS::prove, sharded: local cross-term stripes -> partial commitments -> all-gather -> host sum; folds on local data
+terms, partial = S.VanillaFS.commit_cross_terms(ck, St, u1c, u1u, W1, u2c, W2)
+commits = all_gather_commitments(curve, partial)
+acc = S.RelaxedPlonkWitness(field, [W1], E).fold([W2], terms, r)
+ch = S.VanillaFS.cross_term_challenges(u1c, u1u, u2c, field)
+_, exp = OE.cross_terms_oracle(O, field, _oracle_gates(gate_T), 0, nfix, nadv, [], fixed, W1, W2, ch)
+mine = ((np.arange(rows) >> 10) % world) == rank
+ok = len(terms) == len(exp) == St.num_cross_terms
+rb = lambda x: np.broadcast_to(x, (rows, 4)).copy()
+Eo, rk = E.copy(), r.reshape(1, 4).copy()
+for j, (t, e) in enumerate(zip(terms, exp)):
+    ok &= bool(np.array_equal(t[mine], e[mine]) and not t[~mine].any())
+    ok &= bool(np.array_equal(commits[j], O.msm(curve, e, bases)))           # the partials add up to commit(T_k) of ALL rows
+    Eo = O.fe_add(field, Eo, O.fe_mul(field, rb(rk[0]), e))
+    rk = O.fe_mul(field, rk, r.reshape(1, 4))
+ok &= bool(np.array_equal(acc.E[mine], Eo[mine]) and np.array_equal(acc.E[~mine], E[~mine]))   # error fold: this rank's stripes
+Wo = O.fe_add(field, W1, O.fe_mul(field, np.broadcast_to(r, W2.shape).copy(), W2))
+ok &= bool(np.array_equal(acc.W[0], Wo))                                                       # witness fold: every row
+t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+dist.destroy_process_group()
+sys.exit(0 if int(t.item()) == 1 else 1)
+'''
+
+
+def test_sharded_prove_world2_gloo(tmp_path, oracle):
+    """bench.py's N > 1 prove: row-sharded cross terms (srs_structure_set_shard) + sharded key + all-gather of the partial
+    commitments + folds, two processes over gloo; every rank checks its stripes and the combined commitments."""
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-C", emu_dir, "-j4"], stdout=subprocess.DEVNULL)
+    script = tmp_path / "prove_worker.py"
+    script.write_text(PROVE_WORKER)
+    env = dict(os.environ, SRS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29593", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
