@@ -975,9 +975,14 @@ static uint64_t fingerprint_of(const Program &p) {
 }
 
 // straight-line C++ for the SSA program (one function template over the field)
-std::string emit_spec_source(const Program &p, const std::string &name) {
+std::string emit_spec_source(const Program &p, const std::string &name, bool shared_mul) {
     std::string o;
     auto opnd = [](int x) { return x >= 0 ? "v" + std::to_string(x) : "U[" + std::to_string(-x - 1) + "]"; };
+    // shared_mul: the multiplications call ONE shared body (mul_ni / sqr_ni, rowprog_dev.cuh) instead of inlining 2 KB of
+    // code each, so a program is tens of KB, not hundreds.  Run-time compiled kernels need that: with every multiplier
+    // inlined they ran 30 % slower than the same ISA linked into the library (profiles/r01_jit_vs_aot.txt), called they
+    // match it.  The ahead-of-time kernels keep the inlined form (3 % faster there).
+    const std::string MUL = shared_mul ? "mul_ni<F>(" : "F::mul(", SQR = shared_mul ? "sqr_ni<F>(" : "F::sqr(";
     o += "template <class F>\n__device__ __forceinline__ fe_t " + name +
          "(const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *__restrict__ U) {\n";
     o += "    const uint32_t mask = C.rows - 1; (void)mask; (void)pt; (void)U;\n";
@@ -990,8 +995,8 @@ std::string emit_spec_source(const Program &p, const std::string &name) {
         case I_LD_ADV: o += d + "ld_adv<F>(C, " + std::to_string(in.a) + ", " + rr + ", pt);\n"; break;
         case I_ADD: o += d + "F::add(" + opnd(in.a) + ", " + opnd(in.b) + ");\n"; break;
         case I_SUB: o += d + "F::sub(" + opnd(in.a) + ", " + opnd(in.b) + ");\n"; break;
-        case I_MUL: o += d + "F::mul(" + opnd(in.a) + ", " + opnd(in.b) + ");\n"; break;
-        case I_SQR: o += d + "F::sqr(" + opnd(in.a) + ");\n"; break;
+        case I_MUL: o += d + MUL + opnd(in.a) + ", " + opnd(in.b) + ");\n"; break;
+        case I_SQR: o += d + SQR + opnd(in.a) + ");\n"; break;
         case I_DBL: o += d + "F::dbl(" + opnd(in.a) + ");\n"; break;
         default: o += d + "F::neg(" + opnd(in.a) + ");\n"; break;
         }
@@ -1153,7 +1158,8 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     //      rows on (one hiprtc compile ~ a second); single-pass degrees only (the kernel body parks d + 1 <= 9 points).
     if (S->cross.spec_id < 0 && S->degree >= 1 && S->degree <= DMAX && !S->cross.insns.empty() && jit::enabled() &&
         (k >= 14 || std::getenv("SRS_JIT_ALWAYS"))) {
-        std::string src = "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" + emit_spec_source(S->cross, "jit_fn");
+        std::string src = "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" +
+                          emit_spec_source(S->cross, "jit_fn", std::getenv("SRS_JIT_INLINE_MUL") == nullptr);
         const char *fname = field == 0 ? "Fr" : "Fq";
         src += std::string("extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n") +
                "    spec_kernel_body<" + fname + ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname +
@@ -1273,7 +1279,7 @@ static void launch_rowprog(const DevArgs &A, uint32_t nslots, hipStream_t st) {
 const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf) {
     if (which >= 3 && (size_t)(which - 3) >= S->gate_progs.size()) { buf.clear(); return buf.c_str(); }
     Program &p = which >= 3 ? S->gate_progs[which - 3] : (which == 0 ? S->cross : (which == 1 ? S->plain_compressed : S->plain_homogeneous));
-    buf = emit_spec_source(p, "spec_fn");
+    buf = emit_spec_source(p, "spec_fn", false);   // ahead-of-time generation: inlined multipliers
     if (fingerprint) *fingerprint = p.fingerprint;
     if (spec_id) *spec_id = p.spec_id;
 #if !defined(SRS_EMU)

@@ -63,6 +63,13 @@ __device__ __forceinline__ fe_t small_times(const fe_t &x, uint32_t j) {   // j 
     return acc;
 }
 
+// One multiplier body per kernel for the straight-line programs (emit_spec_source): a program with every 2 KB multiplier
+// inlined is hundreds of KB of code streamed once per evaluation point; called, it is tens of KB.
+template <class F>
+__device__ __attribute__((noinline)) fe_t mul_ni(fe_t a, fe_t b) { return F::mul(a, b); }
+template <class F>
+__device__ __attribute__((noinline)) fe_t sqr_ni(fe_t a) { return F::sqr(a); }
+
 // column loads (PlonkEvalDomain::eval_column_var / eval_advice_var, src/plonk/eval.rs:57-69,153-228)
 template <class F>
 __device__ __forceinline__ fe_t ld_sel(const RowCtx &C, uint32_t col, uint32_t rr) { return C.sel[col][rr] ? F::one() : F::zero(); }
