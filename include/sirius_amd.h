@@ -191,6 +191,11 @@ size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructur
  * -2 straight-line kernel compiled at structure creation with hiprtc (structures of >= 2^14 rows without an ahead-of-time kernel).
  * Returns the source length (truncated to cap-1).  Used by tools/gen_rowprog_spec.py. */
 size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id);
+/* Developer hook, host only (needs no device): compiles a small row program in the emitted form with hiprtc against the device
+ * headers embedded in the library -- the run-time compilation path of srs_structure_create minus the module load.  0 and the
+ * size of the gfx950 code object, or SRS_ERR_INVALID with the compiler log (log may be NULL).  A structure whose program fails to
+ * compile silently stays on the interpreter, so this is the check that the path is alive. */
+int srs_jit_selfcheck(size_t *code_bytes, char *log, size_t log_cap);
 
 /* Evaluation half of VanillaFS::commit_cross_terms (src/nifs/sangria/mod.rs:102-148):
  *   T_out[k-1][row] = coefficient of X^k in P_homogeneous(fixed, W1 + X*W2, ch1 + X*ch2)[row],  k = 1..d

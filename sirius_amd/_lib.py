@@ -40,6 +40,7 @@ def _prototypes():
         "srs_point_lincomb": (i32, [i32, vp, vp, vp, sz, i32, vp]),
         "srs_point_lincomb_async": (i32, [i32, vp, vp, vp, sz, i32, vp, C.POINTER(C.c_uint64)]),
         "srs_job_wait": (i32, [C.c_uint64]),
+        "srs_jit_selfcheck": (i32, [C.POINTER(sz), C.c_char_p, sz]),
         "srs_profile_enable": (None, [i32]),
         "srs_profile_reset": (None, []),
         "srs_profile_get": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

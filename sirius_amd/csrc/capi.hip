@@ -694,6 +694,22 @@ int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world) {
 size_t srs_structure_num_cross_terms(const srs_structure *S) { return S ? rowprog::degree(S->s) : 0; }
 size_t srs_structure_num_challenges(const srs_structure *S) { return S ? rowprog::num_challenges(S->s) : 0; }
 size_t srs_structure_num_witness_columns(const srs_structure *S) { return S ? rowprog::num_witness_columns(S->s) : 0; }
+int srs_jit_selfcheck(size_t *code_bytes, char *log, size_t log_cap) {
+#if defined(SRS_EMU)
+    (void)code_bytes; (void)log; (void)log_cap;
+    return fail(SRS_ERR_INVALID, "srs_jit_selfcheck: not part of the emulator build");
+#else
+    std::string text;
+    const bool ok = rowprog::jit_selfcheck(code_bytes, text);
+    if (log && log_cap) {
+        const size_t n = std::min(text.size(), log_cap - 1);
+        std::memcpy(log, text.data(), n);
+        log[n] = 0;
+    }
+    return ok ? SRS_OK : fail(SRS_ERR_INVALID, "srs_jit_selfcheck: hiprtc rejected the emitted form: " + text.substr(0, 400));
+#endif
+}
+
 size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id) {
     if (!S) return 0;
     std::string src;

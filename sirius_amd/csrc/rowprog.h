@@ -55,6 +55,8 @@ int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, s
 // straight-line C++ of the structure's row program (tools/gen_rowprog_spec.py), its fingerprint and the
 // ahead-of-time kernel it maps to (-1: interpreter)
 const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf);
+// hiprtc compiles a small program in the emitted form against the embedded device headers (host only, no device needed)
+bool jit_selfcheck(size_t *code_bytes, std::string &log);
 
 // lookup arguments (src/plonk/lookup.rs): all pointers DEVICE; ls / ts / ms HOST arrays of num_lookups DEVICE vectors
 int lookup_coeff_1(Structure *S, const fe_t *advice_dev, const fe_t &r, fe_t *const *ls, fe_t *const *ts, fe_t *const *ms,

@@ -1007,6 +1007,37 @@ std::string emit_spec_source(const Program &p, const std::string &name, bool sha
     return o;
 }
 
+#if !defined(SRS_EMU)
+// the translation unit hiprtc compiles: the emitted program `jit_fn` wrapped in the kernel body the ahead-of-time kernels use
+static std::string jit_translation_unit(const std::string &fn_source, int field) {
+    const char *fname = field == 0 ? "Fr" : "Fq";
+    return "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" + fn_source +
+           "extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n    spec_kernel_body<" + fname +
+           ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname + ">(C, row, pt, U); });\n}\n}\n}\n";
+}
+
+// Host-only check of the run-time compilation path (no device): a small program in the emitted form -- column loads,
+// called and inlined multipliers, a uniform -- must compile with hiprtc against the headers embedded in the library.
+bool jit_selfcheck(size_t *code_bytes, std::string &log) {
+    const std::string fn =
+        "template <class F>\n__device__ __forceinline__ fe_t jit_fn(const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *__restrict__ U) {\n"
+        "    const uint32_t mask = C.rows - 1;\n"
+        "    const fe_t v0 = ld_fix<F>(C, 0, (row + 0u) & mask);\n"
+        "    const fe_t v1 = ld_adv<F>(C, 0, (row + 1u) & mask, pt);\n"
+        "    const fe_t v2 = ld_sel<F>(C, 0, (row + 0u) & mask);\n"
+        "    const fe_t v3 = mul_ni<F>(v0, v1);\n"
+        "    const fe_t v4 = sqr_ni<F>(v3);\n"
+        "    const fe_t v5 = F::mul(U[0], v2);\n"
+        "    return F::sub(F::add(v4, v5), F::dbl(F::neg(v1)));\n}\n";
+    for (int field = 0; field < 2; ++field) {
+        size_t bytes = 0;
+        if (!jit::compile_only(jit_translation_unit(fn, field), &bytes, log)) return false;
+        if (code_bytes) *code_bytes = bytes;
+    }
+    return true;
+}
+#endif
+
 struct Structure {
     int field = 0;
     uint32_t k = 0;
@@ -1158,12 +1189,7 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     //      rows on (one hiprtc compile ~ a second); single-pass degrees only (the kernel body parks d + 1 <= 9 points).
     if (S->cross.spec_id < 0 && S->degree >= 1 && S->degree <= DMAX && !S->cross.insns.empty() && jit::enabled() &&
         (k >= 14 || std::getenv("SRS_JIT_ALWAYS"))) {
-        std::string src = "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" +
-                          emit_spec_source(S->cross, "jit_fn", std::getenv("SRS_JIT_INLINE_MUL") == nullptr);
-        const char *fname = field == 0 ? "Fr" : "Fq";
-        src += std::string("extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n") +
-               "    spec_kernel_body<" + fname + ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname +
-               ">(C, row, pt, U); });\n}\n}\n}\n";
+        const std::string src = jit_translation_unit(emit_spec_source(S->cross, "jit_fn", std::getenv("SRS_JIT_INLINE_MUL") == nullptr), field);
         std::string log;
         if (!jit::compile(src, "srs_jit_rowprog", S->cross.jit, log) && std::getenv("SRS_DEBUG_ROWPROG"))
             std::fprintf(stderr, "rowprog: hiprtc compile failed, staying on the interpreter:\n%s\n", log.c_str());

@@ -81,6 +81,19 @@ def test_async_instance_fold_matches_the_blocking_one():
     assert lib.srs_point_lincomb_async(0, None, None, None, 0, 1, None, ctypes.byref(job)) == _lib.ERR_INVALID
 
 
+def test_run_time_compilation_path_compiles_without_a_device():
+    """hiprtc + the device headers embedded in the library accept the emitted program form (called and inlined multipliers,
+    column loads, uniforms) for both fields -- a header that stops compiling under hiprtc would otherwise only show up as a
+    silent fall-back to the interpreter on the GPU box."""
+    from sirius_amd import _lib
+    lib = _lib.load()
+    log = ctypes.create_string_buffer(1 << 16)
+    size = ctypes.c_size_t()
+    rc = lib.srs_jit_selfcheck(ctypes.byref(size), log, len(log))
+    assert rc == 0, log.value.decode(errors="replace")[-3000:]
+    assert size.value > 4096          # a real gfx950 code object
+
+
 def test_univariate_eval_kats():
     """UnivariatePoly::eval known answers of the reference (src/polynomial/univariate.rs:197-262) through srs_poly_eval
     (host code: runs without a device)."""
