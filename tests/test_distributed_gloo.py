@@ -9,6 +9,13 @@ import numpy as np
 
 from conftest import ROOT
 
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
 WORKER = r'''
 import os, sys
 import numpy as np
@@ -44,7 +51,7 @@ def test_sharded_commit_world2_gloo(tmp_path, oracle):
     script.write_text(WORKER)
     env = dict(os.environ, SRS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29591", str(script)]
+           "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -109,6 +116,6 @@ def test_sharded_prove_world2_gloo(tmp_path, oracle):
     script.write_text(PROVE_WORKER)
     env = dict(os.environ, SRS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29593", str(script)]
+           "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
