@@ -81,6 +81,35 @@ def test_async_instance_fold_matches_the_blocking_one():
     assert lib.srs_point_lincomb_async(0, None, None, None, 0, 1, None, ctypes.byref(job)) == _lib.ERR_INVALID
 
 
+def test_async_instance_fold_from_several_threads():
+    """The job queue is shared by every caller: four host threads submit and join their own jobs concurrently."""
+    import threading
+    import sirius_amd as S
+    import oracle as O
+    from sirius_amd import _lib
+    _lib.load()
+    b = O.make_bases(0, 21, 8)
+    sc = O.ints_to_mont(O.FR, [3, 5, 7, 11, 13, 17, 19, 23])
+    expect = [S.point_lincomb(0, b[j % 8], b[:1 + j % 7], sc[:1 + j % 7]) for j in range(14)]
+    errors = []
+
+    def run(seed):
+        try:
+            order = np.random.default_rng(seed).permutation(14)
+            for _ in range(6):
+                jobs = {int(j): S.point_lincomb_async(0, b[j % 8], b[:1 + j % 7], sc[:1 + j % 7]) for j in order}
+                for j in reversed(order):
+                    if not np.array_equal(jobs[int(j)].wait(), expect[int(j)]):
+                        errors.append((seed, int(j)))
+        except Exception as e:      # surfaced in the main thread
+            errors.append((seed, repr(e)))
+
+    th = [threading.Thread(target=run, args=(s,)) for s in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors[:3]
+
+
 def test_run_time_compilation_path_compiles_without_a_device():
     """hiprtc + the device headers embedded in the library accept the emitted program form (called and inlined multipliers,
     column loads, uniforms) for both fields -- a header that stops compiling under hiprtc would otherwise only show up as a
