@@ -182,19 +182,19 @@ def point_lincomb(curve, acc, points, scalars, repr=L.REPR_MONT):
 class PendingPoint:
     """Result of point_lincomb_async: .wait() -> the (8,) affine point (blocks until the host workers are done)."""
 
-    def __init__(self, job, out):
-        self._job, self._out = job, out
+    def __init__(self, job, out, lib):
+        self._job, self._out, self._lib = job, out, lib      # the job lives in the library instance that accepted it
 
     def wait(self):
         if self._job is not None:
-            L.check(L.lib().srs_job_wait(self._job))
+            L.check(self._lib.srs_job_wait(self._job))
             self._job = None
         return self._out
 
     def __del__(self):       # never leave a job writing into freed memory
         try:
             if self._job is not None:
-                L.lib().srs_job_wait(self._job)
+                self._lib.srs_job_wait(self._job)
         except Exception:
             pass
 
@@ -207,9 +207,10 @@ def point_lincomb_async(curve, acc, points, scalars, repr=L.REPR_MONT):
     a = None if acc is None else np.ascontiguousarray(acc, dtype=np.uint64).reshape(8)
     out = np.zeros(8, dtype=np.uint64)
     job = C.c_uint64()
-    L.check(L.lib().srs_point_lincomb_async(curve, None if a is None else a.ctypes.data, pts.ctypes.data, sc.ctypes.data,
-                                            pts.shape[0], repr, out.ctypes.data, C.byref(job)))
-    return PendingPoint(job.value, out)
+    lib = L.lib()
+    L.check(lib.srs_point_lincomb_async(curve, None if a is None else a.ctypes.data, pts.ctypes.data, sc.ctypes.data,
+                                        pts.shape[0], repr, out.ctypes.data, C.byref(job)))
+    return PendingPoint(job.value, out, lib)
 
 
 def point_mul(curve, scalar, p, repr=L.REPR_MONT):
