@@ -324,7 +324,18 @@ int srs_ck_get_bases(const srs_ck *ck, srs_affine *out) {
     int rc = ensure_device();
     if (rc) return rc;
     return guarded([&]() -> int {
-        if (ck->key.len) SRS_HIP_CHECK(hipMemcpy(out, ck->key.table, ck->key.len * sizeof(affine_t), hipMemcpyDeviceToHost));
+        if (ck->key.len) {       // the table lives in the multiplier's internal Montgomery form: convert window 0 back
+            affine_t *tmp = nullptr;
+            SRS_HIP_CHECK(hipMalloc((void **)&tmp, ck->key.len * sizeof(affine_t)));
+            try {
+                msm::read_bases(ck->key, tmp, nullptr);
+                SRS_HIP_CHECK(hipMemcpy(out, tmp, ck->key.len * sizeof(affine_t), hipMemcpyDeviceToHost));
+            } catch (...) {
+                (void)hipFree(tmp);
+                throw;
+            }
+            (void)hipFree(tmp);
+        }
         return SRS_OK;
     });
 }

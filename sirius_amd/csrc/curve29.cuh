@@ -1,0 +1,167 @@
+// curve29.cuh -- the mixed addition of the MSM bucket accumulation on the 9 x 29-bit limb form (field29.cuh).
+//
+// Same formulas as Ec<C>::madd (curve.cuh; EFD shortw/xyzz madd-2008-s, mdbl-2008-s-1), same completeness (identity
+// operands, Q = +-acc), exact arithmetic -> the same group element.  Coordinates are in R' = 2^261 Montgomery form and
+// are kept LAZILY: a product returns a value < 2P, sums and differences are small multiples of P above the canonical
+// value and are not reduced.  The bound of every intermediate is stated beside it; the multiplier needs
+// A * B < 2^261 * P (> 165 P^2), one operand with limbs < 2^29 and the other < 2^31 (or both < 2^30).
+// "norm" = limbs < 2^29 (after Fp29::normalize or out of a product).
+#pragma once
+#include "curve.cuh"
+#include "field29.cuh"
+
+namespace srs {
+
+struct aff29_t {
+    f29_t x, y;            // norm, < P (table entries); identity = (0, 0) exactly
+};
+struct xyzz29_t {
+    f29_t x, y, zz, zzz;   // x < 9P norm; y < 5P, limbs < 2^31; zz, zzz < 2P norm; identity: zz == 0 exactly
+};
+
+template <class C>
+struct Ec29 {
+    using P = typename C::F::Params;
+    using F = Fp29<P>;
+
+    // 2^261 mod p (the Montgomery one of this form), limb i -- folded at compile time
+    SRS_HD static constexpr uint32_t one_limb(int i) {
+        uint32_t w[8] = {P::r(0), P::r(1), P::r(2), P::r(3), P::r(4), P::r(5), P::r(6), P::r(7)};   // 2^256 mod p
+        for (int d = 0; d < 5; ++d) {
+            uint32_t c = 0;
+            for (int j = 0; j < 8; ++j) {                       // w <- 2 w   (w < p < 2^254: no carry out)
+                uint32_t n = (w[j] << 1) | c;
+                c = w[j] >> 31;
+                w[j] = n;
+            }
+            uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t borrow = 0;
+            for (int j = 0; j < 8; ++j) {                       // t <- w - p
+                uint64_t x = (uint64_t)w[j] - P::p(j) - borrow;
+                t[j] = (uint32_t)x;
+                borrow = (uint32_t)(x >> 32) & 1u;
+            }
+            if (!borrow)
+                for (int j = 0; j < 8; ++j) w[j] = t[j];
+        }
+        const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)w[wi] | (wi + 1 < 8 ? (uint64_t)w[wi + 1] << 32 : 0);
+        uint32_t limb = (uint32_t)(two >> sh);
+        return i < 8 ? (limb & F::MASK) : limb;
+    }
+    // 2^256 mod p as a plain integer in limbs: product with it takes R'-form back to the ABI's 2^256 form
+    SRS_HD static constexpr uint32_t r256_limb(int i) {
+        const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)P::r(wi) | (wi + 1 < 8 ? (uint64_t)P::r(wi + 1) << 32 : 0);
+        uint32_t limb = (uint32_t)(two >> sh);
+        return i < 8 ? (limb & F::MASK) : limb;
+    }
+    SRS_HD static f29_t one() {
+        f29_t o;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o.v[i] = one_limb(i);
+        return o;
+    }
+
+    SRS_HD static xyzz29_t identity() {
+        xyzz29_t o;
+        o.x = F::zero();
+        o.y = F::zero();
+        o.zz = F::zero();
+        o.zzz = F::zero();
+        return o;
+    }
+    SRS_HD static bool is_identity(const xyzz29_t &a) { return F::is_zero_exact(a.zz); }
+    SRS_HD static bool is_identity(const aff29_t &q) { return F::is_zero_exact(q.x) && F::is_zero_exact(q.y); }
+
+    // table entry (8 x u32, R'-form, canonical) -> registers; negate: -Q  (y -> P - y; the identity stays (0, 0))
+    SRS_HD static aff29_t load(const affine_t &q, bool negate) {
+        aff29_t o;
+        o.x = F::unpack(q.x);
+        f29_t y = F::unpack(q.y);
+        f29_t ny = F::normalize(F::template neg_lazy<1, 0>(y));       // P - y  (top limb may pass through -1: wraps back)
+        o.y = F::select(negate && !F::is_zero_exact(y), ny, y);
+        return o;
+    }
+
+    // 2 Q for affine, non-identity Q (mdbl-2008-s-1)
+    SRS_HD static xyzz29_t dbl_affine(const aff29_t &q) {
+        xyzz29_t o;
+        f29_t u = F::add_lazy(q.y, q.y);                                        // 2y < 2P, limbs < 2^30
+        f29_t v = F::sqr(u);                                                    // < 2P norm
+        f29_t w = F::mul(u, v);                                                 // < 2P norm
+        f29_t s = F::mul(q.x, v);                                               // < 2P norm
+        f29_t xx = F::sqr(q.x);                                                 // < 2P norm
+        f29_t m = F::normalize(F::add_lazy(F::add_lazy(xx, xx), xx));           // 3 xx < 6P norm
+        f29_t mm = F::sqr(m);                                                   // 36 P^2: < 2P norm
+        f29_t x3 = F::normalize(F::template sub_lazy<5, 1>(mm, F::add_lazy(s, s)));   // mm - 2s + 5P in (P, 7P) norm
+        f29_t t = F::template sub_lazy<8, 0>(s, x3);                            // s - x3 + 8P in (P, 10P), limbs < 2^31
+        f29_t m1 = F::mul(t, m);                                                // 60 P^2
+        f29_t m2 = F::mul(w, q.y);
+        o.x = x3;
+        o.y = F::template sub_lazy<3, 0>(m1, m2);                               // (P, 5P), limbs < 2^31
+        o.zz = v;
+        o.zzz = w;
+        return o;
+    }
+
+    // acc + Q (madd-2008-s), complete: acc = O, Q = O, Q = +-acc
+    SRS_HD static xyzz29_t madd(const xyzz29_t &a, const aff29_t &q) {
+        if (is_identity(q)) return a;
+        if (is_identity(a)) {
+            xyzz29_t o;
+            o.x = q.x;
+            o.y = q.y;
+            o.zz = one();
+            o.zzz = o.zz;
+            return o;
+        }
+        f29_t u2 = F::mul(a.zz, q.x);                                           // < 2P norm
+        f29_t s2 = F::mul(a.zzz, q.y);                                          // < 2P norm
+        f29_t p = F::normalize(F::template sub_lazy<10, 0>(u2, a.x));           // u2 - X1 + 10P in (P, 12P) norm
+        f29_t r = F::normalize(F::template sub_lazy<6, 2>(s2, a.y));            // s2 - Y1 + 6P  in (P, 8P)  norm
+        f29_t pp = F::sqr(p);                                                   // 144 P^2: < 2P norm
+        f29_t rr = F::sqr(r);                                                   // 64 P^2
+        if (F::is_zero_mod(pp)) {                                               // P == 0: same x
+            if (F::is_zero_mod(rr)) return dbl_affine(q);
+            return identity();
+        }
+        f29_t ppp = F::mul(p, pp);                                              // 24 P^2
+        f29_t qv = F::mul(a.x, pp);                                             // 18 P^2
+        xyzz29_t o;
+        f29_t sub = F::add_lazy(ppp, F::add_lazy(qv, qv));                      // ppp + 2 qv < 6P, limbs < 3 * 2^29
+        o.x = F::normalize(F::template sub_lazy<7, 2>(rr, sub));                // (P, 9P) norm
+        f29_t t = F::template sub_lazy<10, 0>(qv, o.x);                         // qv - X3 + 10P in (P, 12P), limbs < 2^31
+        f29_t m1 = F::mul(t, r);                                                // 96 P^2
+        f29_t m2 = F::mul(a.y, ppp);                                            // 10 P^2
+        o.y = F::template sub_lazy<3, 0>(m1, m2);                               // (P, 5P), limbs < 2^31
+        o.zz = F::mul(a.zz, pp);
+        o.zzz = F::mul(a.zzz, ppp);
+        return o;
+    }
+
+    // R'-form lazy coordinates -> the ABI's canonical 2^256-form point (one product per coordinate)
+    SRS_HD static xyzz_t to_xyzz(const xyzz29_t &a) {
+        f29_t c;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c.v[i] = r256_limb(i);
+        xyzz_t o;
+        o.x = F::to_canonical_fe(F::mul(a.x, c));
+        o.y = F::to_canonical_fe(F::mul(a.y, c));
+        o.zz = F::to_canonical_fe(F::mul(a.zz, c));
+        o.zzz = F::to_canonical_fe(F::mul(a.zzz, c));
+        return o;
+    }
+    // canonical 2^256-form affine point -> canonical R'-form (table build): x * 2^261 = Fp::mul(x~, 2^261 mod p)
+    SRS_HD static affine_t table_form(const affine_t &q) {
+        using G = typename C::F;
+        fe_t c = G::one();
+        for (int d = 0; d < 5; ++d) c = G::dbl(c);            // (2^256 mod p) * 32 mod p = 2^261 mod p, as an integer
+        affine_t o;
+        o.x = G::mul(q.x, c);
+        o.y = G::mul(q.y, c);
+        return o;
+    }
+};
+
+}  // namespace srs

@@ -69,6 +69,7 @@ struct FqP {
 
 template <class P>
 struct Fp {
+    using Params = P;
     SRS_HD static fe_t zero() {
         fe_t o;
 #pragma unroll

@@ -34,7 +34,8 @@ constexpr uint32_t NORM_G = 16;           // points per inversion in the key-exp
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
 static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
 
-// Device-resident commitment key: window-expanded table T[w * len + i] = 2^(16 w) P_i.
+// Device-resident commitment key: window-expanded table T[w * len + i] = 2^(16 w) P_i, coordinates in the
+// R' = 2^261 Montgomery form of the 9 x 29-bit multiplier (field29.cuh) once build_table has run.
 struct Key {
     int curve = 0;            // 0 bn256 G1, 1 grumpkin
     size_t len = 0;           // number of bases held by THIS rank
@@ -49,6 +50,9 @@ struct Key {
 void build_table(Key &k, hipStream_t stream);
 // fills table[0 .. len) with the synthetic key (see k_gen_bases)
 void generate_bases(Key &k, uint64_t seed, hipStream_t stream);
+
+// table[0 .. len) back in the ABI's 2^256 Montgomery form (the table itself is kept in the form of field29.cuh)
+void read_bases(const Key &k, affine_t *out_dev, hipStream_t stream);
 
 // number of bases in table[0 .. len) that are not on the curve (identity counts as on-curve)
 size_t count_off_curve(const Key &k, hipStream_t stream);

@@ -26,6 +26,7 @@
 // Batched entry: the d-1 cross-term commitments share one base prefix and run
 // as one set of launches (grid.y / grid.z = batch index).
 #include "msm.h"
+#include "curve29.cuh"
 #include "prof.h"
 
 #include <algorithm>
@@ -105,6 +106,32 @@ __global__ void k_normalize(const xyzz_t *__restrict__ in, affine_t *__restrict_
     }
 }
 
+// The finished table is kept in the R' = 2^261 Montgomery form of the 9 x 29-bit multiplier that k_accum0 runs on
+// (field29.cuh): one pass over all NWIN * len entries when the key is created.  k_table_unform is the inverse, used by
+// the few readers of the plain bases (srs_ck_get_bases / save_file, the on-curve count).
+template <class C>
+__global__ void k_table_form(affine_t *__restrict__ t, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    t[i] = Ec29<C>::table_form(t[i]);
+}
+template <class C>
+__device__ __forceinline__ affine_t table_unform(const affine_t &q) {
+    using G = typename C::F;
+    fe_t c = G::one();
+    for (int d = 0; d < 5; ++d) c = G::halve(c);          // 2^256 / 32 = 2^251 mod p as an integer: x 2^261 * 2^251 / 2^256 = x 2^256
+    affine_t o;
+    o.x = G::mul(q.x, c);
+    o.y = G::mul(q.y, c);
+    return o;
+}
+template <class C>
+__global__ void k_table_unform(const affine_t *__restrict__ t, affine_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = table_unform<C>(t[i]);
+}
+
 // synthetic key: P_i = [h(seed, g)] G with g the GLOBAL index of local base i  (NOT the reference's
 // SHAKE256 + hash_to_curve key, src/commitment.rs:55-79 -- hash_to_curve is [3P]; any valid points
 // with no known small relation serve parity and timing)
@@ -148,7 +175,7 @@ template <class C>
 __global__ void k_on_curve(const affine_t *__restrict__ pts, uint32_t n, uint32_t *__restrict__ bad) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (!Ec<C>::is_on_curve(pts[i])) atomicAdd(bad, 1u);
+    if (!Ec<C>::is_on_curve(table_unform<C>(pts[i]))) atomicAdd(bad, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -528,7 +555,6 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum0(const uint32_t *__restrict__ sorted, size_t sorted_stride, const uint32_t *__restrict__ plan,
              size_t plan_stride, const affine_t *__restrict__ table, xyzz_t *__restrict__ parts,
              size_t parts_stride, uint32_t l0) {
-    using F = typename C::F;
     uint32_t m = blockIdx.y;
     const uint32_t *off = plan + (size_t)m * plan_stride;
     const uint32_t *tp = off + (NBUCKET + 1);
@@ -540,7 +566,9 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     uint32_t e = off[b + 1];
     if (e > s + l0) e = s + l0;
     const uint32_t *src = sorted + (size_t)m * sorted_stride;
-    xyzz_t acc = Ec<C>::identity();
+    // the additions run on the 9 x 29-bit limb form (curve29.cuh); the table is stored in its Montgomery form
+    using E29 = Ec29<C>;
+    xyzz29_t acc = E29::identity();
     if (s < e) {
         uint32_t v = src[s];
         affine_t p = table[v & 0x7FFFFFFFu];
@@ -551,13 +579,12 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
                 vn = src[j + 1];
                 pn = table[vn & 0x7FFFFFFFu];
             }
-            if (v >> 31) p.y = F::neg(p.y);
-            acc = Ec<C>::madd(acc, p);
+            acc = E29::madd(acc, E29::load(p, (v >> 31) != 0));
             v = vn;
             p = pn;
         }
     }
-    parts[(size_t)m * parts_stride + t] = acc;
+    parts[(size_t)m * parts_stride + t] = E29::to_xyzz(acc);
 }
 
 // level >= 1: (bucket, part) over the previous level's parts, <= L1 full adds each.
@@ -782,6 +809,8 @@ static void build_table_t(Key &k, hipStream_t stream) {
         SRS_LAUNCH((k_table_step<C>), (ceil_div(n, 256)), (256), 0, stream, prev, tmp, n);
         SRS_LAUNCH((k_normalize<C>), (ceil_div(ceil_div(n, NORM_G), 128)), (128), 0, stream, (const xyzz_t *)tmp, cur, n);
     }
+    const size_t total = (size_t)n * NWIN;
+    SRS_LAUNCH((k_table_form<C>), (ceil_div(total, 256)), (256), 0, stream, k.table, total);
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
     SRS_HIP_CHECK(hipFree(tmp));
 }
@@ -813,6 +842,12 @@ size_t count_off_curve(const Key &k, hipStream_t stream) {
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
     (void)hipFree(d_bad);
     return bad;
+}
+
+void read_bases(const Key &k, affine_t *out_dev, hipStream_t stream) {
+    if (k.len == 0) return;
+    if (k.curve == 0) SRS_LAUNCH((k_table_unform<Bn256>), (ceil_div(k.len, 256)), (256), 0, stream, (const affine_t *)k.table, out_dev, k.len);
+    else SRS_LAUNCH((k_table_unform<Grumpkin>), (ceil_div(k.len, 256)), (256), 0, stream, (const affine_t *)k.table, out_dev, k.len);
 }
 
 void build_table(Key &k, hipStream_t stream) {

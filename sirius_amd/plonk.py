@@ -145,7 +145,8 @@ class PlonkStructure:
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
         hs, gs = [], []
         for l, t, m in zip(ls, ts, ms):
-            (al, space, n, _), (at, s2, n2, _), (am, s3, n3, _) = _buf(l, 4), _buf(t, 4), _buf(m, 4)
+            # every keepalive stays bound until the C call below has returned (a converted temporary must outlive it)
+            (al, space, n, keep_l), (at, s2, n2, keep_t), (am, s3, n3, keep_m) = _buf(l, 4), _buf(t, 4), _buf(m, 4)
             assert space == s2 == s3 and n == n2 == n3
             h, g = _alloc_like(l, n), _alloc_like(l, n)
             L.check(L.lib().srs_lookup_coeff_2(self.field, al, at, am, r.ctypes.data, n, space, _stream(),
@@ -169,8 +170,8 @@ class PlonkStructure:
 def batch_invert_assigned(field, numerators, denominators, has_denominator=None):
     """`util::batch_invert_assigned` (src/util/mod.rs:119-153) for one flattened column of `Assigned<F>` cells:
     numerators[i] * denominators[i]^-1 where has_denominator[i] (all cells when None), numerators[i] otherwise; 1/0 := 0."""
-    an, space, n, _ = _buf(numerators, 4)
-    ad, s2, n2, _ = _buf(denominators, 4)
+    an, space, n, keep_n = _buf(numerators, 4)        # distinct names: both conversions must outlive the C call
+    ad, s2, n2, keep_d = _buf(denominators, 4)
     assert space == s2 and n == n2
     out = _alloc_like(numerators, n)
     hp, keep = None, None
@@ -298,14 +299,14 @@ class RelaxedPlonkWitness:
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
         newW = []
         for w1, w2 in zip(self.W, W2):
-            a1, space, n, _ = _buf(w1, 4)
-            a2, space2, n2, _ = _buf(w2, 4)
+            a1, space, n, keep1 = _buf(w1, 4)             # distinct names: both conversions must outlive the C call
+            a2, space2, n2, keep2 = _buf(w2, 4)
             assert space == space2 and n == n2
             out = _alloc_like(w1, n)
             L.check(L.lib().srs_fold_witness(self.field, out.data_ptr() if _is_torch(out) else out.ctypes.data, a1, a2,
                                              r.ctypes.data, n, space, _stream()))
             newW.append(out)
-        ae, space, n, _ = _buf(self.E, 4)
+        ae, space, n, keep_e = _buf(self.E, 4)
         tb = [_buf(t, 4) for t in cross_terms]
         assert all(b[1] == space and b[2] == n for b in tb)
         tp = (C.c_void_p * max(len(tb), 1))(*[b[0] for b in tb])
