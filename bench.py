@@ -1,28 +1,33 @@
 #!/usr/bin/env python
-"""bench.py -- IVC fold-steps/s of the Sangria prover hot path on synthetic Poseidon-shaped traces.
+"""bench.py -- IVC fold-steps/s of the folding-prover hot path on synthetic Poseidon-shaped traces (MI355X).
 
-One "step" = the hot-path work of one `SangriaIVC::fold_step`
-(reference src/ivc/sangria/incrementally_verifiable_computation.rs:429-635) at the
-`sangria_poseidon` bench shapes (benches/sangria_poseidon.rs:28-36: k = 17, key 2^21 per curve):
-  A. VanillaFS::prove on the secondary (grumpkin) circuit : 5 cross terms x 2^17 rows evaluated,
-     committed (batched MSM), instance fold (host scalar-muls), witness + error-vector fold
-  B. primary witness commit   : MSM of 12 * 2^17 scalars on bn256
-  C. VanillaFS::prove on the primary (bn256) circuit      : 6 cross terms x 2^17, commit, folds
-  D. secondary witness commit : MSM of 7 * 2^17 scalars on grumpkin
-Everything the reference keeps on the CPU by construction (halo2 witness synthesis, Poseidon
-random oracle, circuit bookkeeping) is outside the path and outside the step; the Fiat-Shamir
-challenge r is a seeded constant.  Inputs (witnesses, fixed columns, expanded keys) are resident
-in HBM before the timed region; the accumulator produced by step i is the input of step i+1.
+Default workload = BASELINE.json configs[2], the north-star target: one `CyclefoldIVC::next`
+(reference src/ivc/cyclefold/incrementally_verifiable_computation/mod.rs:210-335; bench benches/cyclefold_poseidon.rs:27-34,116-126)
+at k = 20 with a 2^24 commitment key.  One "step" = the hot-path work of one `next`, in the reference's order:
+  A. ProtoGalaxy::prove on the primary (bn256) circuit, src/nifs/protogalaxy/mod.rs:400-481:
+       compute_F (2^21 leaves), compute_G (accumulator + incoming trace), compute_K_from_G (256 points), calculate_e,
+       fold_instance (host scalar-muls, off the critical path), fold_witness (12 * 2^20)
+  B. fold_support_circuit, :404-473 -- the support circuit (grumpkin, k = 15, support_circuit/tiny_gate.rs:56-82):
+       its witness arrives from the host and is committed (3 * 2^15 scalars), then SangriaFS::prove: 2 cross terms evaluated and
+       committed (batched MSM), witness and error-vector folds
+  C. the new primary witness arrives FROM THE HOST (halo2 synthesis is CPU work, src/table/circuit_runner.rs:71-107) and is
+       committed: 12 * 2^20 scalars -- uploaded inside the timed region, in chunks that overlap the MSM of the
+       chunks already in HBM (srs_commit_upload); the device copy is the incoming trace of the next step
+Accumulators, fixed columns and the expanded keys stay resident in HBM; challenges are seeded constants (the Poseidon random
+oracle is host code in the reference; `--ro-challenge` derives them with the library's off-circuit sponge instead).
+`--leaf-rows compat` evaluates every ProtoGalaxy leaf at row 0 as the reference does (src/plonk/mod.rs:714, SURVEY.md Q1: less
+memory traffic); the default `true` reads the leaf's own row -- the heavier, intended computation.
 
-Multi-GPU (torchrun, one rank per GPU): every MSM is sharded block-cyclically over the ranks
-(rank-local window tables), partial commitments (64 B) are all-gathered over RCCL and summed on
-the host; cross-term evaluation and the folds are replicated.  One IVC chain is inherently
-sequential, so this is STRONG scaling of a single fold step.
+`--config sangria` runs BASELINE configs[1] (one SangriaIVC::fold_step at k = 17) as the main line instead; by default it is
+reported as a secondary object next to the 2^24 MSM / NTT microbenchmark (configs[4]), each with its own roofline.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (MSM bucket accumulation):
-achieved = 96 B x scalars per launch / measured launch time (HIP events on the launch stream).
-`cpu_baseline` times the CPU oracle (oracle/, a port of the reference algorithms -- the Rust
-reference itself cannot be built here) on the same workload, rank 0 / N = 1 only.
+Multi-GPU (torchrun, one rank per GPU): every MSM is sharded block-cyclically over the ranks, the 64-byte partial commitments
+are all-gathered over RCCL and summed on the host; the row programs are replicated (support-circuit cross terms row-sharded).
+One IVC chain is sequential, so this is STRONG scaling of a single step.
+
+Prints ONE JSON line (rank 0).  `roofline`: dominant kernel = MSM bucket accumulation; achieved = 96 B x scalars / launch time
+(HIP events on the launch stream, inside the library).  `cpu_baseline`: the CPU oracle (oracle/, a C port of the reference's
+algorithms -- the Rust reference cannot be built in this image) on ONE step of the same workload, rank 0 / N = 1 only.
 """
 import argparse
 import json
@@ -36,126 +41,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-
-MADD_PEAK_G = 10.6
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 MSM_BYTES_PER_SCALAR = 96.0    # 64 B base + 32 B scalar, each read once
+NTT_BYTES_PER_ELEMENT = 64.0   # read once + write once
+# ALU side note: the bucket accumulation is integer-multiplier bound.  One mixed addition = 8 products + 2 squares on the
+# 9 x 29-bit limb form = 8 * 171 + 2 * 135 multiplier instructions (v_mad_u64_u32 / v_mul_lo_u32); the chip issues
+# 31.2 T v_mad_u64_u32 per second (profiles/r02_ubench29_gfx950.txt: 50.7 lane-ops/clk/CU x 256 CUs x 2.4 GHz).
+MAD_ISSUE_PER_S = 31.16e12
+MADD_MULT_INSNS = 8 * 171 + 2 * 135
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--k", type=int, default=17, help="log2 rows (BASELINE configs[1]: 17)")
-    ap.add_argument("--log-key", type=int, default=21, help="log2 commitment-key length per curve")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cyclefold", choices=["cyclefold", "sangria"])
+    ap.add_argument("--k", type=int, default=0, help="log2 rows (default: 20 for cyclefold, 17 for sangria)")
+    ap.add_argument("--log-key", type=int, default=0, help="log2 commitment-key length (default: 24 / 21)")
+    ap.add_argument("--leaf-rows", default="true", choices=["true", "compat"],
+                    help="ProtoGalaxy leaf row: its own row (default) or row 0 like the reference (SURVEY.md Q1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (k=17 Sangria step, 2^24 MSM / NTT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ro-challenge", action="store_true",
-                    help="derive the folding challenge r of every prove from the off-circuit Poseidon oracle over the commitments "
-                         "(T=5, RATE=4, R_F=R_P=10 as benches/sangria_poseidon.rs:80-116) instead of a seeded constant")
+                    help="derive the challenges with the off-circuit Poseidon oracle (host code) instead of seeded constants")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--emu", action="store_true",
+                    help="harness self-test without a GPU: loads the CPU logic emulator (tests/emu, test infrastructure) and keeps "
+                         "'device' tensors in host memory; use a tiny --k.  The numbers it prints are meaningless")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU exchange; lets 2 ranks share one GPU in tests)")
     return ap.parse_args()
 
 
-class Side:
-    """One circuit of the cycle: structure + key + accumulator + incoming instance, all in HBM."""
-
-    def __init__(self, which, k, log_key, rank, world, dev):
-        import torch
-        import sirius_amd as S
-        from workloads import make_structure_inputs
-        w = make_structure_inputs(which, k, seed=0x5349524955530000 + (2 if which == "primary" else 3))
-        self.w = w
-        self.field, self.curve, self.rows = w["field"], w["curve"], w["rows"]
-        self.S = S.PlonkStructure(self.field, k, [], w["fixed"], w["num_advice"], w["gates"])
-        if world > 1:      # cross terms only on the rows of this rank's key stripes (the rows its partial MSMs read)
-            self.S.set_shard(rank, world)
-        assert (w["num_advice"] * self.rows) <= (1 << log_key)
-        self.ck = S.CommitmentKey.setup_synthetic(self.curve, 1 << log_key, seed=42 + self.curve, rank=rank, world=world)
-        up = lambda a: torch.from_numpy(a.view(np.int64)).to(dev)
-        self.accW, self.accE = up(w["W1"]), up(w["E"])          # running accumulator (RelaxedPlonkWitness)
-        self.inW = up(w["W2"])                                   # incoming witness (PlonkWitness.W[0])
-        self.u1c, self.u1u, self.u2c, self.r = w["u1_challenges"], w["u1_u"], w["u2_challenges"], w["r"]
-        self.d = self.S.num_cross_terms
-        # r^1..r^d for the E-commitment fold (accumulator.rs:240-244); host big-int, once
-        from sirius_amd.field import MODULUS, from_mont, ints_to_mont
-        sf = 0 if self.curve == 0 else 1
-        rv = from_mont(sf, self.r)
-        self.rpows = ints_to_mont(sf, [pow(rv, i + 1, MODULUS[sf]) for i in range(self.d)])
-        self.accCW = np.zeros(8, dtype=np.uint64)
-        self.accCE = np.zeros(8, dtype=np.uint64)
-        self.pending = None      # instance fold of the previous step, still running on the host workers
-        # random oracle over the base field of this side's curve (its points are what gets absorbed)
-        self.ro = S.PoseidonHash(1 if self.curve == 0 else 0, 5, 4, 10, 10)
-
-
-COUNT_NONZERO = False
-RO_CHALLENGE = False
-
-
-def combine(S, side, partial, dist, world, dev):
-    """all-gather the per-rank partial commitments (RCCL) and sum them on the host."""
-    if world == 1:
-        return partial
-    from sirius_amd.distributed import all_gather_commitments
-    return all_gather_commitments(side.curve, partial, device=dev if dist.get_backend() == "nccl" else None)
-
-
-def settle(side):
-    """Joins the instance fold of the previous step (its result is this step's accumulator instance)."""
-    if side.pending is not None:
-        side.accCE, side.accCW = side.pending[0].wait(), side.pending[1].wait()
-        side.pending = None
-
-
-def prove(S, side, dist, world, dev):
-    """VanillaFS::prove hot path (src/nifs/sangria/mod.rs:253-277)."""
-    settle(side)
-    terms, commits = S.VanillaFS.commit_cross_terms(side.ck, side.S, side.u1c, side.u1u, side.accW, side.u2c, side.inW)
-    if COUNT_NONZERO:     # untimed warm-up only: mixed additions issued = 16 windows x non-zero scalars (ALU roofline)
-        side.nz_terms = sum(int((t != 0).any(dim=1).sum().item()) for t in terms)
-    commits = combine(S, side, commits, dist, world, dev)
-    if RO_CHALLENGE:      # VanillaFS::generate_challenge (src/nifs/sangria/mod.rs:162-179): absorb U1, U2, the cross-term commits
-        from sirius_amd.field import MODULUS, from_mont, ints_to_mont
-        ro = side.ro.reset()
-        for pt in (side.accCW, side.accCE, side.inC):
-            ro.absorb_point(side.curve, pt)
-        for pt in commits:
-            ro.absorb_point(side.curve, pt)
-        sf = 0 if side.curve == 0 else 1
-        side.r = ro.squeeze(128, sf)
-        rv = from_mont(sf, side.r)
-        side.rpows = ints_to_mont(sf, [pow(rv, i + 1, MODULUS[sf]) for i in range(side.d)])
-    # generate_challenge: Poseidon RO on the CPU in the reference -> seeded constant r here.
-    # Both folds depend only on r: the instance fold (host scalar-muls, accumulator.rs:201-264:
-    # W' = W1 + r*W2 ; E' = E + sum r^k T_k) runs on the host while the GPU folds the witness.
-    # The witness fold is stream-ordered (device-resident operands): both kernels are enqueued first; the instance fold (d + 1
-    # host scalar multiplications) is handed to the library's host workers and joined when this side's accumulator instance is
-    # next needed (settle) -- nothing on the device waits for it, so the next commitment is enqueued meanwhile.
-    acc = S.RelaxedPlonkWitness(side.field, [side.accW], side.accE).fold([side.inW], terms, side.r)
-    side.accW, side.accE = acc.W[0], acc.E
-    side.pending = (S.point_lincomb_async(side.curve, side.accCE, commits, side.rpows),
-                    S.point_lincomb_async(side.curve, side.accCW, side.inC.reshape(1, 8), side.r.reshape(1, 4)))
-    return commits
-
-
-def witness_commit(S, side, dist, world, dev):
-    """run_sps_protocol_0: ck.commit(W1)  (src/plonk/mod.rs:441-447)."""
-    side.inC = combine(S, side, side.ck.commit(side.inW), dist, world, dev)
-    return side.inC
-
-
-def fold_step(S, pri, sec, dist, world, dev):
-    prove(S, sec, dist, world, dev)          # A
-    witness_commit(S, pri, dist, world, dev)  # B
-    prove(S, pri, dist, world, dev)          # C
-    witness_commit(S, sec, dist, world, dev)  # D
-
-
 def host_cpus():
-    """CPUs this process may actually use: min(affinity, cgroup v2 quota).  On the GPU box os.cpu_count() is 256 but the
-    container's cpu.max is 16 CPUs -- 256 OpenMP threads there are throttled to a crawl (tools/cpu_probe.py)."""
+    """CPUs this process may actually use: min(affinity, cgroup v2 quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -166,168 +85,520 @@ def host_cpus():
     return n
 
 
-def cpu_baseline(args, pri, sec):
-    """The CPU oracle (port of the reference algorithms) on ONE fold step of the same workload."""
+class Dist:
+    """world / rank / exchange of partial commitments (RCCL all-gather of raw bytes + host sum)."""
+
+    def __init__(self, args):
+        import torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.emu = args.emu
+        if self.emu:
+            self.dev = torch.device("cpu")
+        else:
+            local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            self.dev = torch.device("cuda", local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.dist_backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(backend=args.dist_backend)
+            self.dist = dist
+        assert self.world == args.gpus or self.world == 1, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
+
+    def combine(self, curve, partial):
+        if self.world == 1:
+            return partial
+        from sirius_amd.distributed import all_gather_commitments
+        return all_gather_commitments(curve, partial, device=self.dev if self.dist.get_backend() == "nccl" else None)
+
+    def barrier(self):
+        import torch
+        if self.world > 1:
+            self.dist.barrier()
+        if not self.emu:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        import torch
+        if self.world == 1:
+            return dt
+        red = self.dev if self.dist.get_backend() == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=red)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+
+def up(D, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(D.dev)
+
+
+def pinned_copy(S, a):
+    hb = S.HostBuffer(a.shape[0])
+    hb.array[:] = a
+    return hb
+
+
+# ------------------------------------------------------------------------------------------ Sangria side (configs[1], support circuit)
+class SangriaSide:
+    """One Sangria-folded circuit: structure + key + running accumulator (W, E) in HBM + the incoming witness on the HOST."""
+
+    def __init__(self, S, D, w, log_key, tag):
+        self.w, self.tag = w, tag
+        self.field, self.curve, self.rows = w["field"], w["curve"], w["rows"]
+        self.S = S.PlonkStructure(self.field, w["k"], w.get("selectors", []), w["fixed"], w["num_advice"], w["gates"])
+        if D.world > 1:
+            self.S.set_shard(D.rank, D.world)
+        assert w["num_advice"] * self.rows <= (1 << log_key)
+        self.ck = S.CommitmentKey.setup_synthetic(self.curve, 1 << log_key, seed=42 + self.curve, rank=D.rank, world=D.world)
+        self.accW, self.accE = up(D, w["W1"]), up(D, w["E"])
+        self.host_W = pinned_copy(S, w["W2"])                    # the incoming witness as the CPU synthesis leaves it
+        self.inW = up(D, w["W2"])                                # its device copy (rewritten by every witness commit)
+        self.u1c, self.u1u, self.u2c, self.r = w["u1_challenges"], w["u1_u"], w["u2_challenges"], w["r"]
+        self.d = self.S.num_cross_terms
+        from sirius_amd.field import MODULUS, from_mont, ints_to_mont
+        self.sf = 0 if self.curve == 0 else 1
+        rv = from_mont(self.sf, self.r)
+        self.rpows = ints_to_mont(self.sf, [pow(rv, i + 1, MODULUS[self.sf]) for i in range(self.d)])
+        self.accCW = np.zeros(8, dtype=np.uint64)
+        self.accCE = np.zeros(8, dtype=np.uint64)
+        self.inC = np.zeros(8, dtype=np.uint64)
+        self.pending = None
+        self.ro = S.PoseidonHash(1 if self.curve == 0 else 0, 5, 4, 10, 10)
+        self.nz_terms = 0
+
+    def settle(self):
+        if self.pending is not None:
+            self.accCE, self.accCW = self.pending[0].wait(), self.pending[1].wait()
+            self.pending = None
+
+    def witness_commit(self, S, D, from_host):
+        """run_sps_protocol_0: ck.commit(W1) (src/plonk/mod.rs:441-447).  from_host: the witness comes up from host memory
+        inside this call (chunked, overlapped with the MSM); otherwise it is already resident."""
+        if from_host:
+            c = self.ck.commit_upload(self.host_W.array, dev_copy=self.inW)
+        else:
+            c = self.ck.commit(self.inW)
+        self.inC = D.combine(self.curve, c)
+
+    def prove(self, S, D, ro_challenge=False, count_nonzero=False):
+        """VanillaFS::prove hot path (src/nifs/sangria/mod.rs:253-277)."""
+        self.settle()
+        terms, commits = S.VanillaFS.commit_cross_terms(self.ck, self.S, self.u1c, self.u1u, self.accW, self.u2c, self.inW)
+        if count_nonzero:
+            self.nz_terms = sum(int((t != 0).any(dim=1).sum().item()) for t in terms)
+        commits = D.combine(self.curve, commits)
+        if ro_challenge:      # VanillaFS::generate_challenge (sangria/mod.rs:162-179)
+            from sirius_amd.field import MODULUS, from_mont, ints_to_mont
+            ro = self.ro.reset()
+            for pt in (self.accCW, self.accCE, self.inC):
+                ro.absorb_point(self.curve, pt)
+            for pt in commits:
+                ro.absorb_point(self.curve, pt)
+            self.r = ro.squeeze(128, self.sf)
+            rv = from_mont(self.sf, self.r)
+            self.rpows = ints_to_mont(self.sf, [pow(rv, i + 1, MODULUS[self.sf]) for i in range(self.d)])
+        acc = S.RelaxedPlonkWitness(self.field, [self.accW], self.accE).fold([self.inW], terms, self.r)
+        self.accW, self.accE = acc.W[0], acc.E
+        self.pending = (S.point_lincomb_async(self.curve, self.accCE, commits, self.rpows),
+                        S.point_lincomb_async(self.curve, self.accCW, self.inC.reshape(1, 8), self.r.reshape(1, 4)))
+
+
+def sangria_step(S, D, pri, sec, from_host, ro=False, count=False):
+    """SangriaIVC::fold_step hot path (src/ivc/sangria/incrementally_verifiable_computation.rs:429-635)."""
+    sec.prove(S, D, ro, count)
+    pri.witness_commit(S, D, from_host)
+    pri.prove(S, D, ro, count)
+    sec.witness_commit(S, D, from_host)
+
+
+# ------------------------------------------------------------------------------------------ ProtoGalaxy side (configs[2])
+class PgPrimary:
+    """The primary (bn256) circuit of CyclefoldIVC: ProtoGalaxy accumulator in HBM, incoming trace in HBM (uploaded by the
+    previous step's witness commit), the next witness on the host."""
+
+    def __init__(self, S, D, k, log_key, compat):
+        from sirius_amd import protogalaxy as PG
+        from sirius_amd.field import FR, ints_to_mont
+        from workloads import make_structure_inputs, trace_like
+        import random
+        self.PG, self.compat = PG, compat
+        w = make_structure_inputs("primary", k, seed=0x5349524955530000 + 3)
+        self.w, self.k, self.rows = w, k, w["rows"]
+        self.S = S.PlonkStructure(0, k, [], w["fixed"], w["num_advice"], w["gates"])
+        self.ctx = PG.PolyContext(self.S, 1)
+        n = w["num_advice"] * self.rows
+        assert n <= (1 << log_key)
+        self.ck = S.CommitmentKey.setup_synthetic(S.CURVE_BN256, 1 << log_key, seed=42, rank=D.rank, world=D.world)
+        self.accW, self.inW = up(D, w["W1"]), up(D, w["W2"])
+        rng = np.random.default_rng(77)
+        self.host_W = [pinned_copy(S, w["W2"]), pinned_copy(S, trace_like(rng, n))]      # two witnesses, alternating
+        rnd = random.Random(3)
+        self.m = lambda v: ints_to_mont(0, list(v))
+        self.FR = FR
+        self.betas_i = [rnd.randrange(FR) for _ in range(self.ctx.betas_count)]
+        self.betas = self.m(self.betas_i)
+        self.chal = [rnd.randrange(FR) for _ in range(3)]            # delta, alpha, gamma: seeded (the RO is host code)
+        self.accC = np.zeros(8, dtype=np.uint64)
+        self.inC = np.zeros(8, dtype=np.uint64)
+        self.pending = None
+        self.ro = S.PoseidonHash(0, 5, 4, 10, 10)
+        self.step_no = 0
+
+    def settle(self):
+        if self.pending is not None:
+            self.accC = self.pending.wait()
+            self.pending = None
+
+    def prove(self, S, D, ro_challenge=False):
+        """ProtoGalaxy::prove (src/nifs/protogalaxy/mod.rs:400-481)."""
+        PG, ctx, m, FR = self.PG, self.ctx, self.m, self.FR
+        self.settle()
+        delta, alpha, gamma = self.chal
+        if ro_challenge:      # Challenges::generate_one (mod.rs:80-133): absorb the accumulator and the incoming instance
+            ro = self.ro.reset()
+            ro.absorb_field(np.concatenate([self.accC.reshape(2, 4), self.inC.reshape(2, 4)]))
+            ro.absorb_field(self.betas)
+            delta = PGint(ro.squeeze(128, 0))
+        poly_F = PG.compute_F(ctx, self.betas, m([delta])[0], self.accW, reference_compat=self.compat)
+        if ro_challenge:
+            alpha = PGint(self.ro.absorb_field(poly_F).squeeze(128, 0))
+        f_alpha = PG.poly_eval(poly_F, m([alpha])[0])
+        bs, d = [], delta                                             # BetaStrokeIter (poly/mod.rs:449-462)
+        for b in self.betas_i:
+            bs.append((b + alpha * d) % FR)
+            d = d * d % FR
+        betas_stroke = m(bs)
+        poly_G = PG.compute_G(ctx, betas_stroke, [self.accW, self.inW], reference_compat=self.compat)
+        poly_K = PG.compute_K_from_G(ctx, poly_G, f_alpha)
+        if ro_challenge:
+            gamma = PGint(self.ro.absorb_field(poly_K).squeeze(128, 0))
+        g = m([gamma])[0]
+        Ls = PG.eval_lagrange_poly_for_cyclic_group(g, ctx.lagrange_domain)
+        self.e = PG.calculate_e(poly_F, poly_K, g, m([alpha])[0], ctx.lagrange_domain)
+        self.accW = PG.fold_witness(0, [self.accW, self.inW], Ls)                        # device, stream-ordered
+        self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), Ls[:2])   # fold_instance
+        self.betas_i, self.betas = bs, betas_stroke
+
+    def witness_commit(self, S, D):
+        """generate_plonk_trace -> run_sps_protocol_1: ck.commit(W1) of the NEW witness, host -> HBM inside the call."""
+        hb = self.host_W[self.step_no & 1]
+        self.step_no += 1
+        self.inC = D.combine(S.CURVE_BN256, self.ck.commit_upload(hb.array, dev_copy=self.inW))
+
+
+def PGint(fe):
+    from sirius_amd.field import from_mont
+    return from_mont(0, fe)
+
+
+def cyclefold_step(S, D, pri, sup, ro=False, count=False):
+    """CyclefoldIVC::next hot path (src/ivc/cyclefold/incrementally_verifiable_computation/mod.rs:210-335)."""
+    pri.prove(S, D, ro)                       # A
+    sup.witness_commit(S, D, True)            # B: support-circuit trace ...
+    sup.prove(S, D, ro, count)                #    ... folded into the support accumulator
+    pri.witness_commit(S, D)                  # C
+
+
+# ------------------------------------------------------------------------------------------ measurement helpers
+def timed(D, fn, steps, after=None):
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    if after:
+        after()
+    D.barrier()
+    return D.max_over_ranks(time.perf_counter() - t0)
+
+
+def msm_roofline(S, units_note, nz_madds=None, world=1):
+    """roofline object of the dominant kernel from the library's HIP-event timers (srs_profile_*)."""
+    acc0 = S.profile_get("msm_accum0") or dict(total_ms=0.0, launches=0, units=0)
+    if not acc0["launches"]:
+        return None
+    sec = acc0["total_ms"] * 1e-3
+    achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / sec / 1e9
+    traffic, src = None, None
+    for name in ("r02_pmc_accum0.json", "r01_pmc_accum0.json"):
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if world == 1:
+                traffic = round(pmc["hbm_bytes_per_scalar"] * acc0["units"] / acc0["launches"])
+                src = f"profiles/{name} (PMC bytes/scalar x scalars per launch)"
+            break
+        except Exception:
+            continue
+    roof = {"bound": "hbm", "kernel": "msm::k_accum0 (bucket accumulation)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
+            "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
+            "scalars_per_launch": round(acc0["units"] / acc0["launches"]), "units_note": units_note,
+            "note": "integer-multiplier bound (256-bit modular products), not HBM bound: see DESIGN.md and the `alu` object"}
+    if nz_madds:
+        rate = nz_madds / sec
+        peak = MAD_ISSUE_PER_S / MADD_MULT_INSNS
+        roof["alu"] = {"unit": "G mixed-add/s", "achieved": round(rate / 1e9, 3), "peak": round(peak / 1e9, 3),
+                       "frac": round(rate / peak, 4),
+                       "peak_source": "instruction issue: 31.2 T v_mad_u64_u32/s (profiles/r02_ubench29_gfx950.txt) / 1638 multiplier "
+                                      "instructions per mixed addition (8 products x 171 + 2 squares x 135)"}
+    return roof
+
+
+def nonzero_rows(t):
+    return int((t != 0).any(dim=1).sum().item())
+
+
+# ------------------------------------------------------------------------------------------ CPU baselines (oracle/)
+def cpu_baseline_sangria(args, pri, sec, k):
     import oracle as O
     from oracle import expr as OE
     quota = host_cpus()
-    threads = args.cpu_threads or min(2 * quota, os.cpu_count() or 1)     # 2 threads per granted CPU measured fastest
+    threads = args.cpu_threads or min(2 * quota, os.cpu_count() or 1)
     t_all = 0.0
     for side in (sec, pri):
         w = side.w
-        gate_T = [5, 3] if side is pri else [5]
-        nfix = w["num_fixed"]
-        og, fo, ao = [], 0, 0
-        for T in gate_T:
-            og.append(OE.main_gate_expression(T, 0, fo, ao, nfix)); fo += 2 * T + 5; ao += T + 2
-        bases = side.ck.bases() if side.ck.world == 1 else None
-        if bases is None:
-            return None
+        bases = side.ck.bases()
         ch = np.concatenate([w["u1_challenges"].reshape(-1, 4), w["u1_u"].reshape(1, 4), w["u2_challenges"].reshape(-1, 4),
                              O.ints_to_mont(side.field, [1])])
         t0 = time.perf_counter()
-        cg, T = OE.cross_terms_oracle(O, side.field, og, 0, nfix, w["num_advice"], [], w["fixed"], w["W1"], w["W2"], ch, threads)
-        for t in T:                                               # commit_cross_terms: sequential commits
+        cg, T = OE.cross_terms_oracle(O, side.field, w["gates"], len(w.get("selectors", [])), w["num_fixed"], w["num_advice"],
+                                      w.get("selectors", []), w["fixed"], w["W1"], w["W2"], ch, threads)
+        for t in T:
             O.msm(side.curve, t, bases, threads)
         O.fold_w(side.field, w["W1"], w["W2"], w["r"], threads)
         O.fold_e(side.field, w["E"], T, w["r"], threads)
-        O.msm(side.curve, w["W2"], bases, threads)               # witness commit
+        O.msm(side.curve, w["W2"], bases, threads)
         t_all += time.perf_counter() - t0
     return dict(value=1.0 / t_all, unit="fold-steps/s", cores=threads, kind="port",
-                sample=f"1 fold step, k={args.k} (same synthetic workload; oracle/ = C port of best_multiexp + "
-                       f"GroupedPoly/GraphEvaluator interpreter, OpenMP {threads} threads; host grants {quota} CPUs "
-                       f"of {os.cpu_count()} via cgroup cpu.max)")
+                sample=f"1 fold step, k={k} (same synthetic workload; oracle/ = C port of best_multiexp + GroupedPoly/GraphEvaluator "
+                       f"interpreter, OpenMP {threads} threads; host grants {quota} CPUs of {os.cpu_count()} via cgroup cpu.max)")
 
 
+def cpu_baseline_cyclefold(args, pri, sup, compat):
+    """ONE CyclefoldIVC::next hot path on the CPU oracle: ProtoGalaxy F / G / K + fold_witness, the support-circuit Sangria
+    prove + commits, the 12 * 2^k witness commit."""
+    import oracle as O
+    from oracle import expr as OE
+    from oracle import protogalaxy as OPG
+    quota = host_cpus()
+    threads = args.cpu_threads or min(2 * quota, os.cpu_count() or 1)
+    w = pri.w
+    bases = pri.ck.bases()
+    sbases = sup.ck.bases()
+    oS = OPG.Structure(O, w["gates"], w["k"], [], w["fixed"], w["num_advice"], 0)     # GraphEvaluator per gate (plonk/mod.rs:697-701)
+    octx = oS.context(1)
+    betas = pri.betas_i[:octx.betas_count()]
+    delta, alpha, gamma = pri.chal
+    t0 = time.perf_counter()
+    pF = OPG.compute_F_fast(oS, octx, betas, delta, w["W1"], [], compat, threads)
+    bs = OPG.beta_stroke(betas, alpha, delta)
+    pG = OPG.compute_G_fast(oS, octx, bs, [w["W1"], w["W2"]], [[], []], compat, threads)
+    OPG.compute_K_from_G(octx, pG, OPG.poly_eval(pF, alpha))
+    from oracle import pyref as P
+    Lg = P.eval_lagrange_poly_for_cyclic_group(gamma, octx.lagrange_domain())
+    O.lincomb(O.FR, [w["W1"], w["W2"]], O.ints_to_mont(O.FR, [int(l) for l in Lg[:2]]), threads)
+    t_pg = time.perf_counter() - t0
+    sw = sup.w
+    ch = np.concatenate([sw["u1_u"].reshape(1, 4), O.ints_to_mont(sup.field, [1])])
+    t1 = time.perf_counter()
+    O.msm(sup.curve, sw["W2"], sbases, threads)
+    cg, T = OE.cross_terms_oracle(O, sup.field, sw["gates"], 1, sw["num_fixed"], sw["num_advice"], sw["selectors"], sw["fixed"],
+                                  sw["W1"], sw["W2"], ch, threads)
+    for t in T:
+        O.msm(sup.curve, t, sbases, threads)
+    O.fold_w(sup.field, sw["W1"], sw["W2"], sw["r"], threads)
+    O.fold_e(sup.field, sw["E"], T, sw["r"], threads)
+    t_sup = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    O.msm(0, w["W2"], bases, threads)
+    t_msm = time.perf_counter() - t2
+    t_all = t_pg + t_sup + t_msm
+    return dict(value=1.0 / t_all, unit="fold-steps/s", cores=threads, kind="port",
+                sample=f"1 CycleFold step, k={w['k']} (same synthetic workload: ProtoGalaxy F/G/K + fold {t_pg:.2f} s, support circuit "
+                       f"{t_sup:.2f} s, {w['num_advice']}*2^{w['k']} witness commit {t_msm:.2f} s; oracle/ = C port of best_multiexp, the "
+                       f"GraphEvaluator interpreter and the reference's reduction trees, OpenMP {threads} threads; host grants "
+                       f"{quota} CPUs of {os.cpu_count()} via cgroup cpu.max)")
+
+
+# ------------------------------------------------------------------------------------------ secondary objects
+def extras_sangria(S, D, args, k=17, log_key=21, steps=20, warmup=3):
+    """BASELINE configs[1]: one SangriaIVC::fold_step at k = 17, (a) with every operand resident in HBM (r01's line) and
+    (b) with the two incoming witnesses coming up from host memory inside the step (what a shim on the Rust side pays)."""
+    from workloads import make_structure_inputs
+    pri = SangriaSide(S, D, make_structure_inputs("primary", k, seed=0x5349524955530000 + 2), log_key, "primary")
+    sec = SangriaSide(S, D, make_structure_inputs("secondary", k, seed=0x5349524955530000 + 3), log_key, "secondary")
+    pri.witness_commit(S, D, False)
+    sec.witness_commit(S, D, False)
+    sangria_step(S, D, pri, sec, False, count=True)
+    out = {}
+    for name, from_host in (("device_resident", False), ("host_witness", True)):
+        for _ in range(warmup):
+            sangria_step(S, D, pri, sec, from_host)
+        S.profile_reset()
+        dt = timed(D, lambda: sangria_step(S, D, pri, sec, from_host), steps, after=lambda: (pri.settle(), sec.settle()))
+        out[name] = {"fold_steps_per_s": round(steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4)}
+        if not from_host:
+            nz = sum(nonzero_rows(sd.inW) + sd.nz_terms for sd in (pri, sec))
+            out["roofline"] = msm_roofline(S, "30 * 2^17 scalars per step over 4 launches", 16.0 * nz * steps / D.world, D.world)
+            ct = S.profile_get("rowprog_cross_terms")
+            out["cross_terms_ms_per_launch"] = round(ct["total_ms"] / ct["launches"], 4) if ct and ct["launches"] else None
+    out["workload"] = f"sangria_poseidon fold_step hot path, k={k}, bn256/grumpkin, key 2^{log_key} (BASELINE configs[1])"
+    out["host_path_ms_per_step"] = out["host_witness"]["ms_per_step"]
+    cpu = None
+    if D.world == 1 and not args.no_cpu_baseline and args.config == "sangria":
+        cpu = cpu_baseline_sangria(args, pri, sec, k)
+    return out, cpu, (pri, sec)
+
+
+def extras_microbench(S, D, ck24, log_n=24, reps=3):
+    """BASELINE configs[4]: 2^24-point MSM (bn256 G1) and 2^24-point NTT (Fr), device resident."""
+    import torch
+    from workloads import rand_fe
+    n = 1 << log_n
+    rng = np.random.default_rng(5)
+    out = {"workload": f"2^{log_n}-point MSM (bn256 G1) + 2^{log_n}-point NTT (Fr), device-resident (BASELINE configs[4])"}
+
+    def timeit(fn):
+        fn()
+        D.barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        D.barrier()
+        return (time.perf_counter() - t) / reps
+    a = up(D, rand_fe(rng, n))
+    S.fft.fft(a)
+    for name, fn in (("fft", S.fft.fft), ("ifft", S.fft.ifft)):
+        S.profile_reset()
+        dt = timeit(lambda: fn(a))
+        out[f"ntt_{name}"] = {"ms": round(dt * 1e3, 3), "elements_per_s": round(n / dt),
+                              "roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEMENT * n / dt / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": round(NTT_BYTES_PER_ELEMENT * n / dt / 1e9 / HBM_PEAK_GBS, 5),
+                                           "traffic": None, "note": "whole transform (3 passes), wall clock around the call"}}
+    del a
+    if not D.emu:
+        torch.cuda.empty_cache()
+    for kind in ("uniform", "trace"):
+        d = up(D, rand_fe(rng, n, zero_frac=0.55 if kind == "trace" else 0.0))
+        S.profile_reset()
+        dt = timeit(lambda: ck24.commit(d))
+        roof = msm_roofline(S, f"2^{log_n} scalars per launch")
+        out[f"msm_{kind}"] = {"ms": round(dt * 1e3, 3), "scalars_per_s": round(n / dt), "roofline": roof,
+                              "whole_call_frac_of_hbm": round(MSM_BYTES_PER_SCALAR * n / dt / 1e9 / HBM_PEAK_GBS, 5)}
+        del d
+    return out
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=args.dist_backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.emu:
+        from sirius_amd import _lib
+        _lib.load(os.path.join(ROOT, "tests", "emu", "libsirius_emu.so"))
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    D = Dist(args)
     import sirius_amd as S
+    from workloads import make_support_inputs
 
-    pri = Side("primary", args.k, args.log_key, rank, world, dev)
-    sec = Side("secondary", args.k, args.log_key, rank, world, dev)
-    for side in (pri, sec):
-        side.inC = np.zeros(8, dtype=np.uint64)
-    witness_commit(S, pri, dist, world, dev)
-    witness_commit(S, sec, dist, world, dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    global COUNT_NONZERO, RO_CHALLENGE
-    RO_CHALLENGE = bool(args.ro_challenge)
-    COUNT_NONZERO = True
-    fold_step(S, pri, sec, dist, world, dev)          # extra untimed step that also counts non-zero scalars
-    COUNT_NONZERO = False
-    for _ in range(args.warmup):
-        fold_step(S, pri, sec, dist, world, dev)
-    S.profile_enable(True)
-    S.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fold_step(S, pri, sec, dist, world, dev)
-    settle(pri); settle(sec)     # the last step's instance folds belong to the timed region
-    barrier()
-    dt = time.perf_counter() - t0
-    S.profile_enable(False)
-    red_dev = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # ---- N > 1 only: the same step as N independent replicas (one IVC chain per GPU, unsharded keys, no
-    # collective).  A single chain is sequential by construction (SURVEY.md 8e), so this is the number that
-    # scales; it is reported as an extra field, `value` stays the sharded single-chain rate.
-    replicas = None
-    if world > 1:
-        rp = Side("primary", args.k, args.log_key, 0, 1, dev)
-        rs = Side("secondary", args.k, args.log_key, 0, 1, dev)
-        for side in (rp, rs):
-            side.inC = np.zeros(8, dtype=np.uint64)
-        witness_commit(S, rp, None, 1, dev)
-        witness_commit(S, rs, None, 1, dev)
-        fold_step(S, rp, rs, None, 1, dev)
-        rsteps = max(3, args.steps // 2)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(rsteps):
-            fold_step(S, rp, rs, None, 1, dev)
-        settle(rp); settle(rs)
-        barrier()
-        rdt = time.perf_counter() - t1
-        tt = torch.tensor([rdt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        replicas = world * rsteps / float(tt.item())
-
-    if rank == 0:
-        acc0 = S.profile_get("msm_accum0") or dict(total_ms=0.0, launches=0, units=0)
-        roof = None
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_accum0.json")))
-            if acc0["launches"] and world == 1:
-                traffic = round(pmc["hbm_bytes_per_scalar"] * acc0["units"] / acc0["launches"])
-        except Exception:
-            traffic = None
-        if acc0["launches"]:
-            achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / (acc0["total_ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "msm::k_accum0 (bucket accumulation)", "achieved": round(achieved, 3),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                    "traffic_source": "profiles/r01_pmc_accum0.json (PMC bytes/scalar x scalars per launch)" if traffic else None,
-                    "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
-                    "note": "integer-ALU bound (256-bit modmul), not HBM bound: see DESIGN.md and the `alu` object"}
-            # the bound that actually applies: mixed additions (8M+2S in XYZZ) per second against the rate the same
-            # instruction mix reaches in isolation on this chip (tools/ubench.hip, profiles/r01_ubench_gfx950_v2_fips_mul.txt)
-            nz = sum(int((sd.inW != 0).any(dim=1).sum().item()) + getattr(sd, "nz_terms", 0) for sd in (pri, sec))
-            madds = 16.0 * nz * args.steps / max(world, 1)
-            roof["alu"] = {"unit": "G mixed-add/s", "achieved": round(madds / (acc0["total_ms"] * 1e-3) / 1e9, 3),
-                           "peak": MADD_PEAK_G, "frac": round(madds / (acc0["total_ms"] * 1e-3) / 1e9 / MADD_PEAK_G, 4),
-                           "peak_source": "measured: profiles/r01_ubench_gfx950_v2_fips_mul.txt (madd 10.6 G/s)"}
-        ct = S.profile_get("rowprog_cross_terms")
-        scalars_per_step = (12 + 7 + 6 + 5) * (1 << args.k)
-        out = {
-            "metric": "IVC fold-steps/s (Sangria, Poseidon-shaped synthetic trace, 2^k rows)",
-            "value": round(args.steps / dt, 4), "unit": "fold-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u256 (8 x u32 Montgomery limbs, modular)",
-            "data": "synthetic",
-            "config": {"workload": f"sangria_poseidon fold_step hot path, k={args.k}, bn256/grumpkin, key 2^{args.log_key}",
-                       "primary": "12 advice / 26 fixed / 2 gates / 6 cross terms", "secondary": "7 advice / 15 fixed / 1 gate / 5 cross terms",
-                       "parallelism": f"msm-shard{world}" if world > 1 else "single-gpu"},
-            "msm_scalars_per_s": round(scalars_per_step * args.steps / dt, 1),
-            "roofline": roof,
-            "replicas_fold_steps_per_s": None if replicas is None else round(replicas, 3),
-            "cross_terms_ms_per_launch": round(ct["total_ms"] / ct["launches"], 4) if ct and ct["launches"] else None,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args, pri, sec)
-            except Exception as e:   # the baseline is a reported number, never the product path
-                out["cpu_baseline"] = {"error": repr(e)}
+    out = None
+    if args.config == "cyclefold":
+        k = args.k or 20
+        log_key = args.log_key or 24
+        compat = args.leaf_rows == "compat"
+        pri = PgPrimary(S, D, k, log_key, compat)
+        ks = 15 if not args.emu else min(k, 5)
+        sup = SangriaSide(S, D, make_support_inputs(ks, seed=0x5349524955530000 + 4), ks + 2, "support")
+        sup.witness_commit(S, D, False)
+        pri.inC = D.combine(S.CURVE_BN256, pri.ck.commit(pri.inW))
+        cyclefold_step(S, D, pri, sup, args.ro_challenge, count=True)           # untimed: also counts the non-zero cross-term rows
+        for _ in range(args.warmup):
+            cyclefold_step(S, D, pri, sup, args.ro_challenge)
+        S.profile_enable(True)
+        S.profile_reset()
+        dt = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), args.steps, after=lambda: (pri.settle(), sup.settle()))
+        S.profile_enable(False)
+        scalars_per_step = pri.w["num_advice"] * pri.rows + (3 + 2) * sup.rows
+        if D.rank == 0:
+            nz = sum(nonzero_rows(torch.from_numpy(hb.array.view(np.int64))) for hb in pri.host_W) / 2.0 + nonzero_rows(sup.inW) + sup.nz_terms
+            roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 4 chunks + the support circuit's 5*2^15 per step",
+                                16.0 * nz * args.steps / D.world, D.world)
+            prof = {}
+            for name in ("pg_F_leaves", "pg_G_leaves", "rowprog_cross_terms"):
+                st = S.profile_get(name)
+                if st and st["launches"]:
+                    prof[name + "_ms"] = round(st["total_ms"] / st["launches"], 4)
+            out = {
+                "metric": "IVC fold-steps/s (CycleFold IVC::next hot path, Poseidon-shaped synthetic trace, 2^k rows)",
+                "value": round(args.steps / dt, 4), "unit": "fold-steps/s", "n_gpus": D.world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "u256 (modular; 9 x 29-bit / 8 x 32-bit limbs)",
+                "data": "synthetic",
+                "config": {"workload": f"cyclefold_poseidon IVC::next hot path, k={k}, bn256/grumpkin cycle, key 2^{log_key} (BASELINE configs[2])",
+                           "primary": f"ProtoGalaxy prove: 12 advice / 26 fixed / 2 gates, n = 2^{k + 1} leaves, F 32 / G 8 / K 256 points; "
+                                      f"12*2^{k} witness commit with the witness uploaded from host memory inside the step",
+                           "support": f"Sangria prove on the support circuit: k={ks}, 3 advice / 4 fixed / 1 selector, 2 cross terms; 3*2^{ks} witness commit",
+                           "leaf_rows": args.leaf_rows, "challenges": "poseidon-ro" if args.ro_challenge else "seeded",
+                           "parallelism": f"msm-shard{D.world}" if D.world > 1 else "single-gpu"},
+                "msm_scalars_per_s": round(scalars_per_step * args.steps / dt, 1),
+                "witness_upload_bytes_per_step": int(pri.w["num_advice"] * pri.rows * 32 + 3 * sup.rows * 32),
+                "roofline": roof, "kernel_ms": prof,
+            }
+            if D.world == 1 and not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline_cyclefold(args, pri, sup, compat)
+                except Exception as e:   # the baseline is a reported number, never the product path
+                    out["cpu_baseline"] = {"error": repr(e)}
+        if not args.no_extras and D.world == 1:
+            ck24 = pri.ck if log_key == 24 else None
+            del pri.accW, pri.inW
+            for hb in pri.host_W:
+                hb.close()
+            if not D.emu:
+                torch.cuda.empty_cache()
+            S.profile_enable(True)
+            sec_obj, _, sides = extras_sangria(S, D, args) if not D.emu else extras_sangria(S, D, args, 4, 8, 1, 0)
+            del sides
+            if not D.emu:
+                torch.cuda.empty_cache()
+            micro = extras_microbench(S, D, ck24) if ck24 is not None else (extras_microbench(S, D, pri.ck, log_key, 1) if D.emu else None)
+            S.profile_enable(False)
+            if D.rank == 0:
+                out["secondary"] = {"sangria_k17": sec_obj, "microbench_2p24": micro}
+                out["host_path_ms_per_step"] = sec_obj["host_path_ms_per_step"]
+    else:
+        k = args.k or 17
+        log_key = args.log_key or 21
+        S.profile_enable(True)
+        obj, cpu, sides = extras_sangria(S, D, args, k, log_key, args.steps, args.warmup)
+        S.profile_enable(False)
+        if D.rank == 0:
+            main_leg = obj["host_witness"]
+            out = {
+                "metric": "IVC fold-steps/s (Sangria, Poseidon-shaped synthetic trace, 2^k rows)",
+                "value": main_leg["fold_steps_per_s"], "unit": "fold-steps/s", "n_gpus": D.world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "u256 (modular; 9 x 29-bit / 8 x 32-bit limbs)", "data": "synthetic",
+                "config": {"workload": obj["workload"] + "; incoming witnesses uploaded from host memory inside the step",
+                           "primary": "12 advice / 26 fixed / 2 gates / 6 cross terms", "secondary": "7 advice / 15 fixed / 1 gate / 5 cross terms",
+                           "parallelism": f"msm-shard{D.world}" if D.world > 1 else "single-gpu"},
+                "msm_scalars_per_s": round(30 * (1 << k) * main_leg["fold_steps_per_s"], 1),
+                "device_resident_ms_per_step": obj["device_resident"]["ms_per_step"],
+                "roofline": obj["roofline"], "cross_terms_ms_per_launch": obj["cross_terms_ms_per_launch"],
+            }
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
+    if D.rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if D.world > 1:
+        D.dist.barrier()
+        D.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

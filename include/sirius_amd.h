@@ -65,6 +65,24 @@ int srs_scalar_field_of(int curve);
 /* Layout self-test: the shim passes the raw bytes of F::ONE and F::from(2); rc SRS_ERR_LAYOUT if they
  * are not R mod p and 2R mod p (i.e. the build of halo2curves is not Montgomery-4x64). */
 int srs_layout_selftest(int field, const srs_fe *one, const srs_fe *two);
+/* The same for the point layout: the shim passes the raw bytes of `C::generator()`; rc SRS_ERR_LAYOUT
+ * unless they are x || y in Montgomery form of (1, 2) on bn256 G1 / (1, sqrt(-16)) on grumpkin. */
+int srs_layout_selftest_point(int curve, const srs_affine *generator);
+
+/* ---- memory the shim may own ----
+ * Device-resident vectors are what keeps a fold step off PCIe: the running accumulator (W, E), the cross terms and the
+ * incoming witness stay in HBM between calls, every compute entry takes them with space = SRS_SPACE_DEVICE, and only the
+ * new witness goes up (srs_commit_upload) and commitments come down.
+ *   srs_dev_alloc / srs_dev_free   : HBM (hipMalloc on the process's device)
+ *   srs_host_alloc / srs_host_free : page-locked host memory (uploads from it are asynchronous to the caller)
+ *   srs_upload   : host -> device, ordered on `stream`
+ *   srs_download : device -> host, returns when the bytes are in `dst_host` */
+int srs_dev_alloc(size_t bytes, void **out);
+void srs_dev_free(void *p);
+int srs_host_alloc(size_t bytes, void **out);
+void srs_host_free(void *p);
+int srs_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int srs_download(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 
 /* ---- CommitmentKey (src/commitment.rs:29-32) ----
  * srs_ck_create: device cache of `CommitmentKey<C>::ck` (Rust keeps owning the Box<[C]>).
@@ -101,6 +119,27 @@ int srs_commit(srs_ck *ck, const srs_fe *scalars, size_t n, int space, int repr,
  * out[m] = commit(scalars[m][0..n[m]]) for m < batch, one set of launches. */
 int srs_commit_batch(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, size_t batch,
                      int space, int repr, void *stream, srs_affine *out);
+/* `ck.commit(&W)` for a witness that was just produced on the host (run_sps_protocol_*, src/plonk/mod.rs:441-447), leaving
+ * a device copy behind for the prover calls that follow (VanillaFS::prove / ProtoGalaxy::prove take it with
+ * SRS_SPACE_DEVICE).  The vector goes up in a few chunks on an internal copy stream and the MSM of chunk j runs while chunk
+ * j+1 is still on the bus; the partial sums are added on the host.  dev_copy: n elements of HBM (srs_dev_alloc) or NULL
+ * (library staging, no copy kept).  Same result and errors as srs_commit. */
+int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *dev_copy, int repr, void *stream,
+                      srs_affine *out);
+
+/* ---- one process, several GPUs (`srs_ck_create(.., n_devices, ..)`) ----
+ * The Rust IVC driver is a single process (src/ivc/sangria/incrementally_verifiable_computation.rs:429), so the library
+ * itself spreads a key over `n_devices` GPUs (0 = all visible): device d keeps the block-cyclic stripes s % n_devices == d
+ * of the window table, every commit PARTITIONS the scalars the same way (device d receives only its stripes: n * 32 /
+ * n_devices bytes over its own link, straight from the caller's buffer), the n_devices partial sums land in page-locked
+ * host memory and are added there -- the caller sees an ordinary key: srs_commit / srs_commit_batch / srs_commit_upload
+ * return the full commitment.  More logical shards than physical devices are allowed (shard d runs on device d % count):
+ * that is how the path is tested on a one-GPU box.  Scalars with space = SRS_SPACE_DEVICE must live on the process's
+ * device (shard 0's); the other shards fetch their stripes with peer copies. */
+int srs_ck_create_multi(int curve, const srs_affine *bases, size_t len, int space, int n_devices, srs_ck **out);
+int srs_ck_setup_synthetic_multi(int curve, size_t len, uint64_t seed, int n_devices, srs_ck **out);
+int srs_ck_num_shards(const srs_ck *ck);      /* 1 for an ordinary key */
+
 /* out = sum of `n` affine points (host); combines per-rank partial commitments. */
 int srs_point_sum(int curve, const srs_affine *points, size_t n, srs_affine *out);
 /* out = [scalar] P  (the 1-element best_multiexp of src/nifs/sangria/accumulator.rs:213,243), host. */
@@ -191,6 +230,11 @@ size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructur
  * -2 straight-line kernel compiled at structure creation with hiprtc (structures of >= 2^14 rows without an ahead-of-time kernel).
  * Returns the source length (truncated to cap-1).  Used by tools/gen_rowprog_spec.py. */
 size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id);
+/* Which kernel a structure's row programs run on (a failed run-time compilation silently leaves the interpreter in place:
+ * this makes it observable).  which: 0 = cross terms, 1 = gates (deciders), 2 = ProtoGalaxy leaves.
+ * Returns SRS_KERNEL_INTERPRETER, SRS_KERNEL_AHEAD_OF_TIME or SRS_KERNEL_RUNTIME_COMPILED; -1 for a bad argument. */
+enum { SRS_KERNEL_INTERPRETER = 0, SRS_KERNEL_AHEAD_OF_TIME = 1, SRS_KERNEL_RUNTIME_COMPILED = 2 };
+int srs_structure_kernel_kind(const srs_structure *S, int which);
 /* Developer hook, host only (needs no device): compiles a small row program in the emitted form with hiprtc against the device
  * headers embedded in the library -- the run-time compilation path of srs_structure_create minus the module load.  0 and the
  * size of the gfx950 code object, or SRS_ERR_INVALID with the compiler log (log may be NULL).  A structure whose program fails to

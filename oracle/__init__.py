@@ -228,3 +228,29 @@ def fold_e(field, e, terms, r, threads=0):
     lib().o_fold_e(C.c_int(field), _p(e), tp, C.c_size_t(len(ts)), _p(r), _p(out),
                    C.c_size_t(e.shape[0]), C.c_int(threads))
     return out
+
+
+def lincomb(field, ws, coefs, threads=0):
+    """sum_j coefs[j] * ws[j]  (ProtoGalaxy::fold_witness / FoldedWitness::new)."""
+    ws = [_fe(w) for w in ws]
+    cf = _fe(np.asarray(coefs, dtype=np.uint64).reshape(-1, 4))
+    assert cf.shape[0] >= len(ws)
+    wp = (C.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    out = np.empty_like(ws[0])
+    lib().o_lincomb(C.c_int(field), wp, _p(cf), C.c_size_t(len(ws)), _p(out), C.c_size_t(ws[0].size // 4), C.c_int(threads))
+    return out
+
+
+def pg_tree(field, leaves, count, weights, threads=0):
+    """The reduction tree of compute_F / compute_G.  leaves: (n, 4) shared by all points or (P, n, 4); weights (P, t, 4)
+    with n = 2^t; leaves beyond `count` are zero.  -> (P, 4)."""
+    lv = _fe(leaves)
+    w = _fe(weights)
+    P, t = w.shape[0], w.shape[1]
+    n = 1 << t
+    stride = 0 if lv.ndim == 2 else lv.shape[1]
+    assert (lv.shape[0] if lv.ndim == 2 else lv.shape[1]) >= min(count, n)
+    out = np.empty((P, 4), dtype=np.uint64)
+    lib().o_pg_tree(C.c_int(field), _p(lv), C.c_size_t(stride), C.c_size_t(n), C.c_size_t(count), _p(w), C.c_size_t(P),
+                    C.c_size_t(t), _p(out), C.c_int(threads))
+    return out

@@ -611,3 +611,57 @@ void o_fold_e(int field, const ofe *e, const ofe *const *t, size_t n_terms, cons
     }
     free(pw);
 }
+
+/* ------------------------------------------------------------------ ProtoGalaxy
+ * src/nifs/protogalaxy/mod.rs:176-210 (fold_witness), poly/folded_witness.rs:20-180 (FoldedWitness::new):
+ *   out[i] = sum_j coef[j] * w[j][i]
+ */
+void o_lincomb(int field, const ofe *const *w, const ofe *coef, size_t J, ofe *out, size_t n, int threads) {
+    oracle_init(); threads = clamp_threads(threads); const fparams *f = &F[field];
+#pragma omp parallel for num_threads(threads)
+    for (size_t i = 0; i < n; ++i) {
+        ofe a; fmul(f, &a, &coef[0], &w[0][i]);
+        for (size_t j = 1; j < J; ++j) { ofe m; fmul(f, &m, &coef[j], &w[j][i]); fadd(f, &a, &a, &m); }
+        out[i] = a;
+    }
+}
+
+/* The binary reduction tree of compute_F / compute_G (src/nifs/protogalaxy/poly/mod.rs:68-203, 308-425):
+ *   node(height h) = left + right * weight[h]        (leaves are height 0; `reducer`, :127-163 and :333-361)
+ * over `n` (a power of two) leaves, for P independent points:
+ *   leaf i of point p = leaves[p * leaves_stride + i] if i < count else 0     (count = rows * gates; padding leaves are 0,
+ *                        get_evaluate_witness_fn returns zero beyond the last gate, src/plonk/mod.rs:705-711)
+ *   weights of point p = weights[p * t + h], h < t = log2(n)
+ * compute_F: ONE leaf table (leaves_stride = 0), 32 weight vectors beta + X_p * delta; compute_G: one table per point
+ * (the folded witnesses), the same weights beta' for every point.  out[p] = root.  Serial recursion per point below
+ * 2^12 leaves, OpenMP tasks above (the reference: rayon::join above 2^18, :171-186).
+ */
+static void pg_tree_rec(const fparams *f, const ofe *leaves, size_t count, const ofe *w, size_t lo, size_t len, unsigned h, ofe *out) {
+    if (len == 1) {
+        if (lo < count) *out = leaves[lo]; else memset(out, 0, sizeof(*out));
+        return;
+    }
+    ofe l, r, m;
+    if (len > 4096) {
+#pragma omp task shared(l)
+        pg_tree_rec(f, leaves, count, w, lo, len / 2, h - 1, &l);
+#pragma omp task shared(r)
+        pg_tree_rec(f, leaves, count, w, lo + len / 2, len / 2, h - 1, &r);
+#pragma omp taskwait
+    } else {
+        pg_tree_rec(f, leaves, count, w, lo, len / 2, h - 1, &l);
+        pg_tree_rec(f, leaves, count, w, lo + len / 2, len / 2, h - 1, &r);
+    }
+    fmul(f, &m, &r, &w[h - 1]);
+    fadd(f, out, &l, &m);
+}
+void o_pg_tree(int field, const ofe *leaves, size_t leaves_stride, size_t n, size_t count, const ofe *weights, size_t P, size_t t,
+               ofe *out, int threads) {
+    oracle_init(); threads = clamp_threads(threads); const fparams *f = &F[field];
+    for (size_t p = 0; p < P; ++p) {
+#pragma omp parallel num_threads(threads)
+#pragma omp single
+        pg_tree_rec(f, leaves + p * leaves_stride, count, weights + p * t, 0, n, (unsigned)t, &out[p]);
+    }
+}
+

@@ -106,6 +106,13 @@ void o_fold_w(int field, const ofe *w1, const ofe *w2, const ofe *r, ofe *out, s
 void o_fold_e(int field, const ofe *e, const ofe *const *t, size_t n_terms, const ofe *r,
               ofe *out, size_t n, int threads);
 
+/* ---- ProtoGalaxy (src/nifs/protogalaxy/) ---- */
+/* out[i] = sum_j coef[j] * w[j][i]   (fold_witness, mod.rs:176-210; FoldedWitness::new, poly/folded_witness.rs:20-180) */
+void o_lincomb(int field, const ofe *const *w, const ofe *coef, size_t J, ofe *out, size_t n, int threads);
+/* the weighted binary reduction tree of compute_F / compute_G (poly/mod.rs:68-203, 308-425); see oracle.c */
+void o_pg_tree(int field, const ofe *leaves, size_t leaves_stride, size_t n, size_t count, const ofe *weights, size_t P, size_t t,
+               ofe *out, int threads);
+
 #ifdef __cplusplus
 }
 #endif

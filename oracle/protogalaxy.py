@@ -190,3 +190,56 @@ def new_accumulator_betas(beta, count):                                        #
         out.append(b)
         b = b * 2 % FR
     return out
+
+
+# ---- the same polynomials with the leaf tables, witness folds and reduction trees in C (oracle.c: o_eval_program, o_lincomb,
+# o_pg_tree) -- identical values (tests/test_oracle_pins.py::test_pg_fast_equals_literal), usable at the bench sizes
+# (bench.py's cpu_baseline leg, mid-size GPU parity tests).  `threads` = OpenMP threads.
+def _leaf_table(S, W_mont, challenges_ints, compat, threads):
+    """(count, 4) Montgomery leaves: leaf i = gates[i / 2^k] at row i % 2^k (compat: row 0, Q1)."""
+    O = S.O
+    ch = O.ints_to_mont(O.FR, list(challenges_ints)) if len(challenges_ints) else np.zeros((0, 4), np.uint64)
+    tabs = [O.eval_program(O.FR, pr, S.selectors, S.fixed, W_mont, W_mont, ch, threads) for pr in S.progs]
+    if compat:
+        tabs = [np.ascontiguousarray(np.broadcast_to(t[0], t.shape)) for t in tabs]
+    return np.ascontiguousarray(np.concatenate(tabs, axis=0))
+
+
+def compute_F_fast(S, ctx, betas, delta, W_mont, challenges, compat=True, threads=0):
+    O = S.O
+    n, t = ctx.count_with_padding, ctx.betas_count()
+    betas = list(betas)[:t]
+    deltas = [delta]
+    for _ in range(t - 1):
+        deltas.append(deltas[-1] * deltas[-1] % FR)
+    leaves = _leaf_table(S, W_mont, challenges, compat, threads)
+    Xs = list(P.iter_cyclic_subgroup(ctx.fft_points_count_F().bit_length() - 1))
+    weights = np.stack([O.ints_to_mont(O.FR, [(b + X * d) % FR for b, d in zip(betas, deltas)]) for X in Xs])
+    points = O.mont_to_ints(O.FR, O.pg_tree(O.FR, leaves, leaves.shape[0], weights, threads))
+    P.ifft(points)
+    return points
+
+
+def compute_G_fast(S, ctx, betas_stroke, Ws_mont, challenges_list, compat=True, threads=0):
+    O = S.O
+    assert len(Ws_mont) >= 2, "You can't fold 0 traces"
+    t = ctx.betas_count()
+    bs = O.ints_to_mont(O.FR, list(betas_stroke)[:t]).reshape(1, t, 4)
+    pts = list(P.iter_cyclic_subgroup(ctx.fft_log_domain_size_G()))[:ctx.fft_points_count_G]
+    points = []
+    for X in pts:
+        L = P.eval_lagrange_poly_for_cyclic_group(X, ctx.lagrange_domain())
+        w = O.lincomb(O.FR, Ws_mont, O.ints_to_mont(O.FR, [int(l) for l in L[:len(Ws_mont)]]), threads)
+        ch = [sum(L[j] * challenges_list[j][c] for j in range(len(Ws_mont))) % FR for c in range(len(challenges_list[0]))]
+        leaves = _leaf_table(S, w, ch, compat, threads)
+        points.append(O.mont_to_ints(O.FR, O.pg_tree(O.FR, leaves, leaves.shape[0], bs, threads))[0])
+    P.ifft(points)
+    return points
+
+
+def evaluate_e_fast(S, ctx, betas, W_mont, challenges, compat=True, threads=0):
+    O = S.O
+    t = ctx.betas_count()
+    leaves = _leaf_table(S, W_mont, challenges, compat, threads)
+    w = O.ints_to_mont(O.FR, list(betas)[:t]).reshape(1, t, 4)
+    return O.mont_to_ints(O.FR, O.pg_tree(O.FR, leaves, leaves.shape[0], w, threads))[0]

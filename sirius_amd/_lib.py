@@ -32,6 +32,18 @@ def _prototypes():
         "srs_version": (C.c_char_p, []),
         "srs_scalar_field_of": (i32, [i32]),
         "srs_layout_selftest": (i32, [i32, vp, vp]),
+        "srs_layout_selftest_point": (i32, [i32, vp]),
+        "srs_dev_alloc": (i32, [sz, C.POINTER(vp)]),
+        "srs_dev_free": (None, [vp]),
+        "srs_host_alloc": (i32, [sz, C.POINTER(vp)]),
+        "srs_host_free": (None, [vp]),
+        "srs_upload": (i32, [vp, vp, sz, vp]),
+        "srs_download": (i32, [vp, vp, sz, vp]),
+        "srs_commit_upload": (i32, [vp, vp, sz, vp, i32, vp, vp]),
+        "srs_ck_create_multi": (i32, [i32, vp, sz, i32, i32, C.POINTER(vp)]),
+        "srs_ck_setup_synthetic_multi": (i32, [i32, sz, C.c_uint64, i32, C.POINTER(vp)]),
+        "srs_ck_num_shards": (i32, [vp]),
+        "srs_structure_kernel_kind": (i32, [vp, i32]),
         "srs_ck_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "srs_ck_create_sharded": (i32, [i32, vp, sz, i32, u32, u32, C.POINTER(vp)]),
         "srs_ck_setup_synthetic": (i32, [i32, sz, C.c_uint64, u32, u32, C.POINTER(vp)]),

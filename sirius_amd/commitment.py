@@ -69,6 +69,32 @@ class CommitmentKey:
         return self
 
     @classmethod
+    def create_multi(cls, curve, bases, n_devices=0):
+        """One process, several GPUs (srs_ck_create_multi): the library spreads the key over `n_devices` shards (0 = all
+        visible devices; more shards than devices are folded onto the devices round-robin) and partitions the scalars of
+        every commit the same way.  The handle behaves like an ordinary key: commits return the full commitment."""
+        addr, space, n, keep = _buf(bases, 8)
+        self = cls.__new__(cls)
+        self.curve, self._len, self.rank, self.world = curve, n, 0, 1
+        h = C.c_void_p()
+        L.check(L.lib().srs_ck_create_multi(curve, addr, n, space, n_devices, C.byref(h)))
+        self._h = h
+        return self
+
+    @classmethod
+    def setup_synthetic_multi(cls, curve, n, seed=0, n_devices=0):
+        self = cls.__new__(cls)
+        self.curve, self._len, self.rank, self.world = curve, n, 0, 1
+        h = C.c_void_p()
+        L.check(L.lib().srs_ck_setup_synthetic_multi(curve, n, seed, n_devices, C.byref(h)))
+        self._h = h
+        return self
+
+    @property
+    def num_shards(self):
+        return L.lib().srs_ck_num_shards(self._h)
+
+    @classmethod
     def load_from_file(cls, curve, file_path, k, rank=0, world=1):
         """`CommitmentKey::load_from_file` + the on-curve validation of `load_or_setup_cache`
         (src/commitment.rs:112-160): raw `[C; 2^k]` dump; IOError on a short/missing file,
@@ -141,6 +167,23 @@ class CommitmentKey:
             raise TooLongInput(n, self._len)
         out = np.zeros(8, dtype=np.uint64)
         L.check(L.lib().srs_commit(self._h, addr, n, space, repr, _stream(), out.ctypes.data))
+        return out
+
+    def commit_upload(self, v_host, dev_copy=None, repr=L.REPR_MONT):
+        """`ck.commit(&W)` for a witness fresh from the host that also leaves a device copy (srs_commit_upload): chunked
+        upload overlapped with the MSM of the chunks already in HBM.  v_host: numpy (n, 4) uint64 (ideally page-locked,
+        `HostBuffer`); dev_copy: torch CUDA tensor of the same shape or None."""
+        a = np.ascontiguousarray(v_host, dtype=np.uint64)
+        assert a.shape[-1] == 4
+        n = a.size // 4
+        if n > self._len:
+            raise TooLongInput(n, self._len)
+        dptr = None
+        if dev_copy is not None:
+            assert _is_torch(dev_copy) and dev_copy.is_contiguous() and dev_copy.numel() == 4 * n
+            dptr = dev_copy.data_ptr()
+        out = np.zeros(8, dtype=np.uint64)
+        L.check(L.lib().srs_commit_upload(self._h, a.ctypes.data, n, dptr, repr, _stream(), out.ctypes.data))
         return out
 
     def commit_batch(self, vs, repr=L.REPR_MONT):
@@ -219,3 +262,26 @@ def point_mul(curve, scalar, p, repr=L.REPR_MONT):
     out = np.zeros(8, dtype=np.uint64)
     L.check(L.lib().srs_point_mul(curve, s.ctypes.data, repr, q.ctypes.data, out.ctypes.data))
     return out
+
+
+class HostBuffer:
+    """Page-locked host memory from the library (srs_host_alloc) viewed as a numpy (n, 4) uint64 array: uploads from it
+    are asynchronous to the caller.  Keep the object alive while `.array` is in use."""
+
+    def __init__(self, n_fe):
+        p = C.c_void_p()
+        L.check(L.lib().srs_host_alloc(max(n_fe, 1) * 32, C.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n_fe, 4))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            L.lib().srs_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -36,9 +36,83 @@ using namespace srs;
 
 static_assert(sizeof(srs_fe) == sizeof(fe_t) && sizeof(srs_affine) == sizeof(affine_t), "ABI layout");
 
-struct srs_ck {
+// One logical shard of a multi-device key (srs_ck_create_multi): its stripes of the window table on `device`, a stream and a
+// staging arena there, and a host thread bound to that device which runs the shard's part of every commit.
+struct CkShard {
+    int device = 0;
     msm::Key key;
+    Arena staging;
+    hipStream_t stream = nullptr;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::function<void()> job;      // set by post(), cleared by the worker
+    bool has_job = false, quit = false;
+    int rc = 0;
+    std::string err;
+
+    void loop() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return has_job || quit; });
+                if (quit && !has_job) return;
+                fn = job;
+            }
+            int r = 0;
+            std::string e;
+            try {
+                fn();
+            } catch (const DeviceError &de) {
+                r = de.rc;
+                e = get_error();
+            } catch (const std::exception &ex) {
+                r = SRS_ERR_DEVICE;
+                e = ex.what();
+            } catch (...) {
+                r = SRS_ERR_DEVICE;
+                e = "unknown exception in a key shard";
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            rc = r;
+            err = e;
+            has_job = false;
+            done_cv.notify_all();
+        }
+    }
+    void post(std::function<void()> fn) {
+#if defined(SRS_EMU)
+        // the CPU logic emulator keeps one global execution context (tests/emu/hipemu.h): shard jobs run inline, one by one
+        rc = 0;
+        try {
+            fn();
+        } catch (const DeviceError &de) {
+            rc = de.rc;
+            err = get_error();
+        }
+        return;
+#endif
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(fn);
+        has_job = true;
+        rc = 0;
+        cv.notify_one();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return !has_job; });
+        return rc;
+    }
+};
+
+struct srs_ck {
+    msm::Key key;       // the key of a single-device handle; for a multi-device handle only curve / global_len are meaningful
     Arena staging;      // H2D staging of host scalars
+    hipStream_t copy_stream = nullptr;       // srs_commit_upload: uploads run here, the MSMs on the caller's stream
+    std::vector<hipEvent_t> events;
+    std::vector<std::unique_ptr<CkShard>> shards;      // non-empty: multi-device key
 };
 
 struct srs_poseidon {
@@ -204,6 +278,156 @@ int ensure_device() {
 #endif
 }
 
+// ---- multi-device keys --------------------------------------------------------------------------------------------
+int physical_device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    return n;
+}
+
+// copies the block-cyclic stripes of shard `d` (stripe s with s % world == d) of src[0 .. n) compactly to dst (a buffer on
+// the shard's device); src is host memory or memory of the process's device.  One strided copy for the whole stripes
+// plus one for the tail.  Returns the number of elements copied (= shard_count(n, d, world)).
+size_t copy_stripes(fe_t *dst, const fe_t *src, size_t n, uint32_t d, uint32_t world, bool src_is_device, hipStream_t st) {
+    const size_t S = (size_t)1 << msm::STRIPE_LOG;
+    const hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (world == 1) {
+        if (n) SRS_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(fe_t), kind, st));
+        return n;
+    }
+    const size_t full = n >> msm::STRIPE_LOG, rem = n & (S - 1);
+    const size_t mine = full / world + (d < full % world ? 1 : 0);          // whole stripes of this shard
+    if (mine)
+        SRS_HIP_CHECK(hipMemcpy2DAsync(dst, S * sizeof(fe_t), src + (size_t)d * S, (size_t)world * S * sizeof(fe_t),
+                                       S * sizeof(fe_t), mine, kind, st));
+    size_t cnt = mine * S;
+    if (rem && d == full % world) {
+        SRS_HIP_CHECK(hipMemcpyAsync(dst + cnt, src + full * S, rem * sizeof(fe_t), kind, st));
+        cnt += rem;
+    }
+    return cnt;
+}
+
+template <class C>
+void sum_partials_t(const std::vector<std::vector<xyzz_t>> &parts, size_t batch, xyzz_t *out) {
+    for (size_t m = 0; m < batch; ++m) {
+        xyzz_t a = Ec<C>::identity();
+        for (const auto &p : parts) a = Ec<C>::add(a, p[m]);
+        out[m] = a;
+    }
+}
+
+// commit through a multi-device key: every shard thread stages ITS stripes of every vector on its device (from the caller's
+// host buffer, or with a peer copy from the process's device) and runs its partial MSMs; the partial sums are added here.
+// ready: event recorded on the caller's stream after the producer of device-resident scalars (or nullptr).
+int multi_commit(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, size_t batch, int space, int repr, hipEvent_t ready,
+                 xyzz_t *res) {
+    const uint32_t world = (uint32_t)ck->shards.size();
+    std::vector<std::vector<xyzz_t>> parts(world, std::vector<xyzz_t>(batch));
+    for (uint32_t d = 0; d < world; ++d) {
+        CkShard *sh = ck->shards[d].get();
+        sh->post([=, &parts]() {
+            size_t total = 256;
+            std::vector<uint32_t> nloc(batch);
+            for (size_t m = 0; m < batch; ++m) {
+                nloc[m] = (uint32_t)shard_count(n[m], d, world);
+                total += Arena::pad(((size_t)nloc[m] + 1) * sizeof(fe_t));
+            }
+            sh->staging.reserve(total);
+            sh->staging.reset();
+            if (ready) SRS_HIP_CHECK(hipStreamWaitEvent(sh->stream, ready, 0));
+            std::vector<const fe_t *> dptr(batch);
+            for (size_t m = 0; m < batch; ++m) {
+                fe_t *dst = sh->staging.take<fe_t>((size_t)nloc[m] + 1);
+                copy_stripes(dst, reinterpret_cast<const fe_t *>(scalars[m]), n[m], d, world, space == SRS_SPACE_DEVICE, sh->stream);
+                dptr[m] = dst;
+            }
+            msm::run(sh->key, dptr.data(), nloc.data(), (uint32_t)batch, repr == SRS_REPR_MONT, sh->stream, parts[d].data());
+        });
+    }
+    int rc = SRS_OK;
+    std::string err;
+    for (uint32_t d = 0; d < world; ++d) {
+        int r = ck->shards[d]->wait();
+        if (r && !rc) { rc = r; err = ck->shards[d]->err; }
+    }
+    if (rc) return fail(rc, "multi-device commit: " + err);
+    if (ck->key.curve == SRS_CURVE_BN256) sum_partials_t<Bn256>(parts, batch, res); else sum_partials_t<Grumpkin>(parts, batch, res);
+    return SRS_OK;
+}
+
+void free_shards(srs_ck *ck) {
+    for (auto &sp : ck->shards) {
+        CkShard *sh = sp.get();
+        if (sh->worker.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(sh->mu);
+                sh->quit = true;
+            }
+            sh->cv.notify_one();
+            sh->worker.join();
+        }
+        (void)hipSetDevice(sh->device);
+        if (sh->key.table) (void)hipFree(sh->key.table);
+        if (sh->key.h_result) (void)hipHostFree(sh->key.h_result);
+        sh->key.arena.release();
+        sh->staging.release();
+        if (sh->stream) (void)hipStreamDestroy(sh->stream);
+    }
+    ck->shards.clear();
+}
+
+// builds the shards of a multi-device key: `fill(shard)` must leave table[0 .. key.len) (window 0) on the shard's device
+template <class Fill>
+int create_multi(int curve, size_t len, int n_devices, Fill fill, srs_ck **out) {
+    const int phys = physical_device_count();
+    if (phys <= 0) return fail(SRS_ERR_DEVICE, "no HIP device visible: libsirius_amd has no CPU path");
+    const uint32_t world = n_devices > 0 ? (uint32_t)n_devices : (uint32_t)phys;
+    if (world > 64) return fail(SRS_ERR_INVALID, "srs_ck_create_multi: more than 64 shards");
+    int home = 0;
+#if !defined(SRS_EMU)
+    home = g_device;
+#endif
+    srs_ck *ck = new srs_ck();
+    ck->key.curve = curve;
+    ck->key.global_len = len;
+    ck->key.len = 0;
+    try {
+        for (uint32_t d = 0; d < world; ++d) {
+            std::unique_ptr<CkShard> sh(new CkShard());
+            sh->device = (home + (int)d) % phys;               // shard 0 on the process's device
+            sh->key.curve = curve;
+            sh->key.global_len = len;
+            sh->key.rank = d;
+            sh->key.world = world;
+            sh->key.len = shard_count(len, d, world);
+            sh->key.compact_scalars = true;                    // the shard is handed ITS scalars, already gathered
+            SRS_HIP_CHECK(hipSetDevice(sh->device));
+            if (sh->device != home) (void)hipDeviceEnablePeerAccess(home, 0);      // stripes of device-resident scalars come by peer copy
+            SRS_HIP_CHECK(hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking));
+            if (sh->key.len) {
+                SRS_HIP_CHECK(hipMalloc((void **)&sh->key.table, sh->key.len * msm::NWIN * sizeof(affine_t)));
+                fill(*sh);
+                msm::build_table(sh->key, sh->stream);
+            }
+            ck->shards.push_back(std::move(sh));
+        }
+        SRS_HIP_CHECK(hipSetDevice(home));
+#if !defined(SRS_EMU)
+        for (auto &sp : ck->shards) {
+            CkShard *sh = sp.get();
+            sh->worker = std::thread([sh] { sh->loop(); });
+        }
+#endif
+    } catch (...) {
+        (void)hipSetDevice(home);
+        srs_ck_free(ck);
+        throw;
+    }
+    *out = ck;
+    return SRS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -249,6 +473,74 @@ int srs_layout_selftest(int field, const srs_fe *one, const srs_fe *two) {
     if (std::memcmp(&o, &eo, 32) != 0 || std::memcmp(&t, &et, 32) != 0)
         return fail(SRS_ERR_LAYOUT, "field elements are not 4x64 little-endian Montgomery (R = 2^256)");
     return SRS_OK;
+}
+
+int srs_layout_selftest_point(int curve, const srs_affine *generator) {
+    if (!valid_curve(curve) || !generator) return fail(SRS_ERR_INVALID, "srs_layout_selftest_point: bad argument");
+    affine_t g, e;
+    std::memcpy(&g, generator, 64);
+    if (curve == SRS_CURVE_BN256) {
+        e.x = Fq::one();
+        e.y = Fq::dbl(Fq::one());                                   // bn256 G1 generator (1, 2)
+    } else {
+        // grumpkin generator (1, sqrt(-16)), y = 17631683881184975370165255887551781615748388533673675138860
+        fe_t y;
+        const uint32_t yc[8] = {0x823f272cu, 0x833fc48du, 0xf1181294u, 0x2d270d45u, 0x06a45d63u, 0xcf135e75u, 0x00000002u, 0u};
+        for (int j = 0; j < 8; ++j) y.v[j] = yc[j];
+        e.x = Fr::one();
+        e.y = Fr::to_mont(y);
+    }
+    if (std::memcmp(&g, &e, 64) != 0)
+        return fail(SRS_ERR_LAYOUT, "the generator is not x || y in 4x64 little-endian Montgomery form (R = 2^256)");
+    return SRS_OK;
+}
+
+int srs_dev_alloc(size_t bytes, void **out) {
+    if (!out) return fail(SRS_ERR_INVALID, "srs_dev_alloc: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        void *p = nullptr;
+        SRS_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+        *out = p;
+        return SRS_OK;
+    });
+}
+void srs_dev_free(void *p) {
+    if (p && ensure_device() == SRS_OK) (void)hipFree(p);
+}
+int srs_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(SRS_ERR_INVALID, "srs_host_alloc: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        void *p = nullptr;
+        SRS_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+        *out = p;
+        return SRS_OK;
+    });
+}
+void srs_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+int srs_upload(void *dst_dev, const void *src_host, size_t bytes, void *stream) {
+    if (bytes && (!dst_dev || !src_host)) return fail(SRS_ERR_INVALID, "srs_upload: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        if (bytes) SRS_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+        return SRS_OK;
+    });
+}
+int srs_download(void *dst_host, const void *src_dev, size_t bytes, void *stream) {
+    if (bytes && (!dst_host || !src_dev)) return fail(SRS_ERR_INVALID, "srs_download: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        if (bytes) SRS_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        SRS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        return SRS_OK;
+    });
 }
 
 int srs_ck_create_sharded(int curve, const srs_affine *bases, size_t len, int space, uint32_t rank,
@@ -319,10 +611,45 @@ int srs_ck_setup_synthetic(int curve, size_t len, uint64_t seed, uint32_t rank, 
     });
 }
 
+static int read_shard_bases(const msm::Key &key, hipStream_t st, srs_affine *out) {       // key.len points, this shard's window 0
+    if (!key.len) return SRS_OK;
+    affine_t *tmp = nullptr;
+    SRS_HIP_CHECK(hipMalloc((void **)&tmp, key.len * sizeof(affine_t)));
+    try {
+        msm::read_bases(key, tmp, st);
+        SRS_HIP_CHECK(hipMemcpyAsync(out, tmp, key.len * sizeof(affine_t), hipMemcpyDeviceToHost, st));
+        SRS_HIP_CHECK(hipStreamSynchronize(st));
+    } catch (...) {
+        (void)hipFree(tmp);
+        throw;
+    }
+    (void)hipFree(tmp);
+    return SRS_OK;
+}
+
 int srs_ck_get_bases(const srs_ck *ck, srs_affine *out) {
-    if (!ck || (ck->key.len && !out)) return fail(SRS_ERR_INVALID, "srs_ck_get_bases: bad argument");
+    if (!ck || ((ck->key.len || !ck->shards.empty()) && !out)) return fail(SRS_ERR_INVALID, "srs_ck_get_bases: bad argument");
     int rc = ensure_device();
     if (rc) return rc;
+    if (!ck->shards.empty()) {           // multi-device key: the whole key, stripes gathered from the shards
+        return guarded([&]() -> int {
+            const size_t S = (size_t)1 << msm::STRIPE_LOG, len = ck->key.global_len;
+            const uint32_t world = (uint32_t)ck->shards.size();
+            for (uint32_t d = 0; d < world; ++d) {
+                CkShard *sh = ck->shards[d].get();
+                std::vector<srs_affine> loc(sh->key.len);
+                SRS_HIP_CHECK(hipSetDevice(sh->device));
+                read_shard_bases(sh->key, sh->stream, loc.data());
+                size_t at = 0;
+                for (size_t st = d; st * S < len; st += world) {
+                    size_t cnt = std::min(S, len - st * S);
+                    std::memcpy(out + st * S, loc.data() + at, cnt * sizeof(srs_affine));
+                    at += cnt;
+                }
+            }
+            return ensure_device();
+        });
+    }
     return guarded([&]() -> int {
         if (ck->key.len) {       // the table lives in the multiplier's internal Montgomery form: convert window 0 back
             affine_t *tmp = nullptr;
@@ -339,7 +666,7 @@ int srs_ck_get_bases(const srs_ck *ck, srs_affine *out) {
         return SRS_OK;
     });
 }
-size_t srs_ck_local_len(const srs_ck *ck) { return ck ? ck->key.len : 0; }
+size_t srs_ck_local_len(const srs_ck *ck) { return ck ? (ck->shards.empty() ? ck->key.len : ck->key.global_len) : 0; }
 
 int srs_ck_load_file(int curve, const char *path, size_t k, uint32_t rank, uint32_t world, srs_ck **out) {
     if (!valid_curve(curve) || !path || !out || k >= 32) return fail(SRS_ERR_INVALID, "srs_ck_load_file: bad argument");
@@ -364,7 +691,7 @@ int srs_ck_load_file(int curve, const char *path, size_t k, uint32_t rank, uint3
 int srs_ck_save_file(const srs_ck *ck, const char *path) {
     if (!ck || !path) return fail(SRS_ERR_INVALID, "srs_ck_save_file: bad argument");
     if (ck->key.world != 1) return fail(SRS_ERR_INVALID, "srs_ck_save_file: sharded key");
-    std::vector<srs_affine> host(ck->key.len);
+    std::vector<srs_affine> host(srs_ck_local_len(ck));
     int rc = srs_ck_get_bases(ck, host.data());
     if (rc) return rc;
     FILE *f = std::fopen(path, "wb");
@@ -380,8 +707,17 @@ int srs_ck_count_off_curve(const srs_ck *ck, size_t *bad) {
     int rc = ensure_device();
     if (rc) return rc;
     return guarded([&]() -> int {
-        *bad = msm::count_off_curve(ck->key, nullptr);
-        return SRS_OK;
+        if (ck->shards.empty()) {
+            *bad = msm::count_off_curve(ck->key, nullptr);
+            return SRS_OK;
+        }
+        size_t total = 0;
+        for (auto &sp : ck->shards) {
+            SRS_HIP_CHECK(hipSetDevice(sp->device));
+            total += msm::count_off_curve(sp->key, sp->stream);
+        }
+        *bad = total;
+        return ensure_device();
     });
 }
 
@@ -389,8 +725,43 @@ int srs_ck_create(int curve, const srs_affine *bases, size_t len, int space, srs
     return srs_ck_create_sharded(curve, bases, len, space, 0, 1, out);
 }
 
+int srs_ck_create_multi(int curve, const srs_affine *bases, size_t len, int space, int n_devices, srs_ck **out) {
+    if (!valid_curve(curve) || !out || (!bases && len) || n_devices < 0) return fail(SRS_ERR_INVALID, "srs_ck_create_multi: bad argument");
+    if (len > ((size_t)1 << 27)) return fail(SRS_ERR_INVALID, "srs_ck_create_multi: key longer than 2^27 bases");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        return create_multi(curve, len, n_devices, [&](CkShard &sh) {
+            const size_t S = (size_t)1 << msm::STRIPE_LOG;
+            const hipMemcpyKind kind = space == SRS_SPACE_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+            size_t local = 0;
+            for (size_t st = sh.key.rank; st * S < len; st += sh.key.world) {
+                size_t cnt = std::min(S, len - st * S);
+                SRS_HIP_CHECK(hipMemcpyAsync(sh.key.table + local, bases + st * S, cnt * sizeof(affine_t), kind, sh.stream));
+                local += cnt;
+            }
+        }, out);
+    });
+}
+int srs_ck_setup_synthetic_multi(int curve, size_t len, uint64_t seed, int n_devices, srs_ck **out) {
+    if (!valid_curve(curve) || !out || n_devices < 0) return fail(SRS_ERR_INVALID, "srs_ck_setup_synthetic_multi: bad argument");
+    if (len > ((size_t)1 << 27)) return fail(SRS_ERR_INVALID, "srs_ck_setup_synthetic_multi: key longer than 2^27 bases");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        return create_multi(curve, len, n_devices, [&](CkShard &sh) { msm::generate_bases(sh.key, seed, sh.stream); }, out);
+    });
+}
+int srs_ck_num_shards(const srs_ck *ck) { return ck ? (ck->shards.empty() ? 1 : (int)ck->shards.size()) : 0; }
+
 void srs_ck_free(srs_ck *ck) {
     if (!ck) return;
+    if (!ck->shards.empty()) {
+        free_shards(ck);
+        (void)ensure_device();
+    }
+    for (hipEvent_t e : ck->events) (void)hipEventDestroy(e);
+    if (ck->copy_stream) (void)hipStreamDestroy(ck->copy_stream);
     if (ck->key.table) (void)hipFree(ck->key.table);
     if (ck->key.h_result) (void)hipHostFree(ck->key.h_result);
     ck->key.arena.release();
@@ -412,6 +783,24 @@ int srs_commit_batch(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, 
     }
     int rc = ensure_device();
     if (rc) return rc;
+    if (!ck->shards.empty()) {
+        return guarded([&]() -> int {
+            hipStream_t st = (hipStream_t)stream;
+            hipEvent_t ready = nullptr;
+            if (space == SRS_SPACE_DEVICE) {           // the shards' streams wait for whatever produced the scalars on `stream`
+                if (ck->events.empty()) { hipEvent_t e; SRS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ck->events.push_back(e); }
+                ready = ck->events[0];
+                SRS_HIP_CHECK(hipEventRecord(ready, st));
+            }
+            std::vector<xyzz_t> res(batch);
+            int mrc = multi_commit(ck, scalars, n, batch, space, repr, ready, res.data());
+            if (mrc) return mrc;
+            std::vector<affine_t> aff(batch);
+            to_affine_batch(ck->key.curve, res.data(), aff.data(), batch);
+            std::memcpy(out, aff.data(), batch * sizeof(affine_t));
+            return SRS_OK;
+        });
+    }
     return guarded([&]() -> int {
         hipStream_t st = (hipStream_t)stream;
         const uint32_t world = ck->key.world, rank = ck->key.rank;
@@ -445,6 +834,88 @@ int srs_commit(srs_ck *ck, const srs_fe *scalars, size_t n, int space, int repr,
     const srs_fe *v[1] = {scalars};
     size_t nn[1] = {n};
     return srs_commit_batch(ck, v, nn, 1, space, repr, stream, out);
+}
+
+int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *dev_copy, int repr, void *stream, srs_affine *out) {
+    if (!ck || !out || (n && !scalars_host)) return fail(SRS_ERR_INVALID, "srs_commit_upload: bad argument");
+    if (n > ck->key.global_len)
+        return fail(SRS_ERR_TOO_LONG_INPUT, "Can't commit too long input: input len: " + std::to_string(n) + ", but limit is " +
+                                                std::to_string(ck->key.global_len));
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!ck->shards.empty() || ck->key.world != 1 || n == 0) {
+        // multi-device key: every shard pulls its stripes from the host buffer over its own link; sharded (process-per-GPU)
+        // key: the kernels pick this rank's stripes out of the full vector.  The device copy is a plain upload.
+        if (dev_copy && n) {
+            rc = guarded([&]() -> int {
+                SRS_HIP_CHECK(hipMemcpyAsync(dev_copy, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
+                return SRS_OK;
+            });
+            if (rc) return rc;
+        }
+        if (ck->shards.empty() && dev_copy) return srs_commit(ck, dev_copy, n, SRS_SPACE_DEVICE, repr, stream, out);
+        return srs_commit(ck, scalars_host, n, SRS_SPACE_HOST, repr, stream, out);
+    }
+    return guarded([&]() -> int {
+        // chunks: a few large pieces (every MSM has a fixed tail of ~0.5 ms), stripe-aligned
+        static const size_t want = [] { const char *e = std::getenv("SRS_COMMIT_CHUNKS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
+        size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n >> 20));
+        chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
+        size_t per = ((n + chunks - 1) / chunks + 1023) & ~(size_t)1023;
+        chunks = (n + per - 1) / per;
+        fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
+        if (!dst) {
+            ck->staging.reserve(Arena::pad(n * sizeof(fe_t)) + 256);
+            ck->staging.reset();
+            dst = ck->staging.take<fe_t>(n);
+        }
+        if (!ck->copy_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->copy_stream, hipStreamNonBlocking));
+        while (ck->events.size() < chunks + 1) {
+            hipEvent_t e;
+            SRS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ck->events.push_back(e);
+        }
+        msm::reserve(ck->key, (uint32_t)per, 1);
+        // the copy stream must not overwrite dst while earlier work on the caller's stream still reads it
+        SRS_HIP_CHECK(hipEventRecord(ck->events[chunks], st));
+        SRS_HIP_CHECK(hipStreamWaitEvent(ck->copy_stream, ck->events[chunks], 0));
+        const fe_t *src = reinterpret_cast<const fe_t *>(scalars_host);
+        std::vector<bool> launched(chunks, false);
+        auto upload = [&](size_t j) {
+            const size_t a = j * per, len = std::min(per, n - a);
+            SRS_HIP_CHECK(hipMemcpyAsync(dst + a, src + a, len * sizeof(fe_t), hipMemcpyHostToDevice, ck->copy_stream));
+            SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
+        };
+        auto launch = [&](size_t j) {
+            const size_t a = j * per, len = std::min(per, n - a);
+            SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
+            const fe_t *ptr = dst + a;
+            const uint32_t nn = (uint32_t)len, base = (uint32_t)a;
+            launched[j] = msm::enqueue(ck->key, &ptr, &nn, &base, 1, repr == SRS_REPR_MONT, st, (uint32_t)j);
+        };
+        // a pageable source makes hipMemcpyAsync block the caller: issue upload j+1 before MSM j so both are in flight either way
+        upload(0);
+        for (size_t j = 0; j < chunks; ++j) {
+            if (j + 1 < chunks) upload(j + 1);
+            launch(j);
+        }
+        SRS_HIP_CHECK(hipStreamSynchronize(st));
+        SRS_HIP_CHECK(hipGetLastError());
+        auto go = [&](auto tag) {
+            using C = decltype(tag);
+            xyzz_t acc = Ec<C>::identity(), part;
+            for (size_t j = 0; j < chunks; ++j) {
+                msm::finish(ck->key, 1, (uint32_t)j, launched[j], &part);
+                acc = Ec<C>::add(acc, part);
+            }
+            affine_t a = Ec<C>::to_affine(acc);
+            std::memcpy(out, &a, sizeof(a));
+        };
+        if (ck->key.curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
+        prof::collect();
+        return SRS_OK;
+    });
 }
 
 int srs_point_sum(int curve, const srs_affine *points, size_t n, srs_affine *out) {
@@ -719,6 +1190,11 @@ int srs_jit_selfcheck(size_t *code_bytes, char *log, size_t log_cap) {
     }
     return ok ? SRS_OK : fail(SRS_ERR_INVALID, "srs_jit_selfcheck: hiprtc rejected the emitted form: " + text.substr(0, 400));
 #endif
+}
+
+int srs_structure_kernel_kind(const srs_structure *S, int which) {
+    if (!S || which < 0 || which > 2) return -1;
+    return rowprog::kernel_kind(S->s, which);
 }
 
 size_t srs_structure_program_source(srs_structure *S, int which, char *buf, size_t cap, uint64_t *fingerprint, int *spec_id) {
@@ -1311,8 +1787,7 @@ int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_f
         if (space == SRS_SPACE_DEVICE) {
             int erc = rowprog::lincomb(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *const *>(W),
                                        reinterpret_cast<const fe_t *>(coefs), J, n, st, err);
-            if (erc) return fail(erc, "srs_fold_lincomb: " + err);
-            SRS_HIP_CHECK(hipStreamSynchronize(st));
+            if (erc) return fail(erc, "srs_fold_lincomb: " + err);   // stream-ordered, see srs_fold_witness
         } else {
             fe_t *buf = nullptr;
             SRS_HIP_CHECK(hipMalloc((void **)&buf, J * n * sizeof(fe_t)));

@@ -29,6 +29,7 @@ constexpr uint32_t RED_COLS = NBUCKET / RED_ROWS;
 constexpr uint32_t RED_THREADS = 4 * RED_COLS;   // k_reduce_final: one quad per element, 128 elements
 constexpr uint32_t ACC1_QUAD_MAX = 1u << 16;     // k_accum1 runs one quad per output when a level has at most this many outputs (x batch)
 constexpr uint32_t BATCH_ARGS = 16;    // MSMs per set of launches (batch descriptor = kernel argument); larger batches are chunked
+constexpr uint32_t LANDING_SLOTS = 16;  // sets of launches whose results may be in flight at once (chunked commits)
 constexpr uint32_t NORM_G = 16;           // points per inversion in the key-expansion normalise
 
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
@@ -41,6 +42,7 @@ struct Key {
     size_t len = 0;           // number of bases held by THIS rank
     size_t global_len = 0;    // length of the whole key (== len when world == 1)
     uint32_t rank = 0, world = 1;
+    bool compact_scalars = false;   // world > 1: the scalar vectors handed to run() hold ONLY this rank's stripes, gathered (multi-device keys)
     affine_t *table = nullptr;
     Arena arena;              // per-key scratch (grow-only)
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
@@ -64,6 +66,16 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch);
 // only this rank's stripes are read (n[m] is then the LOCAL count).
 void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch, int is_mont,
          hipStream_t stream, xyzz_t *result_host);
+
+// The two halves of run() for callers that keep several sets of launches in flight (chunked commits whose uploads overlap
+// the previous chunk's MSM):  enqueue() only launches (<= BATCH_ARGS MSMs; MSM m reads bases [base[m], base[m] + n[m]),
+// base_host == nullptr: the usual prefix); the partial sums land in page-locked slot `slot` in stream order.  After the
+// caller has synchronised the stream, finish() does the host end.  The scratch arena is shared: sets of launches on ONE
+// stream reuse it in stream order; reserve() sizes it up front (growing it later would free memory still in use).
+bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch, int is_mont,
+             hipStream_t stream, uint32_t slot);
+void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host);
+void reserve(Key &k, uint32_t n_max, uint32_t batch);
 
 }  // namespace msm
 }  // namespace srs

@@ -186,6 +186,7 @@ __global__ void k_on_curve(const affine_t *__restrict__ pts, uint32_t n, uint32_
 struct BatchDesc {
     const fe_t *ptr[BATCH_ARGS];
     uint32_t n[BATCH_ARGS];
+    uint32_t base[BATCH_ARGS];      // first base of MSM m inside the key (0 for the usual prefix commit; chunked commits slide it)
 };
 
 template <class C>
@@ -329,7 +330,7 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
         if (code != 0xFFFFu) {
             uint32_t pos = atomicAdd(&cur[(code & 0x7FFFu) / SEG_BUCKETS], 1u);
             ok[pos] = (uint16_t)(code & 0x7FFFu);
-            op[pos] = (w * table_stride + i) | ((code & 0x8000u) << 16);
+            op[pos] = (w * table_stride + bd.base[m] + i) | ((code & 0x8000u) << 16);
         }
     });
 }
@@ -401,7 +402,7 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     for_each_digit(d, lo, hi, [&](uint32_t i, uint32_t code) {
         if (code != 0xFFFFu) {
             uint32_t pos = atomicAdd(&h[code & 0x7FFFu], 1u);
-            out[pos] = (w * table_stride + i) | ((code & 0x8000u) << 16);
+            out[pos] = (w * table_stride + bd.base[m] + i) | ((code & 0x8000u) << 16);
         }
     });
 }
@@ -896,15 +897,14 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 4096;
 }
 
+// launches one set of <= BATCH_ARGS MSMs on `stream`; the 3 partial sums of MSM m land in landing slot `slot`
+// (page-locked host memory) in stream order.  Returns false when every MSM is empty (nothing was launched).
 template <class C>
-static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch,
-                  int is_mont, hipStream_t stream, xyzz_t *result_host) {
+static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch,
+                      int is_mont, hipStream_t stream, uint32_t slot) {
     uint32_t n_max = 0;
     for (uint32_t m = 0; m < batch; ++m) n_max = std::max(n_max, n_host[m]);
-    if (n_max == 0) {
-        for (uint32_t m = 0; m < batch; ++m) result_host[m] = Ec<C>::identity();
-        return;
-    }
+    if (n_max == 0) return false;
     const uint64_t M = (uint64_t)n_max * NWIN;
     const int levels = levels_for(M);
     const size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1) + 4;
@@ -933,10 +933,12 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
     for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
         bd.ptr[m] = m < batch ? scalars_dev[m] : nullptr;
         bd.n[m] = m < batch ? n_host[m] : 0;
+        bd.base[m] = (m < batch && base_host) ? base_host[m] : 0;
     }
     SRS_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)NBUCKET * batch * sizeof(uint32_t), stream));
 
-    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont, k.rank, k.world);
+    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont,
+               k.compact_scalars ? 0u : k.rank, k.compact_scalars ? 1u : k.world);
     // tile = digits per workgroup: large enough that the fixed 2^15-bin zero/scan of the LDS histogram is
     // amortised, small enough to give ~SORT_TARGET_BLOCKS workgroups (one per CU, 128 KiB LDS each)
     uint32_t tile = (uint32_t)(((uint64_t)n_max * NWIN * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
@@ -990,25 +992,52 @@ static void run_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap, (const uint32_t *)plan,
                plan_stride, rc);
     SRS_LAUNCH((k_reduce_final<C>), (3, batch), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_out);
-    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * sizeof(xyzz_t)));
-    xyzz_t *two = static_cast<xyzz_t *>(k.h_result);
+    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
+    xyzz_t *two = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
     SRS_HIP_CHECK(hipMemcpyAsync(two, d_out, 3 * (size_t)batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
-    SRS_HIP_CHECK(hipStreamSynchronize(stream));
-    SRS_HIP_CHECK(hipGetLastError());
-    for (uint32_t m = 0; m < batch; ++m) {             // S = RED_COLS * (2 A' + Z) + B on the host (10 group ops)
+    return true;
+}
+
+// host end of enqueue_t, after `stream` has been synchronised:  S = RED_COLS * (2 A' + Z) + B  (10 group operations per MSM)
+template <class C>
+static void finish_t(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host) {
+    if (!launched) {
+        for (uint32_t m = 0; m < batch; ++m) result_host[m] = Ec<C>::identity();
+        return;
+    }
+    const xyzz_t *two = static_cast<const xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
+    for (uint32_t m = 0; m < batch; ++m) {
         xyzz_t a = Ec<C>::add(Ec<C>::dbl(two[3 * m]), two[3 * m + 2]);
-        for (uint32_t k = 1; k < RED_COLS; k <<= 1) a = Ec<C>::dbl(a);
+        for (uint32_t j = 1; j < RED_COLS; j <<= 1) a = Ec<C>::dbl(a);
         result_host[m] = Ec<C>::add(a, two[3 * m + 1]);
     }
-    prof::collect();
 }
+
+bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch, int is_mont,
+             hipStream_t stream, uint32_t slot) {
+    if (batch > BATCH_ARGS || slot >= LANDING_SLOTS) {
+        set_error("internal: msm::enqueue batch / slot out of range");
+        throw DeviceError{5};
+    }
+    return k.curve == 0 ? enqueue_t<Bn256>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot)
+                        : enqueue_t<Grumpkin>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot);
+}
+void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host) {
+    if (k.curve == 0) finish_t<Bn256>(k, batch, slot, launched, result_host); else finish_t<Grumpkin>(k, batch, slot, launched, result_host);
+}
+void reserve(Key &k, uint32_t n_max, uint32_t batch) { k.arena.reserve(workspace_bytes(n_max, batch)); }
 
 void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch, int is_mont,
          hipStream_t stream, xyzz_t *result_host) {
     for (uint32_t at = 0; at < batch; at += BATCH_ARGS) {          // the batch descriptor is a kernel argument of BATCH_ARGS slots
         const uint32_t b = std::min<uint32_t>(BATCH_ARGS, batch - at);
-        if (k.curve == 0) run_t<Bn256>(k, scalars_dev + at, n_host + at, b, is_mont, stream, result_host + at);
-        else run_t<Grumpkin>(k, scalars_dev + at, n_host + at, b, is_mont, stream, result_host + at);
+        const bool launched = enqueue(k, scalars_dev + at, n_host + at, nullptr, b, is_mont, stream, 0);
+        if (launched) {
+            SRS_HIP_CHECK(hipStreamSynchronize(stream));
+            SRS_HIP_CHECK(hipGetLastError());
+        }
+        finish(k, b, 0, launched, result_host + at);
+        prof::collect();
     }
 }
 

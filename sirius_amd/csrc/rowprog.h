@@ -55,6 +55,7 @@ int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, s
 // straight-line C++ of the structure's row program (tools/gen_rowprog_spec.py), its fingerprint and the
 // ahead-of-time kernel it maps to (-1: interpreter)
 const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf);
+int kernel_kind(const Structure *S, int which);      // which: 0 cross terms, 1 gates, 2 ProtoGalaxy leaves -> 0 / 1 / 2
 // hiprtc compiles a small program in the emitted form against the embedded device headers (host only, no device needed)
 bool jit_selfcheck(size_t *code_bytes, std::string &log);
 

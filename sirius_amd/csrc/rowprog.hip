@@ -1302,6 +1302,17 @@ static void launch_rowprog(const DevArgs &A, uint32_t nslots, hipStream_t st) {
     else SRS_LAUNCH((k_rowprog<F, 32>), (blocks), (RP_THREADS), 0, st, A);
 }
 
+// 0 interpreter, 1 ahead-of-time specialised kernel, 2 compiled at run time (include/sirius_amd.h SRS_KERNEL_*)
+int kernel_kind(const Structure *S, int which) {
+    if (which == 2) return S->pg_spec_id >= 0 ? 1 : 0;
+    const Program &p = which == 0 ? S->cross : S->plain_compressed;
+    if (p.spec_id >= 0) return 1;
+#if !defined(SRS_EMU)
+    if (p.jit.function) return 2;
+#endif
+    return 0;
+}
+
 const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spec_id, std::string &buf) {
     if (which >= 3 && (size_t)(which - 3) >= S->gate_progs.size()) { buf.clear(); return buf.c_str(); }
     Program &p = which >= 3 ? S->gate_progs[which - 3] : (which == 0 ? S->cross : (which == 1 ? S->plain_compressed : S->plain_homogeneous));

@@ -221,7 +221,7 @@ def test_commit_degenerate_bases(srs, oracle, cid):
     _degenerate_bases_case(srs, oracle, cid, 70000)       # enough entries for several accumulation levels
 
 
-@pytest.mark.parametrize("cid,n", [(0, 1 << 24), (1, 12 << 20)])
+@pytest.mark.parametrize("cid,n", [(0, 1 << 24), (1, 12 << 20), (0, 12 << 20)])      # the last: configs[2]'s witness commit on ITS curve (bn256)
 def test_commit_full_size_properties(srs, oracle, cid, n):
     """BASELINE configs 5 (2^24-point MSM) and 3 (12 * 2^20 witness commit) at FULL size, through size-independent
     properties: additivity over a split of the vector, commit(2 v) = 2 commit(v) (the scalar doubling done by the fold
@@ -271,3 +271,111 @@ def test_two_pass_scatter_matches_single_pass(srs, oracle):
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT=mode), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_commit_upload_chunked(srs, oracle, cid):
+    """srs_commit_upload (witness straight from host memory, chunked upload overlapped with the MSM of the chunks already in
+    HBM, device copy left behind) == the oracle's commitment, for every chunk count incl. ragged last chunks, pageable and
+    page-locked sources; the device copy equals the source."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O, sirius_amd as S\n"
+        "from conftest import seeded_scalars\n"
+        f"cid = {cid}\n"
+        "for n, kind in ((70001, 'uniform'), (4096, 'trace'), (1, 'uniform'), (3000, 'uniform')):\n"
+        "    bases = O.make_bases(cid, 4, n + 5); ck = S.CommitmentKey(cid, bases)\n"
+        "    v = seeded_scalars(O, cid, n, 19, kind); want = O.msm(cid, v, bases[:n])\n"
+        "    hb = S.HostBuffer(n); hb.array[:] = v\n"
+        "    d = torch.zeros((n, 4), dtype=torch.int64, device='cuda')\n"
+        "    assert np.array_equal(ck.commit_upload(v), want)\n"
+        "    assert np.array_equal(ck.commit_upload(hb.array, dev_copy=d), want)\n"
+        "    assert np.array_equal(d.cpu().numpy().view(np.uint64), v)\n"
+        "    assert np.array_equal(ck.commit(d), want)\n"
+        "    try:\n"
+        "        ck.commit_upload(np.zeros((n + 6, 4), np.uint64)); raise SystemExit('no TooLongInput')\n"
+        "    except S.TooLongInput: pass\n"
+        "    ck.close(); hb.close()\n"
+        "print('ok')\n")
+    for chunks in ("1", "2", "3", "7", "16"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS=chunks), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_commit_upload_default_chunking_large(srs, oracle):
+    """Default chunking (4 chunks from 2^22 scalars on) at a size with real overlap: additivity against plain commits."""
+    import torch
+    n = (5 << 20) + 12345
+    ck = srs.CommitmentKey.setup_synthetic(0, n, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    v = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    v[:, 3] &= (1 << 60) - 1
+    v[torch.rand(n, device="cuda", generator=g) < 0.5] = 0
+    want = ck.commit(v)
+    hb = srs.HostBuffer(n)
+    hb.array[:] = v.cpu().numpy().view(np.uint64)
+    d = torch.empty_like(v)
+    assert np.array_equal(ck.commit_upload(hb.array, dev_copy=d), want)
+    assert torch.equal(d, v)
+    assert np.array_equal(ck.commit_upload(hb.array), want)          # library staging, no copy kept
+    ck.close()
+    hb.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_multi_device_key_single_process(srs, oracle, cid):
+    """srs_ck_create_multi: ONE process, the library spreads the key over several shards (2, 3, 5 logical shards folded onto
+    the visible device(s)) and partitions the scalars of every commit; the caller sees the FULL commitment.  Host and
+    device-resident scalars, batches, ragged lengths (partial stripes, fewer stripes than shards), key read-back."""
+    import torch
+    O = oracle
+    n = 5 * 1024 + 777
+    bases = O.make_bases(cid, 21, n)
+    vs = [seeded_scalars(O, cid, m, 30 + j, kind) for j, (m, kind) in enumerate(((n, "uniform"), (2049, "trace"), (1, "uniform"), (1024, "uniform")))]
+    want = [O.msm(cid, v, bases[: v.shape[0]]) for v in vs]
+    for shards in (2, 3, 5):
+        ck = srs.CommitmentKey.create_multi(cid, bases, shards)
+        assert ck.num_shards == shards and len(ck) == n
+        for v, w in zip(vs, want):
+            assert np.array_equal(ck.commit(v), w)
+            assert np.array_equal(ck.commit(torch.from_numpy(v.view(np.int64)).cuda()), w)
+            assert np.array_equal(ck.commit_upload(v), w)
+        assert np.array_equal(ck.commit_batch(vs), np.stack(want))
+        assert np.array_equal(ck.commit_batch([torch.from_numpy(v.view(np.int64)).cuda() for v in vs]), np.stack(want))
+        assert np.array_equal(ck.commit(vs[0][:0]), np.zeros(8, np.uint64))
+        assert np.array_equal(ck.bases(), bases) and ck.count_off_curve() == 0
+        with pytest.raises(srs.TooLongInput):
+            ck.commit(np.zeros((n + 1, 4), np.uint64))
+        ck.close()
+    # synthetic multi key == synthetic single key (same seeded bases, whatever the sharding)
+    a = srs.CommitmentKey.setup_synthetic(cid, 3000, seed=5)
+    b = srs.CommitmentKey.setup_synthetic_multi(cid, 3000, seed=5, n_devices=3)
+    assert np.array_equal(a.bases(), b.bases())
+    assert np.array_equal(a.commit(vs[1]), b.commit(vs[1]))
+    a.close(); b.close()
+
+
+def test_multi_device_key_in_a_prove(srs, oracle):
+    """A multi-device key behind commit_cross_terms: the cross terms are produced on the process's device and every shard
+    fetches its stripes with a (peer) copy -- same commitments as the single-device key."""
+    from workloads import make_structure_inputs
+    O = oracle
+    k = 11
+    w = make_structure_inputs("secondary", k, seed=77)
+    St = srs.PlonkStructure(w["field"], k, [], w["fixed"], w["num_advice"], w["gates"])
+    bases = O.make_bases(1, 5, 1 << k)
+    ck1, ck3 = srs.CommitmentKey(1, bases), srs.CommitmentKey.create_multi(1, bases, 3)
+    args = (St, w["u1_challenges"], w["u1_u"], w["W1"], w["u2_challenges"], w["W2"])
+    t1, c1 = srs.VanillaFS.commit_cross_terms(ck1, *args)
+    t3, c3 = srs.VanillaFS.commit_cross_terms(ck3, *args)
+    assert np.array_equal(c1, c3) and all(np.array_equal(a, b) for a, b in zip(t1, t3))
+    import torch
+    dv = lambda a: torch.from_numpy(a.view(np.int64)).cuda()
+    t3d, c3d = srs.VanillaFS.commit_cross_terms(ck3, St, w["u1_challenges"], w["u1_u"], dv(w["W1"]), w["u2_challenges"], dv(w["W2"]))
+    assert np.array_equal(c1, c3d)
+    ck1.close(); ck3.close(); St.close()

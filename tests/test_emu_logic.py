@@ -168,3 +168,44 @@ def test_emu_two_pass_scatter():
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT="2"), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
+
+
+def test_emu_commit_upload_and_multi_device_key(emu, oracle, monkeypatch):
+    """Host logic of srs_commit_upload (chunks with sliding base offsets, partial sums added on the host) and of the
+    multi-device key (stripe partition of bases AND scalars, strided copies, partials per shard), on the emulator."""
+    O = oracle
+    monkeypatch.setenv("SRS_COMMIT_CHUNKS", "3")          # read once per process by the library: set before the first upload
+    for cid, shard_counts in ((1, (3,)),):
+        bases = O.make_bases(cid, 7 + cid, 1100)
+        sc = seeded_scalars(O, cid, 1097, 5, "trace")          # 1 whole stripe + a tail
+        want = O.msm(cid, sc, bases[:1097])
+        ck = emu.CommitmentKey(cid, bases)
+        assert np.array_equal(ck.commit_upload(sc), want)
+        dev = np.zeros_like(sc)
+        import torch
+        d = torch.from_numpy(dev.view(np.int64))
+        assert np.array_equal(ck.commit_upload(sc, dev_copy=d), want) and np.array_equal(dev, sc)
+        ck.close()
+        for shards in shard_counts:
+            mk = emu.CommitmentKey.create_multi(cid, bases, shards)
+            assert mk.num_shards == shards
+            assert np.array_equal(mk.commit(sc), want)
+            assert np.array_equal(mk.commit_upload(sc), want)
+            assert np.array_equal(mk.commit_batch([sc, sc[:1000], sc[:0]])[1], O.msm(cid, sc[:1000], bases[:1000]))
+            assert np.array_equal(mk.bases(), bases) and mk.count_off_curve() == 0
+            mk.close()
+
+
+def test_emu_bench_harness():
+    """bench.py end to end on the emulator (tiny sizes): the harness logic -- CycleFold step order, host witness buffers,
+    commit_upload with a device copy, the CPU-baseline leg -- produces the JSON line with the contract's fields."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emu", "--k", "3", "--log-key", "7", "--steps", "1", "--warmup", "0",
+                        "--cpu-threads", "2", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["config"]["workload"].startswith("cyclefold_poseidon") and line["cpu_baseline"]["kind"] == "port"

@@ -159,3 +159,78 @@ def test_fast_paths_equal_general_paths(srs, oracle):
         assert np.array_equal(fast_F, gen_F) and np.array_equal(fast_G, gen_G)
         assert fast_F[ctx.betas_count + 1:].any() == False      # degree t polynomial: higher coefficients are exactly zero
     St.close()
+
+
+def _config_size_case(srs, oracle, k, compare_oracle):
+    """BASELINE configs[2] / [3] shapes: the primary CycleFold structure (MainGate<5> + MainGate<3>, 12 advice / 26 fixed,
+    2 gates -> n = 2^(k+1) leaves).  Size-independent identities in both leaf modes:
+      F(0) = evaluate_e(betas);  G(1) = evaluate_e(betas');  calculate_e(F, K, gamma, alpha) = G(gamma) (K is an exact quotient);
+      fold_witness is linear: fold(acc, in; L) - L0 acc - L1 in = 0 on a sample of rows.
+    With compare_oracle the coefficient vectors of F and G and the value e are compared with the CPU oracle (oracle/
+    protogalaxy.py *_fast: the reference's leaf function, folded witnesses and reduction trees, in C) at FULL size."""
+    import random
+    import torch
+    from oracle import expr as OE
+    from oracle import protogalaxy as OPG
+    from oracle import pyref as P
+    from sirius_amd import protogalaxy as PG
+    from workloads import make_structure_inputs
+    O = oracle
+    w = make_structure_inputs("primary", k, seed=1000 + k)
+    S = srs.PlonkStructure(0, k, [], w["fixed"], w["num_advice"], w["gates"])
+    ctx = PG.PolyContext(S, 1)
+    t = k + 1
+    assert (ctx.count_of_evaluation_with_padding, ctx.betas_count, ctx.fft_points_count_F, ctx.fft_points_count_G,
+            ctx.fft_log_domain_size_K) == (1 << t, t, 32, 8, 8)
+    dev = lambda a: torch.from_numpy(a.view(np.int64)).cuda()
+    W0, W1 = dev(w["W1"]), dev(w["W2"])
+    rnd = random.Random(k)
+    betas = [rnd.randrange(P.FR) for _ in range(t)]
+    delta, alpha, gamma = (rnd.randrange(P.FR) for _ in range(3))
+    m = lambda v: O.ints_to_mont(O.FR, list(v))
+    bs = OPG.beta_stroke(betas, alpha, delta)
+    if compare_oracle:
+        gate_T = [5, 3]
+        og, fo, ao = [], 0, 0
+        for T in gate_T:
+            og.append(OE.main_gate_expression(T, 0, fo, ao, w["num_fixed"])); fo += 2 * T + 5; ao += T + 2
+        oS = OPG.Structure(O, og, k, [], w["fixed"], w["num_advice"], 0)
+        octx = oS.context(1)
+    seen = {}
+    for compat in (True, False):
+        pF = PG.compute_F(ctx, m(betas), m([delta])[0], W0, reference_compat=compat)
+        pG = PG.compute_G(ctx, m(bs), [W0, W1], reference_compat=compat)
+        iF, iG = O.mont_to_ints(O.FR, pF), O.mont_to_ints(O.FR, pG)
+        e_b = O.mont_to_ints(O.FR, PG.evaluate_e_from_trace(ctx, m(betas), W0, reference_compat=compat))[0]
+        e_bs = O.mont_to_ints(O.FR, PG.evaluate_e_from_trace(ctx, m(bs), W0, reference_compat=compat))[0]
+        assert iF[0] == e_b, "F(0) = evaluate_e(betas)"
+        assert sum(iG) % P.FR == e_bs, "G(1) = evaluate_e(betas')"
+        assert all(c == 0 for c in iF[t + 1:]), "deg F <= t"
+        Fa = PG.poly_eval(pF, m([alpha])[0])
+        pK = PG.compute_K_from_G(ctx, pG, Fa)
+        e_new = PG.calculate_e(pF, pK, m([gamma])[0], m([alpha])[0], ctx.lagrange_domain)
+        assert np.array_equal(PG.poly_eval(pG, m([gamma])[0]), e_new), "F(alpha) L0(gamma) + Z(gamma) K(gamma) = G(gamma)"
+        seen[compat] = (iF, iG)
+        if compare_oracle:
+            assert iF == OPG.compute_F_fast(oS, octx, betas, delta, w["W1"], [], compat), f"compute_F vs oracle (compat={compat})"
+            assert iG == OPG.compute_G_fast(oS, octx, bs, [w["W1"], w["W2"]], [[], []], compat), f"compute_G vs oracle (compat={compat})"
+            assert e_b == OPG.evaluate_e_fast(oS, octx, betas, w["W1"], [], compat), "evaluate_e vs oracle"
+    assert seen[True] != seen[False]
+    Lg = PG.eval_lagrange_poly_for_cyclic_group(m([gamma])[0], ctx.lagrange_domain)
+    Wf = PG.fold_witness(0, [W0, W1], Lg)
+    idx = torch.from_numpy(np.random.default_rng(k).integers(0, w["W1"].shape[0], size=4096)).cuda()
+    got = Wf[idx].cpu().numpy().view(np.uint64)
+    want = O.lincomb(O.FR, [np.ascontiguousarray(w["W1"][idx.cpu().numpy()]), np.ascontiguousarray(w["W2"][idx.cpu().numpy()])],
+                     O.ints_to_mont(O.FR, O.mont_to_ints(O.FR, Lg)[:2]))
+    assert np.array_equal(got, want), "fold_witness rows"
+    S.close()
+
+
+def test_cyclefold_config_k20_vs_oracle(srs, oracle):
+    """BASELINE configs[2] (cyclefold_poseidon, k = 20): ProtoGalaxy F / G / e at full size against the CPU oracle."""
+    _config_size_case(srs, oracle, 20, compare_oracle=True)
+
+
+def test_protogalaxy_config_k22_properties(srs, oracle):
+    """BASELINE configs[3] (ProtoGalaxy at k = 22, n = 2^23 leaves) on one GPU: the identities at full size."""
+    _config_size_case(srs, oracle, 22, compare_oracle=False)

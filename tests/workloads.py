@@ -32,6 +32,31 @@ def sangria_shape(which):
     return dict(field=1, curve=1, gate_T=[5])   # grumpkin circuit over Fq
 
 
+def support_gate(num_selectors=1, num_fixed=4):
+    """The one gate of the CycleFold support circuit (reference src/ivc/cyclefold/support_circuit/tiny_gate.rs:56-82):
+      s * (state0 * state1 * mul + state0 * sum0 + state1 * sum1 + rc - output)
+    1 selector, fixed = (mul, sum0, sum1, rc), advice = (state0, state1, output); k = 15 (support_circuit/mod.rs:68)."""
+    s = X.Polynomial(0)
+    F = lambda i: X.Polynomial(num_selectors + i)
+    A = lambda i: X.Polynomial(num_selectors + num_fixed + i)
+    mul, sum0, sum1, rc = F(0), F(1), F(2), F(3)
+    s0, s1, out = A(0), A(1), A(2)
+    inner = X.Sum(X.Sum(X.Sum(X.Sum(X.Product(X.Product(s0, s1), mul), X.Product(s0, sum0)), X.Product(s1, sum1)), rc), X.Negated(out))
+    return X.Product(s, inner)
+
+
+def make_support_inputs(k, seed):
+    """Synthetic support-circuit structure (grumpkin circuit over Fq): -> dict like make_structure_inputs, plus `selectors`."""
+    rng = np.random.default_rng(seed)
+    rows = 1 << k
+    sel = (rng.random(rows) < 0.8).astype(np.uint8)
+    fixed = [rand_fe(rng, rows, zero_frac=0.5) for _ in range(4)]
+    return dict(field=1, curve=1, k=k, rows=rows, gates=[support_gate()], selectors=[sel], fixed=fixed, num_fixed=4,
+                num_advice=3, W1=trace_like(rng, 3 * rows), W2=trace_like(rng, 3 * rows), E=rand_fe(rng, rows),
+                u1_challenges=rand_fe(rng, 0), u1_u=rand_fe(rng, 1)[0], u2_challenges=rand_fe(rng, 0), r=rand_fe(rng, 1)[0],
+                modulus=MODULUS[1])
+
+
 def gates_for(gate_T):
     nfix = sum(2 * T + 5 for T in gate_T)
     nadv = sum(T + 2 for T in gate_T)
