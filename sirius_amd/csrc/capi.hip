@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <set>
 #include <thread>
@@ -669,16 +670,22 @@ int srs_ck_get_bases(const srs_ck *ck, srs_affine *out) {
 size_t srs_ck_local_len(const srs_ck *ck) { return ck ? (ck->shards.empty() ? ck->key.len : ck->key.global_len) : 0; }
 
 int srs_ck_load_file(int curve, const char *path, size_t k, uint32_t rank, uint32_t world, srs_ck **out) {
-    if (!valid_curve(curve) || !path || !out || k >= 32) return fail(SRS_ERR_INVALID, "srs_ck_load_file: bad argument");
+    if (!valid_curve(curve) || !path || !out) return fail(SRS_ERR_INVALID, "srs_ck_load_file: bad argument");
+    if (k > 27) return fail(SRS_ERR_INVALID, "srs_ck_load_file: key longer than 2^27 bases");      // srs_ck_create's limit, before any allocation
     const size_t len = (size_t)1 << k;
-    std::vector<srs_affine> host(len);
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(SRS_ERR_IO, std::string("srs_ck_load_file: cannot open ") + path);
-    size_t got = std::fread(host.data(), sizeof(srs_affine), len, f);
-    std::fclose(f);
-    if (got != len) return fail(SRS_ERR_IO, "srs_ck_load_file: failed to fill whole buffer");      // read_exact
+    std::vector<srs_affine> host;
+    int rc = guarded([&]() -> int {
+        host.resize(len);
+        FILE *f = std::fopen(path, "rb");
+        if (!f) return fail(SRS_ERR_IO, std::string("srs_ck_load_file: cannot open ") + path);
+        size_t got = std::fread(host.data(), sizeof(srs_affine), len, f);
+        std::fclose(f);
+        if (got != len) return fail(SRS_ERR_IO, "srs_ck_load_file: failed to fill whole buffer");      // read_exact
+        return SRS_OK;
+    });
+    if (rc) return rc;
     srs_ck *ck = nullptr;
-    int rc = srs_ck_create_sharded(curve, host.data(), len, SRS_SPACE_HOST, rank, world, &ck);
+    rc = srs_ck_create_sharded(curve, host.data(), len, SRS_SPACE_HOST, rank, world, &ck);
     if (rc) return rc;
     size_t bad = 0;
     rc = srs_ck_count_off_curve(ck, &bad);
@@ -862,8 +869,20 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
         static const size_t want = [] { const char *e = std::getenv("SRS_COMMIT_CHUNKS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
         size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n >> 20));
         chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
-        size_t per = ((n + chunks - 1) / chunks + 1023) & ~(size_t)1023;
-        chunks = (n + per - 1) / per;
+        // chunk boundaries: equal pieces when a count is forced; by default a SHORT first chunk (its upload is the only one
+        // nothing overlaps) and growing ones after it: 1/12, 1/5, 1/3, rest of the vector
+        std::vector<size_t> cut(1, 0);
+        if (want || chunks < 4) {
+            const size_t per = ((n + chunks - 1) / chunks + 1023) & ~(size_t)1023;
+            for (size_t a = per; a < n; a += per) cut.push_back(a);
+        } else {
+            const double frac[3] = {1.0 / 12, 1.0 / 12 + 1.0 / 5, 1.0 / 12 + 1.0 / 5 + 1.0 / 3};
+            for (double f : frac) cut.push_back(((size_t)(f * (double)n) + 1023) & ~(size_t)1023);
+        }
+        cut.push_back(n);
+        chunks = cut.size() - 1;
+        size_t per = 0;
+        for (size_t j = 0; j < chunks; ++j) per = std::max(per, cut[j + 1] - cut[j]);
         fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
         if (!dst) {
             ck->staging.reserve(Arena::pad(n * sizeof(fe_t)) + 256);
@@ -883,12 +902,12 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
         const fe_t *src = reinterpret_cast<const fe_t *>(scalars_host);
         std::vector<bool> launched(chunks, false);
         auto upload = [&](size_t j) {
-            const size_t a = j * per, len = std::min(per, n - a);
+            const size_t a = cut[j], len = cut[j + 1] - a;
             SRS_HIP_CHECK(hipMemcpyAsync(dst + a, src + a, len * sizeof(fe_t), hipMemcpyHostToDevice, ck->copy_stream));
             SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
         };
         auto launch = [&](size_t j) {
-            const size_t a = j * per, len = std::min(per, n - a);
+            const size_t a = cut[j], len = cut[j + 1] - a;
             SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
             const fe_t *ptr = dst + a;
             const uint32_t nn = (uint32_t)len, base = (uint32_t)a;
@@ -1052,14 +1071,16 @@ public:
         cv_.notify_one();
         return id;
     }
-    // false: unknown (or already waited-for) job
-    bool wait(uint64_t id) {
+    // -1: unknown (or already waited-for) job; otherwise the job's result code (0 = it ran to completion)
+    int wait(uint64_t id, std::string &err) {
         std::unique_lock<std::mutex> lk(mu_);
-        if (!open_.count(id)) return false;
+        if (!open_.count(id)) return -1;
         done_cv_.wait(lk, [&] { return done_.count(id) != 0; });
+        const int rc = done_[id].first;
+        err = done_[id].second;
         done_.erase(id);
         open_.erase(id);
-        return true;
+        return rc;
     }
 
 private:
@@ -1073,16 +1094,27 @@ private:
                 job = std::move(queue_.front());
                 queue_.pop_front();
             }
-            job.second();
+            int rc = SRS_OK;
+            std::string err;
+            try {                                  // an exception must neither escape the detached thread nor leave the job open
+                job.second();
+            } catch (const std::exception &e) {
+                rc = SRS_ERR_DEVICE;
+                err = e.what();
+            } catch (...) {
+                rc = SRS_ERR_DEVICE;
+                err = "unknown exception in an asynchronous job";
+            }
             std::lock_guard<std::mutex> lk(mu_);
-            done_.insert(job.first);
+            done_[job.first] = std::make_pair(rc, err);
             done_cv_.notify_all();
         }
     }
     std::mutex mu_;
     std::condition_variable cv_, done_cv_;
     std::deque<std::pair<uint64_t, std::function<void()>>> queue_;
-    std::set<uint64_t> open_, done_;
+    std::set<uint64_t> open_;
+    std::map<uint64_t, std::pair<int, std::string>> done_;
     uint64_t last_id_ = 0;
 };
 }  // namespace
@@ -1109,7 +1141,10 @@ int srs_point_lincomb_async(int curve, const srs_affine *acc, const srs_affine *
 }
 
 int srs_job_wait(uint64_t job) {
-    if (!AsyncJobs::get().wait(job)) return fail(SRS_ERR_INVALID, "srs_job_wait: unknown job");
+    std::string err;
+    const int rc = AsyncJobs::get().wait(job, err);
+    if (rc < 0) return fail(SRS_ERR_INVALID, "srs_job_wait: unknown job");
+    if (rc) return fail(rc, "srs_job_wait: the job failed: " + err);
     return SRS_OK;
 }
 
@@ -1240,8 +1275,9 @@ static int cross_terms_impl(srs_structure *S, srs_ck *ck, const srs_fe *W1, cons
         }
         std::vector<fe_t *> dT(d);
         for (size_t k = 0; k < d; ++k) dT[k] = own_T ? S->io.take<fe_t>(rows) : reinterpret_cast<fe_t *>(T_out[k]);
-        if (own_T && rowprog::shard_world(s) > 1)        // rows of the other ranks' stripes are not evaluated: hand back zeros, not stale staging
-            for (size_t k = 0; k < d; ++k) SRS_HIP_CHECK(hipMemsetAsync(dT[k], 0, rows * sizeof(fe_t), st));
+        if (rowprog::shard_world(s) > 1)                 // rows of the other ranks' stripes are not evaluated: they read as zero, in the
+            for (size_t k = 0; k < d; ++k)               // library's staging and in caller-provided device vectors alike (the error fold
+                SRS_HIP_CHECK(hipMemsetAsync(dT[k], 0, rows * sizeof(fe_t), st));      // then leaves E unchanged outside the local stripes)
         std::string err;
         // with a key, the batched MSM below runs on the same stream and ends with a synchronisation
         int erc = rowprog::evaluate(s, 0, dW1, dW2, reinterpret_cast<const fe_t *>(challenges), n_challenges, dT.data(), st, err, ck == nullptr);
@@ -1449,6 +1485,9 @@ int srs_is_sat_witness_commit(srs_ck *ck, const srs_fe *const *W, const size_t *
                               size_t *w_mismatch_count, int *e_mismatch) {
     if (!ck || !w_mismatch_count || (n_rounds && (!W || !n || !W_commitments)) || (E && (!E_commitment || !e_mismatch)))
         return fail(SRS_ERR_INVALID, "srs_is_sat_witness_commit: bad argument");
+    if (ck->shards.empty() && ck->key.world > 1)       // a rank's partial sum never equals the full commitment
+        return fail(SRS_ERR_INVALID, "srs_is_sat_witness_commit: key sharded across processes (combine the partial commitments with "
+                                     "srs_point_sum and compare on the caller's side, or use a multi-device key)");
     std::vector<const srs_fe *> v(W, W + n_rounds);
     std::vector<size_t> nn(n, n + n_rounds);
     if (E) { v.push_back(E); nn.push_back(n_E); }

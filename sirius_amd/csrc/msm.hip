@@ -857,7 +857,20 @@ void build_table(Key &k, hipStream_t stream) {
 
 // number of thread-sequential levels after level 0 so that the wavefront-level final pass sees
 // at most ~FINAL_FANIN parts per bucket even if every entry fell into one bucket
+// gathered mixed additions per level-0 thread: 16 for small MSMs (the chip needs every thread it can get), up to 128 for
+// large ones -- each doubling halves the partial sums the later levels have to combine with the dearer full additions
+// (12 * 2^20 trace-like scalars: 1.4 -> 0.5 ms of k_accum1 per commit) while level 0 still launches >= 2^19 threads.
+// SRS_MSM_L0=<log2> forces a value (tests).
+static uint32_t l0_log_for(uint64_t M) {
+    static const int forced = [] { const char *e = std::getenv("SRS_MSM_L0"); return e ? std::atoi(e) : 0; }();
+    if (forced >= 1 && forced <= 7) return (uint32_t)forced;
+    uint32_t lg = ACC_L0_LOG;
+    while (lg < 7 && (M >> (lg + 1)) >= (1ull << 19)) ++lg;
+    return lg;
+}
+
 static int levels_for(uint64_t max_entries) {
+    const uint64_t ACC_L0 = 1ull << l0_log_for(max_entries);
     uint64_t parts = (max_entries + ACC_L0 - 1) / ACC_L0;
     int levels = 1;
     while (parts > FINAL_FANIN && levels < MAX_LEVELS) {
@@ -879,7 +892,7 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     uint64_t M = (uint64_t)n_max * NWIN;
     int levels = levels_for(M);
     size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1) + 4;
-    uint64_t parts0 = M / ACC_L0 + NBUCKET + 1;
+    uint64_t parts0 = (M >> l0_log_for(M)) + NBUCKET + 1;
     uint64_t parts1 = parts0 / ACC_L1 + NBUCKET + 1;
     size_t per = 0;
     per += Arena::pad(M * sizeof(uint16_t));                 // digits
@@ -907,8 +920,9 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     if (n_max == 0) return false;
     const uint64_t M = (uint64_t)n_max * NWIN;
     const int levels = levels_for(M);
+    const uint32_t l0_log = l0_log_for(M);
     const size_t plan_stride = (size_t)(levels + 1) * (NBUCKET + 1) + 4;
-    const uint64_t parts0_cap = M / ACC_L0 + NBUCKET + 1;
+    const uint64_t parts0_cap = (M >> l0_log) + NBUCKET + 1;
     const uint64_t parts1_cap = parts0_cap / ACC_L1 + NBUCKET + 1;
 
     Arena &A = k.arena;
@@ -948,7 +962,7 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
     SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
-               levels, (uint32_t)ACC_L0_LOG, (uint32_t)ACC_L1_LOG);
+               levels, l0_log, (uint32_t)ACC_L1_LOG);
     if (two_pass) {
         const uint32_t T1 = tiles * NWIN;
         SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, plan_stride);
@@ -969,7 +983,7 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
         prof::Scope ps("msm_accum0", stream, units);
         SRS_LAUNCH((k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                    (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride,
-                   (const affine_t *)k.table, ping, (size_t)parts0_cap, (uint32_t)ACC_L0);
+                   (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log);
     }
     xyzz_t *cur = ping, *nxt = pong;
     size_t cur_stride = parts0_cap, nxt_stride = parts1_cap;

@@ -379,3 +379,25 @@ def test_multi_device_key_in_a_prove(srs, oracle):
     t3d, c3d = srs.VanillaFS.commit_cross_terms(ck3, St, w["u1_challenges"], w["u1_u"], dv(w["W1"]), w["u2_challenges"], dv(w["W2"]))
     assert np.array_equal(c1, c3d)
     ck1.close(); ck3.close(); St.close()
+
+
+def test_long_level0_parts_match_oracle(srs, oracle):
+    """Large MSMs give every level-0 thread up to 128 gathered additions (msm.hip l0_log_for); forced here through
+    SRS_MSM_L0 on sizes the oracle can do (read once per process -> subprocesses), skewed and uniform scalars."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O, sirius_amd as S\n"
+        "from conftest import seeded_scalars\n"
+        "for cid, n, kind in ((0, 70000, 'uniform'), (1, 33333, 'trace'), (0, 5, 'uniform')):\n"
+        "    bases = O.make_bases(cid, 4, n); ck = S.CommitmentKey(cid, bases)\n"
+        "    vs = [seeded_scalars(O, cid, n, 9 + j, kind) for j in range(2)]\n"
+        "    for g, v in zip(ck.commit_batch(vs), vs): assert np.array_equal(g, O.msm(cid, v, bases))\n"
+        "print('ok')\n")
+    from conftest import ROOT
+    for l0 in ("5", "7"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0=l0), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (l0, r.stdout[-500:], r.stderr[-1500:])

@@ -209,3 +209,21 @@ def test_emu_bench_harness():
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["config"]["workload"].startswith("cyclefold_poseidon") and line["cpu_baseline"]["kind"] == "port"
+
+
+def test_emu_long_level0_parts():
+    """msm.hip l0_log_for: 64 gathered additions per level-0 thread (the setting of large MSMs), forced on a small one."""
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O, sirius_amd as S\n"
+        "from sirius_amd import _lib\n"
+        "from conftest import seeded_scalars\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "bases = O.make_bases(1, 4, 400); ck = S.CommitmentKey(1, bases)\n"
+        "for kind in ('uniform', 'trace'):\n"
+        "    v = seeded_scalars(O, 1, 400, 9, kind); assert np.array_equal(ck.commit(v), O.msm(1, v, bases))\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0="6"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
