@@ -105,7 +105,11 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_rowprog(DevArgs A) {
 
 template <class F, int ID>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_rowprog_spec(DevArgs A) {
-    spec_kernel_body<F>(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return SpecCall<F, ID>::run(C, row, pt, U); });
+    // sweep form: every column is read once for all points, bodies on the 9 x 29-bit multiplier.  The callers of these kernels
+    // (cross terms, plain gate evaluation) never pass a coefficient table, and the specialised programs have d <= DMAX.
+    sweep_kernel_body<F>(A, [](const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *U, uint32_t nu, fe_t *acc) {
+        SpecCall<F, ID>::sweep(C, row, npts, U, nu, acc);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,6 +226,44 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_spec(PgArgs A) {
     }
 }
 
+// k_pg_leaves_spec in sweep form (compute_G with integer points, evaluate_e): every leaf row is swept ONCE for all P points
+// (its columns are read once, the Lagrange fold advances by one addition per point) and the thread's LPT leaves are summed
+// with the weights of the leaf-index bits it owns,  tot(p) = sum_l w_l leaf_l(p),  w_l = prod_{b in bits(l)} c_(TL + b)
+// (the same 7 products per point as the pairwise combine).  Needs wpts == 1, P <= DMAX + 1 and affine advice leaves.
+template <class F, int ID, uint32_t LPT>
+__global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
+    __shared__ fe_t red[RP_THREADS];
+    __shared__ fe_t acc[(DMAX + 1) * RP_THREADS];
+    __shared__ fe_t tot[(DMAX + 1) * RP_THREADS];
+    __shared__ fe_t wl[LPT];
+    constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
+    const uint32_t gate = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const GateProg G = A.gates[gate];
+    const uint32_t TL = A.tile_log - LPT_LOG;
+    const uint32_t row0 = (tile << A.tile_log) + tid;
+    const fe_t *w = A.weights;
+    if (tid < LPT) {
+        fe_t x = F::one();
+        for (uint32_t b = 0; b < LPT_LOG; ++b)
+            if ((tid >> b) & 1u) x = F::mul(x, w[(size_t)(TL + b) * A.wpts]);
+        wl[tid] = x;
+    }
+    __syncthreads();
+    for (uint32_t l = 0; l < LPT; ++l) {
+        PgSpecCall<F, ID>::sweep(gate, A.ctx, A.compat ? 0u : row0 + (l << TL), A.P, A.utab + G.utab_off, G.n_uniform, acc + tid);
+        const fe_t c = wl[l];
+        for (uint32_t p = 0; p < A.P; ++p) {
+            const fe_t v = acc[p * RP_THREADS + tid];
+            tot[p * RP_THREADS + tid] = l == 0 ? v : F::add(tot[p * RP_THREADS + tid], F::mul(v, c));
+        }
+    }
+    for (uint32_t p = 0; p < A.P; ++p) {
+        weighted_tree<F>(red, tot[p * RP_THREADS + tid], w, A.wpts, TL);
+        if (tid == 0) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = red[0];
+        __syncthreads();
+    }
+}
+
 // compute_F as a POLYNOMIAL tree (no evaluation points, no ifft).  F(X) = sum_i f_i prod_{b in bits(i)} (beta_b + X delta_b)
 // has degree t = log2(#leaves); the reference evaluates it at next_pow2(t + 1) points (one weighted tree per point, t'n
 // multiplies) and interpolates.  The same coefficients come out of ONE tree whose nodes are polynomials:
@@ -244,10 +286,13 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
 #pragma unroll
     for (uint32_t l = 0; l < LPT; ++l) {
         const uint32_t row = A.compat ? 0u : row0 + (l << TL);
-        if constexpr (ID >= 0) v[l] = PgSpecCall<F, (ID >= 0 ? ID : 0)>::run(gate, A.ctx, row, 0, A.utab + G.utab_off);
-        else v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, row, 0, A.utab + G.utab_off);
+        if constexpr (ID >= 0) {                           // sweep form with one point: the 9 x 29-bit multiplier
+            PgSpecCall<F, (ID >= 0 ? ID : 0)>::sweep(gate, A.ctx, row, 1, A.utab + G.utab_off, G.n_uniform, slots + threadIdx.x);
+            v[l] = slots[threadIdx.x];
+        } else {
+            v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, row, 0, A.utab + G.utab_off);
+        }
     }
-    (void)slots;
     fe_t c0[4], c1[4];                                     // bit TL: (v0 + v1 (beta + X delta))
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
@@ -578,6 +623,7 @@ struct FieldOps {   // runtime-dispatched host field arithmetic
     fe_t sub(const fe_t &a, const fe_t &b) const { return field == 0 ? Fr::sub(a, b) : Fq::sub(a, b); }
     fe_t mul(const fe_t &a, const fe_t &b) const { return field == 0 ? Fr::mul(a, b) : Fq::mul(a, b); }
     fe_t neg(const fe_t &a) const { return field == 0 ? Fr::neg(a) : Fq::neg(a); }
+    fe_t halve(const fe_t &a) const { return field == 0 ? Fr::halve(a) : Fq::halve(a); }
     fe_t inv(const fe_t &a) const { return field == 0 ? Fr::inv(a) : Fq::inv(a); }
     fe_t from_u64(uint64_t v) const { return field == 0 ? Fr::from_u64(v) : Fq::from_u64(v); }
     bool is_zero(const fe_t &a) const { return Fr::is_zero(a); }
@@ -774,7 +820,7 @@ struct Val {
     fe_t k;       // known value
 };
 struct UOp {      // uniform program: u[dst] = op(u[a], u[b]);  leaves: constant / challenge
-    int op;       // 0 const, 1 challenge(index), 2 add, 3 sub, 4 mul, 5 neg
+    int op;       // 0 const, 1 challenge(index), 2 add, 3 sub, 4 mul, 5 neg, 6 scaled copy: u[a] * 2^(5 b), b signed (sweep form)
     int a, b;
     fe_t c;
     int64_t chal;
@@ -957,6 +1003,16 @@ struct Program {
     Insn *d_insns = nullptr;
     std::vector<VInsn> vins;        // SSA form (virtual registers), kept for emit_spec_source
     int result_vreg = -1;
+    // "sweep" form (plan_sweep): the expression as a sum of terms coef * body, evaluated for ALL points per column load
+    struct SweepTerm { int node; int coef; int sign; int level; };   // node: vreg, or -(u)-1 for a row-independent term; coef: uniform index (pre-scaled)
+    struct SweepCluster { std::vector<int> terms, body, loads; };     // body / loads: vregs in SSA order
+    std::vector<SweepTerm> sw_terms;
+    std::vector<SweepCluster> sw_clusters;
+    std::vector<int> sw_level;      // per vreg: power of 2^-5 its 9 x 29-bit value carries (field29.cuh: R' = 2^261 vs the ABI's 2^256)
+    std::vector<int> sw_raise;      // [delta] -> uniform index of the raw constant 2^(261 - 5 delta): product with it adds delta levels
+    int sw_one = -1;                // uniform index of 2^261 mod p (the radix' one): product with it folds a lazy value below 2p
+    std::map<std::pair<int, int>, int> sw_uat;   // (uniform index, level) -> index of the copy scaled by 2^(-5 level) (operand of a body addition)
+    bool sweep_ok = false;
     uint64_t fingerprint = 0;       // FNV-1a of the SSA program
     int spec_id = -1;               // index into the ahead-of-time specialised kernels, or -1
 #if !defined(SRS_EMU)
@@ -1007,12 +1063,358 @@ std::string emit_spec_source(const Program &p, const std::string &name, bool sha
     return o;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sweep form.  The straight-line program above evaluates ONE point per pass over the row's columns: d + 1 passes, each
+// re-reading every column from L2 / HBM (profiles/r01_pmc_step_kernels.json: 6.3x the algorithmic bytes).  The sweep form
+// turns the loops inside out: the expression is flattened into a sum of TERMS  coef(pt) * body(row, pt)  -- the linear
+// skeleton (+, -, scaling by row-independent values) is distributed, the coefficients become new entries of the uniform
+// table (host work per call) -- and terms sharing columns form CLUSTERS.  A cluster loads its columns once, then loops
+// over the points: advice leaves are affine in the point (W1 + X W2, or the Lagrange fold (w0 + w1)/2 + X (w0 - w1)/2), so the
+// next point costs one addition per leaf; the per-point accumulators live in LDS.  Bodies run on the 9 x 29-bit
+// multiplier (field29.cuh), whose Montgomery radix 2^261 differs from the ABI's 2^256: a product of two ABI-form values
+// comes out 2^-5 short ("level" + 1).  Levels are tracked statically; the term's final multiplication by its coefficient
+// uses a coefficient pre-scaled by 2^(5 (level + 1)) on the host, which lands every term back in ABI form -- the sum is
+// the same field element as the straight-line program's, canonical, bit for bit.
+// ---------------------------------------------------------------------------------------------
+struct SweepBuilder {
+    Program &p;
+    std::map<std::tuple<int, int, int>, int> cse;          // (op, a, b) -> uniform index, for the entries created here
+    std::vector<int> def;                                  // vreg -> index into p.vins
+    explicit SweepBuilder(Program &prog) : p(prog) {
+        int nv = 0;
+        for (auto &in : p.vins) nv = std::max(nv, in.dst + 1);
+        def.assign(nv, -1);
+        for (size_t i = 0; i < p.vins.size(); ++i) def[p.vins[i].dst] = (int)i;
+    }
+    int uop(int op, int a, int b, const fe_t *c = nullptr) {
+        if (op == 4 && a > b) std::swap(a, b);
+        auto key = std::make_tuple(op, a, b);
+        if (!c) { auto it = cse.find(key); if (it != cse.end()) return it->second; }
+        UOp u{};
+        u.op = op;
+        u.a = a;
+        u.b = b;
+        if (c) u.c = *c;
+        p.uops.push_back(u);
+        const int id = (int)p.uops.size() - 1;
+        if (!c) cse[key] = id;
+        return id;
+    }
+    int u_mul(int a, int b) { return a < 0 ? b : (b < 0 ? a : uop(4, a, b)); }      // -1 = coefficient one
+    int u_scaled(int a, int e) { return e == 0 ? a : uop(6, a, e); }
+    int one = -1;
+    int u_one(const FieldOps &f) {
+        if (one < 0) { fe_t o = f.one(); one = uop(0, 0, 0, &o); }
+        return one;
+    }
+    int two = -1;
+    int u_two(const FieldOps &f) {
+        if (two < 0) { fe_t t = f.add(f.one(), f.one()); two = uop(0, 0, 0, &t); }
+        return two;
+    }
+    bool is_linear_mul(const VInsn &in) const { return in.op == I_MUL && ((in.a < 0) != (in.b < 0)); }
+
+    // distribute the linear skeleton below `x` (operand code) with coefficient `coef` (uniform index or -1) and sign
+    void lin(int x, int coef, int sign, const FieldOps &f, int depth) {
+        if (x < 0) {                                         // row-independent value
+            p.sw_terms.push_back({x, coef, sign, 0});
+            return;
+        }
+        const VInsn &in = p.vins[def[x]];
+        if (depth < 64) {
+            switch (in.op) {
+            case I_ADD: lin(in.a, coef, sign, f, depth + 1); lin(in.b, coef, sign, f, depth + 1); return;
+            case I_SUB: lin(in.a, coef, sign, f, depth + 1); lin(in.b, coef, -sign, f, depth + 1); return;
+            case I_NEG: lin(in.a, coef, -sign, f, depth + 1); return;
+            case I_DBL: lin(in.a, u_mul(coef, u_two(f)), sign, f, depth + 1); return;
+            case I_MUL:
+                if (is_linear_mul(in)) {
+                    const int u = in.a < 0 ? -in.a - 1 : -in.b - 1, v = in.a < 0 ? in.b : in.a;
+                    lin(v, u_mul(coef, u), sign, f, depth + 1);
+                    return;
+                }
+                break;
+            default: break;
+            }
+        }
+        p.sw_terms.push_back({x, coef, sign, 0});
+    }
+    // level of a body value; uniform operands of body additions are re-scaled on the host, so they never raise a level
+    int level_of(int v) {
+        if (p.sw_level[v] >= 0) return p.sw_level[v];
+        const VInsn &in = p.vins[def[v]];
+        int l = 0;
+        auto lv = [&](int x) { return x < 0 ? 0 : level_of(x); };
+        switch (in.op) {
+        case I_LD_SEL: case I_LD_FIX: case I_LD_ADV: l = 0; break;
+        case I_MUL: l = lv(in.a) + lv(in.b) + 1; break;
+        case I_SQR: l = 2 * lv(in.a) + 1; break;
+        case I_ADD: case I_SUB: l = std::max(lv(in.a), lv(in.b)); break;
+        default: l = lv(in.a); break;
+        }
+        return p.sw_level[v] = l;
+    }
+    void collect(int v, std::vector<char> &seen, std::vector<int> &body, std::vector<int> &loads) {
+        if (v < 0 || seen[v]) return;
+        seen[v] = 1;
+        const VInsn &in = p.vins[def[v]];
+        if (in.op <= I_LD_ADV) { loads.push_back(v); return; }
+        collect(in.a, seen, body, loads);
+        if (in.op <= I_MUL) collect(in.b, seen, body, loads);
+        body.push_back(v);
+    }
+};
+
+// registers a cluster may spend on hoisted column values: an advice leaf is (value, step) = 16 VGPRs, a fixed one 8
+static constexpr int SWEEP_LOAD_BUDGET = 112;
+
+static void plan_sweep(Program &p, const FieldOps &f) {
+    p.sweep_ok = false;
+    p.sw_terms.clear();
+    p.sw_clusters.clear();
+    if (p.result_vreg < 0 || p.vins.empty() || std::getenv("SRS_NO_SWEEP")) return;
+    SweepBuilder B(p);
+    B.lin(p.result_vreg, -1, +1, f, 0);
+    if (p.sw_terms.empty() || p.sw_terms.size() > 4096) { p.sw_terms.clear(); return; }
+    p.sw_level.assign(B.def.size(), -1);
+    for (auto &t : p.sw_terms) {
+        t.level = t.node < 0 ? 0 : B.level_of(t.node);
+        if (t.level > 40) { p.sw_terms.clear(); return; }
+        if (t.node < 0) {                                    // constant term: fold the coefficient into one ABI-form entry
+            t.coef = B.u_mul(t.coef, -t.node - 1);
+        } else {                                             // coef * 2^(5 (level + 1)): the closing product returns to ABI form
+            t.coef = B.u_scaled(t.coef < 0 ? B.u_one(f) : t.coef, t.level + 1);
+        }
+    }
+    // helper constants of the 2^261-radix bodies
+    int max_level = 0;
+    for (int l : p.sw_level) max_level = std::max(max_level, l);
+    p.sw_one = B.u_scaled(B.u_one(f), 1);
+    p.sw_raise.assign(max_level + 1, -1);
+    for (int d = 1; d <= max_level; ++d) p.sw_raise[d] = B.u_scaled(B.u_one(f), 1 - d);
+    p.sw_uat.clear();
+    for (size_t i = 0; i < p.vins.size(); ++i) {            // uniform operands of body additions at level > 0
+        const VInsn &in = p.vins[i];
+        if ((in.op != I_ADD && in.op != I_SUB) || p.sw_level[in.dst] <= 0) continue;
+        for (int x : {in.a, in.b})
+            if (x < 0) p.sw_uat[{-x - 1, p.sw_level[in.dst]}] = B.u_scaled(-x - 1, -p.sw_level[in.dst]);
+    }
+    // clusters: terms in expression order; a term joins the open cluster while the hoisted columns fit the budget
+    const size_t nv = B.def.size();
+    std::vector<char> in_cluster(nv, 0);
+    Program::SweepCluster cur;
+    int cost = 0;
+    auto load_cost = [&](int v) { return p.vins[B.def[v]].op == I_LD_ADV ? 16 : 8; };
+    auto flush = [&]() {
+        if (cur.terms.empty()) return;
+        std::sort(cur.body.begin(), cur.body.end());
+        std::sort(cur.loads.begin(), cur.loads.end());
+        p.sw_clusters.push_back(cur);
+        cur = Program::SweepCluster();
+        cost = 0;
+        std::fill(in_cluster.begin(), in_cluster.end(), 0);
+    };
+    for (size_t ti = 0; ti < p.sw_terms.size(); ++ti) {
+        const auto &t = p.sw_terms[ti];
+        if (t.node < 0) { cur.terms.push_back((int)ti); continue; }
+        std::vector<char> seen(nv, 0);
+        std::vector<int> body, loads;
+        B.collect(t.node, seen, body, loads);
+        int extra = 0;
+        for (int v : loads) if (!in_cluster[v]) extra += load_cost(v);
+        if (!cur.terms.empty() && cost + extra > SWEEP_LOAD_BUDGET) flush();
+        for (int v : loads) if (!in_cluster[v]) { in_cluster[v] = 1; cur.loads.push_back(v); cost += load_cost(v); }
+        for (int v : body) if (!in_cluster[v]) { in_cluster[v] = 1; cur.body.push_back(v); }
+        cur.terms.push_back((int)ti);
+    }
+    flush();
+    p.sweep_ok = !p.sw_clusters.empty();
+}
+
+// the sweep form as C++: NAME(C, row, npts, Uall, nu, acc) leaves P(pt) in acc[pt * RP_THREADS], pt < npts
+std::string emit_sweep_source(const Program &p, const std::string &name, bool shared_mul) {
+    std::string o;
+    if (!p.sweep_ok) return o;
+    // shared_mul: one multiplier body per kernel (mul29_ni / sqr29_ni, rowprog_dev.cuh) -- the run-time compiled form, see emit_spec_source
+    const std::string MUL = shared_mul ? "mul29_ni<F>(" : "G::mul(", SQR = shared_mul ? "sqr29_ni<F>(" : "G::sqr(";
+    std::vector<int> def;
+    {
+        int nv = 0;
+        for (auto &in : p.vins) nv = std::max(nv, in.dst + 1);
+        def.assign(nv, -1);
+        for (size_t i = 0; i < p.vins.size(); ++i) def[p.vins[i].dst] = (int)i;
+    }
+    auto S = [](int x) { return std::to_string(x); };
+    // uniform entries the bodies need in a re-scaled form are added by plan_sweep only for coefficients; an addition of a
+    // row value of level l and a uniform value is emitted with a run-time multiplication-free trick: the uniform operand is
+    // multiplied by the level-raising constant like any other lower-level operand (rare: constants inside products).
+    o += "template <class F>\n__device__ __forceinline__ void " + name +
+         "(const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *__restrict__ Uall, uint32_t nu, fe_t *__restrict__ acc) {\n";
+    o += "    using G = Fp29<typename F::Params>;\n    const uint32_t mask = C.rows - 1; (void)mask;\n";
+    bool first = true;
+    for (size_t ci = 0; ci < p.sw_clusters.size(); ++ci) {
+        const auto &cl = p.sw_clusters[ci];
+        o += "    {   // cluster " + S((int)ci) + "\n";
+        for (int v : cl.loads) {
+            const VInsn &in = p.vins[def[v]];
+            const std::string rr = "(row + " + std::to_string((uint32_t)in.b) + "u) & mask";
+            if (in.op == I_LD_SEL) o += "        const fe_t l" + S(v) + " = ld_sel<F>(C, " + S(in.a) + ", " + rr + ");\n";
+            else if (in.op == I_LD_FIX) o += "        const fe_t l" + S(v) + " = ld_fix<F>(C, " + S(in.a) + ", " + rr + ");\n";
+            else o += "        fe_t l" + S(v) + ", s" + S(v) + "; adv_affine<F>(C, " + S(in.a) + ", " + rr + ", l" + S(v) + ", s" + S(v) + ");\n";
+        }
+        o += "        for (uint32_t pt = 0; pt < npts; ++pt) {\n";
+        o += "            const fe_t *__restrict__ U = Uall + (size_t)pt * nu; (void)U;\n";
+        std::map<int, double> bound;                           // static bound of a value in units of p (normalised limbs)
+        auto bnd = [&](int x) { return x >= 0 ? bound[x] : 1.0; };
+        auto lvl = [&](int x) { return x >= 0 ? p.sw_level[x] : 0; };
+        std::vector<char> is_load(def.size(), 0);            // column values are unpacked where they are used: a 9-limb copy of
+        for (int v : cl.loads) { is_load[v] = 1; bound[v] = 1.0; }   // every hoisted column, live across the loop body, spills
+        int tmp = 0;
+        // operand x at `level` with a bound <= max_bound: the expression text; b_out = its bound
+        auto prep = [&](int x, int level, double max_bound, double &b_out) -> std::string {
+            if (x < 0) {                                         // row-independent operand: the host keeps a copy at every level needed
+                b_out = 1.0;
+                const int u = -x - 1;
+                if (level <= 0) return "G::unpack(U[" + S(u) + "])";
+                auto it = p.sw_uat.find({u, level});
+                return "G::unpack(U[" + S(it == p.sw_uat.end() ? u : it->second) + "])";
+            }
+            std::string e = is_load[x] ? "G::unpack(l" + S(x) + ")" : "x" + S(x);
+            double b = bnd(x);
+            if (lvl(x) < level) {                                // product with the raw constant 2^(261 - 5 delta): + delta levels
+                const std::string t = "r" + S(tmp++);
+                o += "            const f29_t " + t + " = " + MUL + e + ", G::unpack(U[" + S(p.sw_raise[level - lvl(x)]) + "]));\n";
+                e = t;
+                b = 2.0;
+            }
+            if (b > max_bound) {                                 // product with 2^261 mod p: the same value, below 2p again
+                const std::string t = "r" + S(tmp++);
+                o += "            const f29_t " + t + " = " + MUL + e + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
+                e = t;
+                b = 2.0;
+            }
+            b_out = b;
+            return e;
+        };
+        for (int v : cl.body) {
+            const VInsn &in = p.vins[def[v]];
+            const std::string d = "            const f29_t x" + S(v) + " = ";
+            double ba, bb;
+            switch (in.op) {
+            case I_MUL: {
+                std::string a = prep(in.a, lvl(in.a), 12.0, ba), b = prep(in.b, lvl(in.b), 12.0, bb);      // a uniform operand enters at level 0
+                o += d + MUL + a + ", " + b + ");\n";
+                bound[v] = 2.0;
+                break;
+            }
+            case I_SQR: {
+                std::string a = prep(in.a, lvl(in.a), 12.0, ba);
+                o += d + SQR + a + ");\n";
+                bound[v] = 2.0;
+                break;
+            }
+            case I_ADD: {
+                const int L = p.sw_level[v];
+                std::string a = prep(in.a, L, 30.0, ba), b = prep(in.b, L, 30.0, bb);
+                o += d + "G::normalize(G::add_lazy(" + a + ", " + b + "));\n";
+                bound[v] = ba + bb;
+                break;
+            }
+            case I_SUB: {
+                const int L = p.sw_level[v];
+                std::string a = prep(in.a, L, 30.0, ba), b = prep(in.b, L, 30.0, bb);
+                const int cp = (int)bb + 1;
+                o += d + "G::normalize(G::template sub_lazy<" + S(cp) + ", 0>(" + a + ", " + b + "));\n";
+                bound[v] = ba + cp;
+                break;
+            }
+            case I_DBL: {
+                std::string a = prep(in.a, lvl(in.a), 30.0, ba);
+                o += d + "G::normalize(G::add_lazy(" + a + ", " + a + "));\n";
+                bound[v] = 2 * ba;
+                break;
+            }
+            default: {
+                std::string a = prep(in.a, lvl(in.a), 30.0, ba);
+                const int cp = (int)ba + 1;
+                o += d + "G::normalize(G::template neg_lazy<" + S(cp) + ", 0>(" + a + "));\n";
+                bound[v] = cp;
+                break;
+            }
+            }
+        }
+        // the terms: terms sharing a coefficient are summed first (lazily, 9 x 29), then ONE closing product with the pre-scaled
+        // coefficient per group -> ABI form, canonical; the groups are summed in 8 x 32
+        bool have = false;
+        std::vector<int> order;                                  // coefficient groups in first-appearance order
+        std::map<int, std::vector<int>> groups;
+        for (int ti : cl.terms) {
+            const auto &t = p.sw_terms[ti];
+            const int key = t.node < 0 ? -1 - ti : t.coef;       // constant terms stay alone
+            if (!groups.count(key)) order.push_back(key);
+            groups[key].push_back(ti);
+        }
+        for (int key : order) {
+            const auto &g = groups[key];
+            std::string val;
+            bool negate = false;
+            if (p.sw_terms[g[0]].node < 0) {
+                val = "U[" + S(p.sw_terms[g[0]].coef) + "]";
+                negate = p.sw_terms[g[0]].sign < 0;
+            } else {
+                // all terms of a group share the coefficient, hence the level (the scale 2^(5 (level + 1)) is part of the entry)
+                double b;
+                std::string sum = prep(p.sw_terms[g[0]].node, lvl(p.sw_terms[g[0]].node), 12.0, b);
+                negate = p.sw_terms[g[0]].sign < 0;              // the group is accumulated as +-(first +- ...)
+                for (size_t j = 1; j < g.size(); ++j) {
+                    const auto &t = p.sw_terms[g[j]];
+                    double bj;
+                    std::string e = prep(t.node, lvl(t.node), 12.0, bj);
+                    const bool minus = (t.sign < 0) != negate;
+                    const std::string r = "r" + S(tmp++);
+                    if (minus) {
+                        const int cp = (int)bj + 1;
+                        o += "            const f29_t " + r + " = G::normalize(G::template sub_lazy<" + S(cp) + ", 0>(" + sum + ", " + e + "));\n";
+                        b += cp;
+                    } else {
+                        o += "            const f29_t " + r + " = G::normalize(G::add_lazy(" + sum + ", " + e + "));\n";
+                        b += bj;
+                    }
+                    sum = r;
+                    if (b > 12.0) {
+                        const std::string r2 = "r" + S(tmp++);
+                        o += "            const f29_t " + r2 + " = " + MUL + sum + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
+                        sum = r2;
+                        b = 2.0;
+                    }
+                }
+                val = "G::to_canonical_fe(" + MUL + sum + ", G::unpack(U[" + S(p.sw_terms[g[0]].coef) + "])))";
+            }
+            if (!have) o += std::string("            fe_t t = ") + (negate ? "F::neg(" + val + ")" : val) + ";\n";
+            else o += std::string("            t = ") + (negate ? "F::sub(t, " : "F::add(t, ") + val + ");\n";
+            have = true;
+        }
+        o += first ? "            acc[pt * RP_THREADS] = t;\n" : "            acc[pt * RP_THREADS] = F::add(acc[pt * RP_THREADS], t);\n";
+        for (int v : cl.loads)
+            if (p.vins[def[v]].op == I_LD_ADV) o += "            l" + S(v) + " = F::add(l" + S(v) + ", s" + S(v) + ");\n";
+        o += "        }\n    }\n";
+        first = false;
+    }
+    o += "}\n";
+    return o;
+}
+
 #if !defined(SRS_EMU)
 // the translation unit hiprtc compiles: the emitted program `jit_fn` wrapped in the kernel body the ahead-of-time kernels use
-static std::string jit_translation_unit(const std::string &fn_source, int field) {
-    const char *fname = field == 0 ? "Fr" : "Fq";
+static std::string jit_translation_unit(const std::string &fn_source, int field, bool has_sweep = false) {
+    const std::string fname = field == 0 ? "Fr" : "Fq";
+    std::string body;
+    if (has_sweep)      // same choice as k_rowprog_spec: sweep form whenever the advice leaves are affine in the point
+        body = "    if (A.ctx.wcoef == nullptr && A.npts <= DMAX + 1) {\n        sweep_kernel_body<" + fname +
+               ">(A, [](const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *U, uint32_t nu, fe_t *acc) { jit_fn_sweep<" + fname +
+               ">(C, row, npts, U, nu, acc); });\n        return;\n    }\n";
     return "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" + fn_source +
-           "extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n    spec_kernel_body<" + fname +
+           "extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n" + body + "    spec_kernel_body<" + fname +
            ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname + ">(C, row, pt, U); });\n}\n}\n}\n";
 }
 
@@ -1028,10 +1430,24 @@ bool jit_selfcheck(size_t *code_bytes, std::string &log) {
         "    const fe_t v3 = mul_ni<F>(v0, v1);\n"
         "    const fe_t v4 = sqr_ni<F>(v3);\n"
         "    const fe_t v5 = F::mul(U[0], v2);\n"
-        "    return F::sub(F::add(v4, v5), F::dbl(F::neg(v1)));\n}\n";
+        "    return F::sub(F::add(v4, v5), F::dbl(F::neg(v1)));\n}\n"
+        // and one in sweep form: affine advice leaf, called 9 x 29-bit multipliers, lazy add / sub, closing product
+        "template <class F>\n__device__ __forceinline__ void jit_fn_sweep(const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *__restrict__ Uall, "
+        "uint32_t nu, fe_t *__restrict__ acc) {\n"
+        "    using G = Fp29<typename F::Params>;\n    const uint32_t mask = C.rows - 1;\n"
+        "    const fe_t l0 = ld_fix<F>(C, 0, (row + 0u) & mask);\n"
+        "    fe_t l1, s1; adv_affine<F>(C, 0, (row + 1u) & mask, l1, s1);\n"
+        "    for (uint32_t pt = 0; pt < npts; ++pt) {\n"
+        "        const fe_t *__restrict__ U = Uall + (size_t)pt * nu;\n"
+        "        const f29_t x0 = G::unpack(l0), x1 = G::unpack(l1);\n"
+        "        const f29_t x2 = mul29_ni<F>(x0, x1);\n"
+        "        const f29_t x3 = sqr29_ni<F>(x2);\n"
+        "        const f29_t x4 = G::normalize(G::template sub_lazy<3, 0>(G::normalize(G::add_lazy(x3, x2)), x3));\n"
+        "        acc[pt * RP_THREADS] = G::to_canonical_fe(G::mul(x4, G::unpack(U[0])));\n"
+        "        l1 = F::add(l1, s1);\n    }\n}\n";
     for (int field = 0; field < 2; ++field) {
         size_t bytes = 0;
-        if (!jit::compile_only(jit_translation_unit(fn, field), &bytes, log)) return false;
+        if (!jit::compile_only(jit_translation_unit(fn, field, true), &bytes, log)) return false;
         if (code_bytes) *code_bytes = bytes;
     }
     return true;
@@ -1084,6 +1500,7 @@ static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx
     for (size_t i = 0; i < sizeof(kSpecs) / sizeof(kSpecs[0]); ++i)
         if (kSpecs[i].fingerprint == p.fingerprint && kSpecs[i].id >= 0) p.spec_id = kSpecs[i].id;
     if (std::getenv("SRS_NO_SPEC")) p.spec_id = -1;
+    plan_sweep(p, f);               // appends coefficient entries to p.uops (the fingerprint above is that of the plain program)
     if (std::getenv("SRS_DEBUG_ROWPROG")) {
         int cnt[9] = {0};
         for (auto &in : p.insns) cnt[in.op]++;
@@ -1189,7 +1606,9 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     //      rows on (one hiprtc compile ~ a second); single-pass degrees only (the kernel body parks d + 1 <= 9 points).
     if (S->cross.spec_id < 0 && S->degree >= 1 && S->degree <= DMAX && !S->cross.insns.empty() && jit::enabled() &&
         (k >= 14 || std::getenv("SRS_JIT_ALWAYS"))) {
-        const std::string src = jit_translation_unit(emit_spec_source(S->cross, "jit_fn", std::getenv("SRS_JIT_INLINE_MUL") == nullptr), field);
+        const bool shared = std::getenv("SRS_JIT_INLINE_MUL") == nullptr;
+        const std::string src = jit_translation_unit(emit_spec_source(S->cross, "jit_fn", shared) + emit_sweep_source(S->cross, "jit_fn_sweep", shared),
+                                                     field, S->cross.sweep_ok);
         std::string log;
         if (!jit::compile(src, "srs_jit_rowprog", S->cross.jit, log) && std::getenv("SRS_DEBUG_ROWPROG"))
             std::fprintf(stderr, "rowprog: hiprtc compile failed, staying on the interpreter:\n%s\n", log.c_str());
@@ -1285,6 +1704,12 @@ static bool eval_uniform(const Program &p, const FieldOps &f, const fe_t *ch, si
         case 2: out[i] = f.add(out[u.a], out[u.b]); break;
         case 3: out[i] = f.sub(out[u.a], out[u.b]); break;
         case 4: out[i] = f.mul(out[u.a], out[u.b]); break;
+        case 6: {                                     // u[a] * 2^(5 b): operands of the 2^261-radix multiplier (sweep form)
+            fe_t x = out[u.a];
+            for (int k = 0; k < 5 * (u.b < 0 ? -u.b : u.b); ++k) x = u.b < 0 ? f.halve(x) : f.add(x, x);
+            out[i] = x;
+            break;
+        }
         default: out[i] = f.neg(out[u.a]); break;
         }
     }
@@ -1317,6 +1742,7 @@ const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spe
     if (which >= 3 && (size_t)(which - 3) >= S->gate_progs.size()) { buf.clear(); return buf.c_str(); }
     Program &p = which >= 3 ? S->gate_progs[which - 3] : (which == 0 ? S->cross : (which == 1 ? S->plain_compressed : S->plain_homogeneous));
     buf = emit_spec_source(p, "spec_fn", false);   // ahead-of-time generation: inlined multipliers
+    buf += emit_sweep_source(p, "spec_fn_sweep", false);  // empty when the program has no sweep form
     if (fingerprint) *fingerprint = p.fingerprint;
     if (spec_id) *spec_id = p.spec_id;
 #if !defined(SRS_EMU)
@@ -1688,7 +2114,9 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     a.partial = buf0;
     {
         prof::Scope ps(mode == 0 ? "pg_F_leaves" : (mode == 1 ? "pg_G_leaves" : "pg_e_leaves"), st, S->rows * n_gates);
-        if (S->pg_spec_id >= 0 && lpt == 8) launch_pg_spec(S->pg_spec_id, a, tiles_per_gate, n_gates, tile, st);
+        if (S->pg_spec_id >= 0 && lpt == 8)
+            launch_pg_spec(S->pg_spec_id, a, tiles_per_gate, n_gates, tile, st,
+                           wpts == 1 && P <= DMAX + 1 && a.ctx.wcoef == nullptr && !std::getenv("SRS_NO_SWEEP"));
         else if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, lpt, st);

@@ -2,6 +2,7 @@
 // compiled at run time with hiprtc (jit.hip embeds this file verbatim: keep it free of host-only includes).
 #pragma once
 #include "field.cuh"
+#include "field29.cuh"
 #if defined(SRS_EMU)
 #include "hipemu.h"   // CPU logic emulator (tests/emu)
 #endif
@@ -70,6 +71,11 @@ __device__ __attribute__((noinline)) fe_t mul_ni(fe_t a, fe_t b) { return F::mul
 template <class F>
 __device__ __attribute__((noinline)) fe_t sqr_ni(fe_t a) { return F::sqr(a); }
 
+template <class F>
+__device__ __attribute__((noinline)) f29_t mul29_ni(f29_t a, f29_t b) { return Fp29<typename F::Params>::mul(a, b); }
+template <class F>
+__device__ __attribute__((noinline)) f29_t sqr29_ni(f29_t a) { return Fp29<typename F::Params>::sqr(a); }
+
 // column loads (PlonkEvalDomain::eval_column_var / eval_advice_var, src/plonk/eval.rs:57-69,153-228)
 template <class F>
 __device__ __forceinline__ fe_t ld_sel(const RowCtx &C, uint32_t col, uint32_t rr) { return C.sel[col][rr] ? F::one() : F::zero(); }
@@ -92,6 +98,25 @@ __device__ __forceinline__ fe_t ld_adv(const RowCtx &C, uint32_t col, uint32_t r
     fe_t r = F::mul(cf[0], C.W[0][idx]);
     for (uint32_t j = 1; j < C.J; ++j) r = F::add(r, F::mul(cf[j], C.W[j][idx]));
     return r;
+}
+
+// sweep form (rowprog.hip, emit_sweep_source): an advice leaf as an affine function of the evaluation point,
+// value(pt) = cur + pt * step.  Only for the point sets without a coefficient table (C.wcoef == nullptr):
+//   J == 1: the witness itself;  J == 2: W[0] + pt W[1] (cross terms);  J == 2, half: the Lagrange fold at integer points.
+template <class F>
+__device__ __forceinline__ void adv_affine(const RowCtx &C, uint32_t col, uint32_t rr, fe_t &cur, fe_t &step) {
+    const size_t idx = (size_t)col * C.rows + rr;
+    cur = C.W[0][idx];
+    step = F::zero();
+    if (C.J == 2) {
+        const fe_t w1 = C.W[1][idx];
+        if (C.half) {
+            step = F::halve(F::sub(cur, w1));
+            cur = F::halve(F::add(cur, w1));
+        } else {
+            step = w1;
+        }
+    }
 }
 
 constexpr uint32_t ROW_STRIPE_LOG = 10;   // == msm::STRIPE_LOG: rows and key entries are sharded alike
@@ -133,6 +158,25 @@ __device__ __forceinline__ void spec_kernel_body(const DevArgs &A, Eval eval) {
             for (uint32_t pt = 0; pt < A.npts; ++pt) T = F::add(T, F::mul(A.vinv[k * A.npts + pt], Pv[pt * RP_THREADS + threadIdx.x]));
             A.out[k][row] = T;
         }
+    }
+}
+
+// The same kernel body for a program in sweep form: `sweep(ctx, row, npts, utab, nu, acc)` leaves P(pt) in acc[pt * RP_THREADS].
+template <class F, class Sweep>
+__device__ __forceinline__ void sweep_kernel_body(const DevArgs &A, Sweep sweep) {
+    __shared__ fe_t Pv[(DMAX + 1) * RP_THREADS];
+    bool live;
+    const uint32_t row = shard_row(A.ctx, blockIdx.x * RP_THREADS + threadIdx.x, live);
+    sweep(A.ctx, row, A.npts, A.utab, A.n_uniform, Pv + threadIdx.x);
+    if (!live) return;
+    if (A.d == 0) {
+        A.out[0][row] = Pv[threadIdx.x];
+        return;
+    }
+    for (uint32_t k = 0; k < A.d; ++k) {
+        fe_t T = F::zero();
+        for (uint32_t pt = 0; pt < A.npts; ++pt) T = F::add(T, F::mul(A.vinv[k * A.npts + pt], Pv[pt * RP_THREADS + threadIdx.x]));
+        A.out[k][row] = T;
     }
 }
 
