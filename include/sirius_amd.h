@@ -127,6 +127,19 @@ int srs_commit_batch(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, 
 int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *dev_copy, int repr, void *stream,
                       srs_affine *out);
 
+/* util::concatenate_with_padding (src/util/mod.rs:214-218) into HBM: out = for every column its `lens[c]` elements followed by
+ * zeros up to `pad_size` (a column longer than the pad is kept whole), columns back to back; srs_concat_len = the length of
+ * that vector.  The columns are host vectors (the advice columns CircuitRunner::try_collect_witness leaves behind,
+ * src/table/circuit_runner.rs:71-107), the result is device memory: the host never builds the concatenated copy.
+ * srs_commit_upload_columns = `ck.commit(&concatenate_with_padding(advice, 2^k))` of run_sps_protocol_* (src/plonk/mod.rs:441-447)
+ * in one call: groups of columns go up while the MSM of the previous group runs; dev_copy (srs_concat_len elements, or NULL)
+ * receives the assembled witness for the prover calls that follow. */
+size_t srs_concat_len(const size_t *lens, size_t n_columns, size_t pad_size);
+int srs_concat_with_padding(srs_fe *out_dev, const srs_fe *const *columns_host, const size_t *lens, size_t n_columns, size_t pad_size,
+                            void *stream);
+int srs_commit_upload_columns(srs_ck *ck, const srs_fe *const *columns_host, const size_t *lens, size_t n_columns, size_t pad_size,
+                              srs_fe *dev_copy, int repr, void *stream, srs_affine *out);
+
 /* ---- one process, several GPUs (`srs_ck_create(.., n_devices, ..)`) ----
  * The Rust IVC driver is a single process (src/ivc/sangria/incrementally_verifiable_computation.rs:429), so the library
  * itself spreads a key over `n_devices` GPUs (0 = all visible): device d keeps the block-cyclic stripes s % n_devices == d

@@ -10,7 +10,7 @@ or torch uint64/int64 CUDA tensors of the same shape for data already resident i
 """
 from . import _lib
 from ._lib import (CURVE_BN256, CURVE_GRUMPKIN, FIELD_FQ, FIELD_FR, SiriusAmdError)  # noqa: F401
-from .commitment import CommitmentKey, HostBuffer, PendingPoint, TooLongInput, point_lincomb, point_lincomb_async, point_mul, point_sum  # noqa: F401
+from .commitment import CommitmentKey, HostBuffer, PendingPoint, concatenate_with_padding, TooLongInput, point_lincomb, point_lincomb_async, point_mul, point_sum  # noqa: F401
 from . import fft  # noqa: F401,E402
 from . import distributed, expression, field, plonk, poseidon, protogalaxy  # noqa: F401,E402
 from .poseidon import PoseidonHash  # noqa: F401,E402

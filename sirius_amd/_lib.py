@@ -40,6 +40,9 @@ def _prototypes():
         "srs_upload": (i32, [vp, vp, sz, vp]),
         "srs_download": (i32, [vp, vp, sz, vp]),
         "srs_commit_upload": (i32, [vp, vp, sz, vp, i32, vp, vp]),
+        "srs_concat_len": (sz, [C.POINTER(sz), sz, sz]),
+        "srs_concat_with_padding": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, vp]),
+        "srs_commit_upload_columns": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, sz, vp, i32, vp, vp]),
         "srs_ck_create_multi": (i32, [i32, vp, sz, i32, i32, C.POINTER(vp)]),
         "srs_ck_setup_synthetic_multi": (i32, [i32, sz, C.c_uint64, i32, C.POINTER(vp)]),
         "srs_ck_num_shards": (i32, [vp]),

@@ -186,6 +186,24 @@ class CommitmentKey:
         L.check(L.lib().srs_commit_upload(self._h, a.ctypes.data, n, dptr, repr, _stream(), out.ctypes.data))
         return out
 
+    def commit_upload_columns(self, columns, pad_size, dev_copy=None, repr=L.REPR_MONT):
+        """`ck.commit(&concatenate_with_padding(advice, pad_size))` (run_sps_protocol_*, src/plonk/mod.rs:441-447) straight from
+        the per-column host vectors: the concatenated, zero-padded witness is assembled in HBM (srs_commit_upload_columns),
+        groups of columns go up while the MSM of the previous group runs.  dev_copy: torch tensor of concat_len elements."""
+        cols = [np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 4) for c in columns]
+        lens = (C.c_size_t * max(len(cols), 1))(*[c.shape[0] for c in cols])
+        ptrs = (C.c_void_p * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+        n = L.lib().srs_concat_len(lens, len(cols), pad_size)
+        if n > self._len:
+            raise TooLongInput(n, self._len)
+        dptr = None
+        if dev_copy is not None:
+            assert _is_torch(dev_copy) and dev_copy.is_contiguous() and dev_copy.numel() == 4 * n
+            dptr = dev_copy.data_ptr()
+        out = np.zeros(8, dtype=np.uint64)
+        L.check(L.lib().srs_commit_upload_columns(self._h, ptrs, lens, len(cols), pad_size, dptr, repr, _stream(), out.ctypes.data))
+        return out
+
     def commit_batch(self, vs, repr=L.REPR_MONT):
         """[commit(v) for v in vs] in one set of launches (cross-term commits, sangria/mod.rs:151-154)."""
         bufs = [_buf(v, 4) for v in vs]
@@ -285,3 +303,15 @@ class HostBuffer:
             self.close()
         except Exception:
             pass
+
+
+def concatenate_with_padding(columns, pad_size, out):
+    """`util::concatenate_with_padding` (src/util/mod.rs:214-218) from host columns into the device vector `out`
+    (torch tensor of concat_len elements; host memory under the CPU emulator)."""
+    cols = [np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 4) for c in columns]
+    lens = (C.c_size_t * max(len(cols), 1))(*[c.shape[0] for c in cols])
+    ptrs = (C.c_void_p * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+    n = L.lib().srs_concat_len(lens, len(cols), pad_size)
+    assert out.numel() == 4 * n and out.is_contiguous()
+    L.check(L.lib().srs_concat_with_padding(out.data_ptr(), ptrs, lens, len(cols), pad_size, _stream()))
+    return out

@@ -843,6 +843,100 @@ int srs_commit(srs_ck *ck, const srs_fe *scalars, size_t n, int space, int repr,
     return srs_commit_batch(ck, v, nn, 1, space, repr, stream, out);
 }
 
+namespace {
+// a piece of the vector being committed: `len` elements from host memory land at element offset `off`; whatever lies between
+// pieces is zero (the padding of util::concatenate_with_padding)
+struct Seg {
+    const fe_t *src;
+    size_t off, len;
+};
+
+// uploads dst[a, b) = pieces + zero padding, on stream `cs`
+void upload_range(fe_t *dst, const std::vector<Seg> &segs, size_t a, size_t b, hipStream_t cs) {
+    size_t at = a;
+    for (const Seg &sg : segs) {
+        const size_t lo = std::max(a, sg.off), hi = std::min(b, sg.off + sg.len);
+        if (lo >= hi) continue;
+        if (lo > at) SRS_HIP_CHECK(hipMemsetAsync(dst + at, 0, (lo - at) * sizeof(fe_t), cs));
+        SRS_HIP_CHECK(hipMemcpyAsync(dst + lo, sg.src + (lo - sg.off), (hi - lo) * sizeof(fe_t), hipMemcpyHostToDevice, cs));
+        at = hi;
+    }
+    if (b > at) SRS_HIP_CHECK(hipMemsetAsync(dst + at, 0, (b - at) * sizeof(fe_t), cs));
+}
+
+// the streamed commit of srs_commit_upload / srs_commit_upload_columns (single-device key): chunk j goes up on the key's copy
+// stream while the MSM of chunk j - 1 runs on the caller's stream; `cuts` = chunk boundaries (element offsets, first 0, last n)
+int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const std::vector<size_t> &cut, fe_t *dst, int repr,
+                    hipStream_t st, srs_affine *out) {
+    const size_t chunks = cut.size() - 1;
+    size_t per = 0;
+    for (size_t j = 0; j < chunks; ++j) per = std::max(per, cut[j + 1] - cut[j]);
+    if (!ck->copy_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->copy_stream, hipStreamNonBlocking));
+    while (ck->events.size() < chunks + 1) {
+        hipEvent_t e;
+        SRS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ck->events.push_back(e);
+    }
+    msm::reserve(ck->key, (uint32_t)per, 1);
+    // the copy stream must not overwrite dst while earlier work on the caller's stream still reads it
+    SRS_HIP_CHECK(hipEventRecord(ck->events[chunks], st));
+    SRS_HIP_CHECK(hipStreamWaitEvent(ck->copy_stream, ck->events[chunks], 0));
+    std::vector<bool> launched(chunks, false);
+    auto upload = [&](size_t j) {
+        upload_range(dst, segs, cut[j], cut[j + 1], ck->copy_stream);
+        SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
+    };
+    auto launch = [&](size_t j) {
+        SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
+        const fe_t *ptr = dst + cut[j];
+        const uint32_t nn = (uint32_t)(cut[j + 1] - cut[j]), base = (uint32_t)cut[j];
+        launched[j] = msm::enqueue(ck->key, &ptr, &nn, &base, 1, repr == SRS_REPR_MONT, st, (uint32_t)j);
+    };
+    // a pageable source makes hipMemcpyAsync block the caller: issue upload j+1 before MSM j so both are in flight either way
+    upload(0);
+    for (size_t j = 0; j < chunks; ++j) {
+        if (j + 1 < chunks) upload(j + 1);
+        launch(j);
+    }
+    SRS_HIP_CHECK(hipStreamSynchronize(st));
+    SRS_HIP_CHECK(hipGetLastError());
+    auto go = [&](auto tag) {
+        using C = decltype(tag);
+        xyzz_t acc = Ec<C>::identity(), part;
+        for (size_t j = 0; j < chunks; ++j) {
+            msm::finish(ck->key, 1, (uint32_t)j, launched[j], &part);
+            acc = Ec<C>::add(acc, part);
+        }
+        affine_t a = Ec<C>::to_affine(acc);
+        std::memcpy(out, &a, sizeof(a));
+    };
+    if (ck->key.curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
+    prof::collect();
+    return SRS_OK;
+}
+
+// chunk boundaries of a streamed commit of n elements; `align`: boundaries are multiples of it (columns are never split)
+std::vector<size_t> commit_cuts(size_t n, size_t align) {
+    static const size_t want = [] { const char *e = std::getenv("SRS_COMMIT_CHUNKS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
+    size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n >> 20));
+    chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
+    auto up = [&](size_t x) { return std::min(n, (x + align - 1) / align * align); };
+    std::vector<size_t> cut(1, 0);
+    if (want || chunks < 4) {            // equal pieces
+        const size_t per = up((n + chunks - 1) / chunks);
+        for (size_t a = per; a < n; a += per) cut.push_back(a);
+    } else {                             // a SHORT first chunk (its upload is the only one nothing overlaps), growing ones after it
+        const double frac[3] = {1.0 / 12, 1.0 / 12 + 1.0 / 5, 1.0 / 12 + 1.0 / 5 + 1.0 / 3};
+        for (double f : frac) {
+            const size_t c = up((size_t)(f * (double)n));
+            if (c > cut.back() && c < n) cut.push_back(c);
+        }
+    }
+    cut.push_back(n);
+    return cut;
+}
+}  // namespace
+
 int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *dev_copy, int repr, void *stream, srs_affine *out) {
     if (!ck || !out || (n && !scalars_host)) return fail(SRS_ERR_INVALID, "srs_commit_upload: bad argument");
     if (n > ck->key.global_len)
@@ -865,75 +959,77 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
         return srs_commit(ck, scalars_host, n, SRS_SPACE_HOST, repr, stream, out);
     }
     return guarded([&]() -> int {
-        // chunks: a few large pieces (every MSM has a fixed tail of ~0.5 ms), stripe-aligned
-        static const size_t want = [] { const char *e = std::getenv("SRS_COMMIT_CHUNKS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
-        size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n >> 20));
-        chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
-        // chunk boundaries: equal pieces when a count is forced; by default a SHORT first chunk (its upload is the only one
-        // nothing overlaps) and growing ones after it: 1/12, 1/5, 1/3, rest of the vector
-        std::vector<size_t> cut(1, 0);
-        if (want || chunks < 4) {
-            const size_t per = ((n + chunks - 1) / chunks + 1023) & ~(size_t)1023;
-            for (size_t a = per; a < n; a += per) cut.push_back(a);
-        } else {
-            const double frac[3] = {1.0 / 12, 1.0 / 12 + 1.0 / 5, 1.0 / 12 + 1.0 / 5 + 1.0 / 3};
-            for (double f : frac) cut.push_back(((size_t)(f * (double)n) + 1023) & ~(size_t)1023);
-        }
-        cut.push_back(n);
-        chunks = cut.size() - 1;
-        size_t per = 0;
-        for (size_t j = 0; j < chunks; ++j) per = std::max(per, cut[j + 1] - cut[j]);
         fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
         if (!dst) {
             ck->staging.reserve(Arena::pad(n * sizeof(fe_t)) + 256);
             ck->staging.reset();
             dst = ck->staging.take<fe_t>(n);
         }
-        if (!ck->copy_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->copy_stream, hipStreamNonBlocking));
-        while (ck->events.size() < chunks + 1) {
-            hipEvent_t e;
-            SRS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ck->events.push_back(e);
+        std::vector<Seg> segs(1, Seg{reinterpret_cast<const fe_t *>(scalars_host), 0, n});
+        return commit_streamed(ck, segs, n, commit_cuts(n, 1024), dst, repr, st, out);
+    });
+}
+
+size_t srs_concat_len(const size_t *lens, size_t n_columns, size_t pad_size) {
+    size_t total = 0;
+    for (size_t c = 0; c < n_columns; ++c) total += std::max(lens ? lens[c] : 0, pad_size);
+    return total;
+}
+
+int srs_concat_with_padding(srs_fe *out_dev, const srs_fe *const *columns_host, const size_t *lens, size_t n_columns, size_t pad_size,
+                            void *stream) {
+    if ((n_columns && (!columns_host || !lens)) || (srs_concat_len(lens, n_columns, pad_size) && !out_dev))
+        return fail(SRS_ERR_INVALID, "srs_concat_with_padding: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        std::vector<Seg> segs;
+        size_t off = 0;
+        for (size_t c = 0; c < n_columns; ++c) {
+            if (lens[c] && !columns_host[c]) return fail(SRS_ERR_INVALID, "srs_concat_with_padding: null column");
+            segs.push_back(Seg{reinterpret_cast<const fe_t *>(columns_host[c]), off, lens[c]});
+            off += std::max(lens[c], pad_size);
         }
-        msm::reserve(ck->key, (uint32_t)per, 1);
-        // the copy stream must not overwrite dst while earlier work on the caller's stream still reads it
-        SRS_HIP_CHECK(hipEventRecord(ck->events[chunks], st));
-        SRS_HIP_CHECK(hipStreamWaitEvent(ck->copy_stream, ck->events[chunks], 0));
-        const fe_t *src = reinterpret_cast<const fe_t *>(scalars_host);
-        std::vector<bool> launched(chunks, false);
-        auto upload = [&](size_t j) {
-            const size_t a = cut[j], len = cut[j + 1] - a;
-            SRS_HIP_CHECK(hipMemcpyAsync(dst + a, src + a, len * sizeof(fe_t), hipMemcpyHostToDevice, ck->copy_stream));
-            SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
-        };
-        auto launch = [&](size_t j) {
-            const size_t a = cut[j], len = cut[j + 1] - a;
-            SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
-            const fe_t *ptr = dst + a;
-            const uint32_t nn = (uint32_t)len, base = (uint32_t)a;
-            launched[j] = msm::enqueue(ck->key, &ptr, &nn, &base, 1, repr == SRS_REPR_MONT, st, (uint32_t)j);
-        };
-        // a pageable source makes hipMemcpyAsync block the caller: issue upload j+1 before MSM j so both are in flight either way
-        upload(0);
-        for (size_t j = 0; j < chunks; ++j) {
-            if (j + 1 < chunks) upload(j + 1);
-            launch(j);
-        }
-        SRS_HIP_CHECK(hipStreamSynchronize(st));
-        SRS_HIP_CHECK(hipGetLastError());
-        auto go = [&](auto tag) {
-            using C = decltype(tag);
-            xyzz_t acc = Ec<C>::identity(), part;
-            for (size_t j = 0; j < chunks; ++j) {
-                msm::finish(ck->key, 1, (uint32_t)j, launched[j], &part);
-                acc = Ec<C>::add(acc, part);
-            }
-            affine_t a = Ec<C>::to_affine(acc);
-            std::memcpy(out, &a, sizeof(a));
-        };
-        if (ck->key.curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
-        prof::collect();
+        upload_range(reinterpret_cast<fe_t *>(out_dev), segs, 0, off, (hipStream_t)stream);
         return SRS_OK;
+    });
+}
+
+int srs_commit_upload_columns(srs_ck *ck, const srs_fe *const *columns_host, const size_t *lens, size_t n_columns, size_t pad_size,
+                              srs_fe *dev_copy, int repr, void *stream, srs_affine *out) {
+    if (!ck || !out || (n_columns && (!columns_host || !lens))) return fail(SRS_ERR_INVALID, "srs_commit_upload_columns: bad argument");
+    const size_t n = srs_concat_len(lens, n_columns, pad_size);
+    if (n > ck->key.global_len)
+        return fail(SRS_ERR_TOO_LONG_INPUT, "Can't commit too long input: input len: " + std::to_string(n) + ", but limit is " +
+                                                std::to_string(ck->key.global_len));
+    for (size_t c = 0; c < n_columns; ++c)
+        if (lens[c] && !columns_host[c]) return fail(SRS_ERR_INVALID, "srs_commit_upload_columns: null column");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return guarded([&]() -> int {
+        std::vector<Seg> segs;
+        size_t off = 0;
+        bool uniform = true;                 // every column no longer than the pad: chunk boundaries fall between columns
+        for (size_t c = 0; c < n_columns; ++c) {
+            segs.push_back(Seg{reinterpret_cast<const fe_t *>(columns_host[c]), off, lens[c]});
+            uniform = uniform && lens[c] <= pad_size;
+            off += std::max(lens[c], pad_size);
+        }
+        fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
+        const bool streamed = ck->shards.empty() && ck->key.world == 1 && n != 0;
+        if (!dst) {
+            ck->staging.reserve(Arena::pad((n + 1) * sizeof(fe_t)) + 256);
+            ck->staging.reset();
+            dst = ck->staging.take<fe_t>(n + 1);
+        }
+        if (!streamed) {                     // multi-device / sharded keys: assemble in HBM, then the ordinary commit
+            upload_range(dst, segs, 0, n, st);
+            return srs_commit(ck, reinterpret_cast<const srs_fe *>(dst), n, SRS_SPACE_DEVICE, repr, stream, out);
+        }
+        const size_t align = (uniform && pad_size >= 1024) ? pad_size : 1024;
+        std::vector<size_t> cut = commit_cuts(n, align);
+        return commit_streamed(ck, segs, n, cut, dst, repr, st, out);
     });
 }
 

@@ -1501,6 +1501,7 @@ static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx
         if (kSpecs[i].fingerprint == p.fingerprint && kSpecs[i].id >= 0) p.spec_id = kSpecs[i].id;
     if (std::getenv("SRS_NO_SPEC")) p.spec_id = -1;
     plan_sweep(p, f);               // appends coefficient entries to p.uops (the fingerprint above is that of the plain program)
+    if (!p.sweep_ok) p.spec_id = -1;   // the ahead-of-time kernels ARE the sweep form (SRS_NO_SWEEP: interpreter / point-by-point)
     if (std::getenv("SRS_DEBUG_ROWPROG")) {
         int cnt[9] = {0};
         for (auto &in : p.insns) cnt[in.op]++;
@@ -1592,6 +1593,7 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         if ((size_t)kPgSpecs[e].n_gates != S->gate_progs.size()) continue;
         bool same = true;
         for (size_t g = 0; g < S->gate_progs.size(); ++g) same = same && kPgSpecs[e].fp[g] == S->gate_progs[g].fingerprint;
+        for (size_t g = 0; g < S->gate_progs.size(); ++g) same = same && S->gate_progs[g].sweep_ok;      // the leaf kernels use the sweep form
         if (same && !std::getenv("SRS_NO_SPEC")) S->pg_spec_id = kPgSpecs[e].id;
     }
     // lookup / table polynomials see the advice COLUMNS only (LookupEvalDomain, src/plonk/eval.rs:106-134)
