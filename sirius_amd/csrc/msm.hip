@@ -857,15 +857,16 @@ void build_table(Key &k, hipStream_t stream) {
 
 // number of thread-sequential levels after level 0 so that the wavefront-level final pass sees
 // at most ~FINAL_FANIN parts per bucket even if every entry fell into one bucket
-// gathered mixed additions per level-0 thread: 16 for small MSMs (the chip needs every thread it can get), up to 128 for
-// large ones -- each doubling halves the partial sums the later levels have to combine with the dearer full additions
-// (12 * 2^20 trace-like scalars: 1.4 -> 0.5 ms of k_accum1 per commit) while level 0 still launches >= 2^19 threads.
-// SRS_MSM_L0=<log2> forces a value (tests).
+// gathered mixed additions per level-0 thread.  Two losses pull in opposite directions: every part leaves a partial sum the
+// later levels combine with the dearer full additions (+ 1.4 / L0 of the level-0 work), and the launch ends with a
+// partly filled last wave of workgroups (the chip holds 2^18 level-0 threads at a time: + ~0.5 / waves, waves = entries /
+// (L0 * 2^18)).  16 is best up to ~10 M scalars (measured on the chunks of a 12 * 2^20 commit: 64 cost 0.9 ms more in
+// k_accum0 than it saved in k_accum1), 32 above, 64 from ~40 M.  SRS_MSM_L0=<log2> forces a value (tests).
 static uint32_t l0_log_for(uint64_t M) {
     static const int forced = [] { const char *e = std::getenv("SRS_MSM_L0"); return e ? std::atoi(e) : 0; }();
     if (forced >= 1 && forced <= 7) return (uint32_t)forced;
     uint32_t lg = ACC_L0_LOG;
-    while (lg < 7 && (M >> (lg + 1)) >= (1ull << 19)) ++lg;
+    while (lg < 7 && (M >> (lg + 1)) >= (5ull << 20)) ++lg;
     return lg;
 }
 

@@ -107,8 +107,8 @@ template <class F, int ID>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_rowprog_spec(DevArgs A) {
     // sweep form: every column is read once for all points, bodies on the 9 x 29-bit multiplier.  The callers of these kernels
     // (cross terms, plain gate evaluation) never pass a coefficient table, and the specialised programs have d <= DMAX.
-    sweep_kernel_body<F>(A, [](const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *U, uint32_t nu, fe_t *acc) {
-        SpecCall<F, ID>::sweep(C, row, npts, U, nu, acc);
+    sweep_kernel_body<F>(A, SpecCall<F, ID>::one(), [](const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *U, uint32_t nu, uint32_t *acc, bool accumulate) {
+        SpecCall<F, ID>::sweep(C, row, npts, U, nu, acc, accumulate);
     });
 }
 
@@ -227,38 +227,29 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_spec(PgArgs A) {
 }
 
 // k_pg_leaves_spec in sweep form (compute_G with integer points, evaluate_e): every leaf row is swept ONCE for all P points
-// (its columns are read once, the Lagrange fold advances by one addition per point) and the thread's LPT leaves are summed
-// with the weights of the leaf-index bits it owns,  tot(p) = sum_l w_l leaf_l(p),  w_l = prod_{b in bits(l)} c_(TL + b)
-// (the same 7 products per point as the pairwise combine).  Needs wpts == 1, P <= DMAX + 1 and affine advice leaves.
+// (its columns are read once, the Lagrange fold advances by one addition per point).  The thread's LPT leaves need the weights
+// w_l = prod_{b in bits(l)} c_(TL + b) of the leaf-index bits it owns: the host multiplies the term coefficients of the
+// uniform table by w_l (one table per l, A.utab = [gate][l][P][nu]), so leaf l simply ACCUMULATES onto the same lazy 9 x 29-bit
+// sums in LDS; between leaves the sums are folded below 2p.  Needs wpts == 1, P <= DMAX + 1 and affine advice leaves.
 template <class F, int ID, uint32_t LPT>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     __shared__ fe_t red[RP_THREADS];
-    __shared__ fe_t acc[(DMAX + 1) * RP_THREADS];
-    __shared__ fe_t tot[(DMAX + 1) * RP_THREADS];
-    __shared__ fe_t wl[LPT];
+    __shared__ uint32_t acc_all[(DMAX + 1) * SW_WORDS * RP_THREADS];
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const GateProg G = A.gates[gate];
     const uint32_t TL = A.tile_log - LPT_LOG;
     const uint32_t row0 = (tile << A.tile_log) + tid;
-    const fe_t *w = A.weights;
-    if (tid < LPT) {
-        fe_t x = F::one();
-        for (uint32_t b = 0; b < LPT_LOG; ++b)
-            if ((tid >> b) & 1u) x = F::mul(x, w[(size_t)(TL + b) * A.wpts]);
-        wl[tid] = x;
-    }
-    __syncthreads();
+    uint32_t *acc = acc_all + tid;
+    const fe_t *U0 = A.utab + G.utab_off;
+    const fe_t one261 = U0[PgSpecCall<F, ID>::one(gate)];
     for (uint32_t l = 0; l < LPT; ++l) {
-        PgSpecCall<F, ID>::sweep(gate, A.ctx, A.compat ? 0u : row0 + (l << TL), A.P, A.utab + G.utab_off, G.n_uniform, acc + tid);
-        const fe_t c = wl[l];
-        for (uint32_t p = 0; p < A.P; ++p) {
-            const fe_t v = acc[p * RP_THREADS + tid];
-            tot[p * RP_THREADS + tid] = l == 0 ? v : F::add(tot[p * RP_THREADS + tid], F::mul(v, c));
-        }
+        PgSpecCall<F, ID>::sweep(gate, A.ctx, A.compat ? 0u : row0 + (l << TL), A.P, U0 + (size_t)l * A.P * G.n_uniform, G.n_uniform, acc, l != 0);
+        if (l + 1 < LPT)
+            for (uint32_t p = 0; p < A.P; ++p) sw_fold<F>(acc, p, one261);
     }
     for (uint32_t p = 0; p < A.P; ++p) {
-        weighted_tree<F>(red, tot[p * RP_THREADS + tid], w, A.wpts, TL);
+        weighted_tree<F>(red, sw_finish<F>(acc, p, one261), A.weights, A.wpts, TL);
         if (tid == 0) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = red[0];
         __syncthreads();
     }
@@ -287,8 +278,10 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
     for (uint32_t l = 0; l < LPT; ++l) {
         const uint32_t row = A.compat ? 0u : row0 + (l << TL);
         if constexpr (ID >= 0) {                           // sweep form with one point: the 9 x 29-bit multiplier
-            PgSpecCall<F, (ID >= 0 ? ID : 0)>::sweep(gate, A.ctx, row, 1, A.utab + G.utab_off, G.n_uniform, slots + threadIdx.x);
-            v[l] = slots[threadIdx.x];
+            using PC = PgSpecCall<F, (ID >= 0 ? ID : 0)>;
+            uint32_t *acc = reinterpret_cast<uint32_t *>(slots) + threadIdx.x;      // NSLOT >= 2: 9 words per thread fit
+            PC::sweep(gate, A.ctx, row, 1, A.utab + G.utab_off, G.n_uniform, acc, false);
+            v[l] = sw_finish<F>(acc, 0, (A.utab + G.utab_off)[PC::one(gate)]);
         } else {
             v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, row, 0, A.utab + G.utab_off);
         }
@@ -1011,6 +1004,7 @@ struct Program {
     std::vector<int> sw_level;      // per vreg: power of 2^-5 its 9 x 29-bit value carries (field29.cuh: R' = 2^261 vs the ABI's 2^256)
     std::vector<int> sw_raise;      // [delta] -> uniform index of the raw constant 2^(261 - 5 delta): product with it adds delta levels
     int sw_one = -1;                // uniform index of 2^261 mod p (the radix' one): product with it folds a lazy value below 2p
+    std::vector<int> sw_coef;       // the uniform entries that are term coefficients (dedicated entries: ProtoGalaxy scales them by the leaf weight)
     std::map<std::pair<int, int>, int> sw_uat;   // (uniform index, level) -> index of the copy scaled by 2^(-5 level) (operand of a body addition)
     bool sweep_ok = false;
     uint64_t fingerprint = 0;       // FNV-1a of the SSA program
@@ -1180,16 +1174,24 @@ static void plan_sweep(Program &p, const FieldOps &f) {
     for (auto &t : p.sw_terms) {
         t.level = t.node < 0 ? 0 : B.level_of(t.node);
         if (t.level > 40) { p.sw_terms.clear(); return; }
-        if (t.node < 0) {                                    // constant term: fold the coefficient into one ABI-form entry
-            t.coef = B.u_mul(t.coef, -t.node - 1);
+        if (t.node < 0) {                                    // constant term: coefficient * value, a dedicated ABI-form entry
+            t.coef = B.uop(6, B.u_mul(t.coef, -t.node - 1), 0);
         } else {                                             // coef * 2^(5 (level + 1)): the closing product returns to ABI form
             t.coef = B.u_scaled(t.coef < 0 ? B.u_one(f) : t.coef, t.level + 1);
         }
     }
+    p.sw_coef.clear();
+    for (auto &t : p.sw_terms) p.sw_coef.push_back(t.coef);
+    std::sort(p.sw_coef.begin(), p.sw_coef.end());
+    p.sw_coef.erase(std::unique(p.sw_coef.begin(), p.sw_coef.end()), p.sw_coef.end());
     // helper constants of the 2^261-radix bodies
     int max_level = 0;
     for (int l : p.sw_level) max_level = std::max(max_level, l);
-    p.sw_one = B.u_scaled(B.u_one(f), 1);
+    {                                                        // a constant of its own (never shared with a coefficient entry)
+        fe_t c = f.one();
+        for (int k = 0; k < 5; ++k) c = f.add(c, c);
+        p.sw_one = B.uop(0, 0, 0, &c);
+    }
     p.sw_raise.assign(max_level + 1, -1);
     for (int d = 1; d <= max_level; ++d) p.sw_raise[d] = B.u_scaled(B.u_one(f), 1 - d);
     p.sw_uat.clear();
@@ -1231,7 +1233,7 @@ static void plan_sweep(Program &p, const FieldOps &f) {
     p.sweep_ok = !p.sw_clusters.empty();
 }
 
-// the sweep form as C++: NAME(C, row, npts, Uall, nu, acc) leaves P(pt) in acc[pt * RP_THREADS], pt < npts
+// the sweep form as C++ (see the comment on the signature below)
 std::string emit_sweep_source(const Program &p, const std::string &name, bool shared_mul) {
     std::string o;
     if (!p.sweep_ok) return o;
@@ -1248,10 +1250,15 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
     // uniform entries the bodies need in a re-scaled form are added by plan_sweep only for coefficients; an addition of a
     // row value of level l and a uniform value is emitted with a run-time multiplication-free trick: the uniform operand is
     // multiplied by the level-raising constant like any other lower-level operand (rare: constants inside products).
+    // NAME(C, row, npts, Uall, nu, acc, accumulate): adds (accumulate) or stores the LAZY 9 x 29-bit sum P(pt) * 2^256 + small
+    // multiples of p into the thread's limb-planar LDS accumulators (sw_load / sw_store, rowprog_dev.cuh); NAME_one<F>() = the
+    // uniform index of 2^261 mod p, with which the caller folds (sw_fold) and finishes (sw_finish) them.
+    o += "template <class F> __device__ constexpr uint32_t " + name + "_one() { return " + S(p.sw_one) + "u; }\n";
     o += "template <class F>\n__device__ __forceinline__ void " + name +
-         "(const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *__restrict__ Uall, uint32_t nu, fe_t *__restrict__ acc) {\n";
+         "(const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *__restrict__ Uall, uint32_t nu, uint32_t *__restrict__ acc, bool accumulate) {\n";
     o += "    using G = Fp29<typename F::Params>;\n    const uint32_t mask = C.rows - 1; (void)mask;\n";
     bool first = true;
+    double acc_bound = 2.0;                                      // an accumulator handed in by the caller is folded: < 2p
     for (size_t ci = 0; ci < p.sw_clusters.size(); ++ci) {
         const auto &cl = p.sw_clusters[ci];
         o += "    {   // cluster " + S((int)ci) + "\n";
@@ -1343,58 +1350,83 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
             }
             }
         }
-        // the terms: terms sharing a coefficient are summed first (lazily, 9 x 29), then ONE closing product with the pre-scaled
-        // coefficient per group -> ABI form, canonical; the groups are summed in 8 x 32
-        bool have = false;
+        // the terms: terms sharing a coefficient are summed first, then ONE closing product with the pre-scaled coefficient per
+        // group -> ABI form; everything stays lazy (sums of values < 2p, normalised limbs) down to the accumulator in LDS
         std::vector<int> order;                                  // coefficient groups in first-appearance order
         std::map<int, std::vector<int>> groups;
         for (int ti : cl.terms) {
             const auto &t = p.sw_terms[ti];
-            const int key = t.node < 0 ? -1 - ti : t.coef;       // constant terms stay alone
-            if (!groups.count(key)) order.push_back(key);
-            groups[key].push_back(ti);
+            if (!groups.count(t.coef)) order.push_back(t.coef);
+            groups[t.coef].push_back(ti);
         }
+        std::string total;
+        double total_b = 0;
+        auto lazy_add = [&](std::string &sum, double &b, const std::string &e, double be, bool minus) {
+            const std::string r = "r" + S(tmp++);
+            if (sum.empty()) {
+                if (minus) {
+                    const int cp = (int)be + 1;
+                    o += "            const f29_t " + r + " = G::normalize(G::template neg_lazy<" + S(cp) + ", 0>(" + e + "));\n";
+                    b = cp;
+                } else {
+                    sum = e;
+                    b = be;
+                    return;
+                }
+            } else if (minus) {
+                const int cp = (int)be + 1;
+                o += "            const f29_t " + r + " = G::normalize(G::template sub_lazy<" + S(cp) + ", 0>(" + sum + ", " + e + "));\n";
+                b += cp;
+            } else {
+                o += "            const f29_t " + r + " = G::normalize(G::add_lazy(" + sum + ", " + e + "));\n";
+                b += be;
+            }
+            sum = r;
+        };
+        auto fold = [&](std::string &sum, double &b, double limit) {
+            if (b <= limit) return;
+            const std::string r = "r" + S(tmp++);
+            o += "            const f29_t " + r + " = " + MUL + sum + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
+            sum = r;
+            b = 2.0;
+        };
         for (int key : order) {
             const auto &g = groups[key];
+            const auto &t0 = p.sw_terms[g[0]];
             std::string val;
-            bool negate = false;
-            if (p.sw_terms[g[0]].node < 0) {
-                val = "U[" + S(p.sw_terms[g[0]].coef) + "]";
-                negate = p.sw_terms[g[0]].sign < 0;
+            bool negate = t0.sign < 0;                           // the group enters the cluster sum as +-(first +- ...)
+            double vb = 1.0;
+            if (t0.node < 0) {
+                val = "G::unpack(U[" + S(t0.coef) + "])";        // constant term (ABI form, canonical)
             } else {
                 // all terms of a group share the coefficient, hence the level (the scale 2^(5 (level + 1)) is part of the entry)
-                double b;
-                std::string sum = prep(p.sw_terms[g[0]].node, lvl(p.sw_terms[g[0]].node), 12.0, b);
-                negate = p.sw_terms[g[0]].sign < 0;              // the group is accumulated as +-(first +- ...)
-                for (size_t j = 1; j < g.size(); ++j) {
+                std::string sum;
+                double b = 0;
+                for (size_t j = 0; j < g.size(); ++j) {
                     const auto &t = p.sw_terms[g[j]];
                     double bj;
                     std::string e = prep(t.node, lvl(t.node), 12.0, bj);
-                    const bool minus = (t.sign < 0) != negate;
-                    const std::string r = "r" + S(tmp++);
-                    if (minus) {
-                        const int cp = (int)bj + 1;
-                        o += "            const f29_t " + r + " = G::normalize(G::template sub_lazy<" + S(cp) + ", 0>(" + sum + ", " + e + "));\n";
-                        b += cp;
-                    } else {
-                        o += "            const f29_t " + r + " = G::normalize(G::add_lazy(" + sum + ", " + e + "));\n";
-                        b += bj;
-                    }
-                    sum = r;
-                    if (b > 12.0) {
-                        const std::string r2 = "r" + S(tmp++);
-                        o += "            const f29_t " + r2 + " = " + MUL + sum + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
-                        sum = r2;
-                        b = 2.0;
-                    }
+                    lazy_add(sum, b, e, bj, (t.sign < 0) != negate);
+                    fold(sum, b, 12.0);
                 }
-                val = "G::to_canonical_fe(" + MUL + sum + ", G::unpack(U[" + S(p.sw_terms[g[0]].coef) + "])))";
+                const std::string r = "r" + S(tmp++);
+                o += "            const f29_t " + r + " = " + MUL + sum + ", G::unpack(U[" + S(t0.coef) + "]));\n";
+                val = r;
+                vb = 2.0;
             }
-            if (!have) o += std::string("            fe_t t = ") + (negate ? "F::neg(" + val + ")" : val) + ";\n";
-            else o += std::string("            t = ") + (negate ? "F::sub(t, " : "F::add(t, ") + val + ");\n";
-            have = true;
+            lazy_add(total, total_b, val, vb, negate);
+            fold(total, total_b, 24.0);
         }
-        o += first ? "            acc[pt * RP_THREADS] = t;\n" : "            acc[pt * RP_THREADS] = F::add(acc[pt * RP_THREADS], t);\n";
+        if (first) {
+            o += "            sw_store(acc, pt, accumulate ? G::normalize(G::add_lazy(sw_load(acc, pt), " + total + ")) : " + total + ");\n";
+        } else {
+            o += "            sw_store(acc, pt, G::normalize(G::add_lazy(sw_load(acc, pt), " + total + ")));\n";
+        }
+        acc_bound += total_b;
+        if (acc_bound > 100.0) {                                 // fold the accumulators before they outgrow the 261-bit limbs
+            o += "            sw_store(acc, pt, " + MUL + "sw_load(acc, pt), G::unpack(U[" + S(p.sw_one) + "])));\n";
+            acc_bound = 2.0;
+        }
         for (int v : cl.loads)
             if (p.vins[def[v]].op == I_LD_ADV) o += "            l" + S(v) + " = F::add(l" + S(v) + ", s" + S(v) + ");\n";
         o += "        }\n    }\n";
@@ -1411,8 +1443,8 @@ static std::string jit_translation_unit(const std::string &fn_source, int field,
     std::string body;
     if (has_sweep)      // same choice as k_rowprog_spec: sweep form whenever the advice leaves are affine in the point
         body = "    if (A.ctx.wcoef == nullptr && A.npts <= DMAX + 1) {\n        sweep_kernel_body<" + fname +
-               ">(A, [](const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *U, uint32_t nu, fe_t *acc) { jit_fn_sweep<" + fname +
-               ">(C, row, npts, U, nu, acc); });\n        return;\n    }\n";
+               ">(A, jit_fn_sweep_one<" + fname + ">(), [](const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *U, uint32_t nu, uint32_t *acc, "
+               "bool accumulate) { jit_fn_sweep<" + fname + ">(C, row, npts, U, nu, acc, accumulate); });\n        return;\n    }\n";
     return "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" + fn_source +
            "extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n" + body + "    spec_kernel_body<" + fname +
            ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname + ">(C, row, pt, U); });\n}\n}\n}\n";
@@ -1432,8 +1464,9 @@ bool jit_selfcheck(size_t *code_bytes, std::string &log) {
         "    const fe_t v5 = F::mul(U[0], v2);\n"
         "    return F::sub(F::add(v4, v5), F::dbl(F::neg(v1)));\n}\n"
         // and one in sweep form: affine advice leaf, called 9 x 29-bit multipliers, lazy add / sub, closing product
+        "template <class F> __device__ constexpr uint32_t jit_fn_sweep_one() { return 1u; }\n"
         "template <class F>\n__device__ __forceinline__ void jit_fn_sweep(const RowCtx &C, uint32_t row, uint32_t npts, const fe_t *__restrict__ Uall, "
-        "uint32_t nu, fe_t *__restrict__ acc) {\n"
+        "uint32_t nu, uint32_t *__restrict__ acc, bool accumulate) {\n"
         "    using G = Fp29<typename F::Params>;\n    const uint32_t mask = C.rows - 1;\n"
         "    const fe_t l0 = ld_fix<F>(C, 0, (row + 0u) & mask);\n"
         "    fe_t l1, s1; adv_affine<F>(C, 0, (row + 1u) & mask, l1, s1);\n"
@@ -1443,7 +1476,8 @@ bool jit_selfcheck(size_t *code_bytes, std::string &log) {
         "        const f29_t x2 = mul29_ni<F>(x0, x1);\n"
         "        const f29_t x3 = sqr29_ni<F>(x2);\n"
         "        const f29_t x4 = G::normalize(G::template sub_lazy<3, 0>(G::normalize(G::add_lazy(x3, x2)), x3));\n"
-        "        acc[pt * RP_THREADS] = G::to_canonical_fe(G::mul(x4, G::unpack(U[0])));\n"
+        "        const f29_t x5 = G::mul(x4, G::unpack(U[0]));\n"
+        "        sw_store(acc, pt, accumulate ? G::normalize(G::add_lazy(sw_load(acc, pt), x5)) : x5);\n"
         "        l1 = F::add(l1, s1);\n    }\n}\n";
     for (int field = 0; field < 2; ++field) {
         size_t bytes = 0;
@@ -1476,7 +1510,7 @@ struct Structure {
     uint8_t **d_sel_ptrs = nullptr;
     fe_t **d_fix_ptrs = nullptr;
     std::vector<void *> owned;
-    fe_t *d_vinv = nullptr;
+    fe_t *d_vinv = nullptr, *d_vinv29 = nullptr;
     Arena arena;
     std::vector<uint8_t> host_stage;   // source of the per-call staging copy (must outlive the asynchronous copy)
     uint32_t shard_rank = 0, shard_world = 1;   // cross terms: evaluate only this rank's row stripes (set_shard)
@@ -1629,6 +1663,12 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         SRS_HIP_CHECK(hipMalloc((void **)&S->d_vinv, S->vinv.size() * sizeof(fe_t)));
         S->owned.push_back(S->d_vinv);
         SRS_HIP_CHECK(hipMemcpy(S->d_vinv, S->vinv.data(), S->vinv.size() * sizeof(fe_t), hipMemcpyHostToDevice));
+        std::vector<fe_t> v29(S->vinv);                        // * 2^5: operands of the 2^261-radix multiplier (sweep_kernel_body)
+        for (auto &x : v29)
+            for (int k = 0; k < 5; ++k) x = f.add(x, x);
+        SRS_HIP_CHECK(hipMalloc((void **)&S->d_vinv29, v29.size() * sizeof(fe_t)));
+        S->owned.push_back(S->d_vinv29);
+        SRS_HIP_CHECK(hipMemcpy(S->d_vinv29, v29.data(), v29.size() * sizeof(fe_t), hipMemcpyHostToDevice));
     }
     const hipMemcpyKind kind = space_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     std::vector<uint8_t *> selp(num_selectors);
@@ -1815,6 +1855,7 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
     for (uint32_t k0 = 0; k0 < (d ? d : 1); k0 += DMAX) {
         a.d = d ? std::min<uint32_t>(DMAX, d - k0) : 0;
         a.vinv = S->d_vinv ? S->d_vinv + (size_t)k0 * npts : nullptr;
+        a.vinv29 = S->d_vinv29 ? S->d_vinv29 + (size_t)k0 * npts : nullptr;
         a.out = d_out + k0;
         prof::Scope ps(mode == 0 ? "rowprog_cross_terms" : "rowprog_eval", st, S->rows);
         if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
@@ -1976,6 +2017,11 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     } else {
         for (size_t c = 0; c < n_ch; ++c) ch_pt[0][c] = challenges_host[0][c];
     }
+    // 8 leaves per thread once a gate has >= 1024 rows: 1024-leaf tiles, the first three tree levels in registers
+    const uint32_t lpt = S->k >= 10 ? 8u : 1u;
+    const uint32_t tile_log = lpt == 8 ? 10u : std::min<uint32_t>(7, S->k);
+    // the specialised leaf kernel in sweep form (k_pg_leaves_sweep): integer-point G and evaluate_e of a known gate set
+    const bool sweep_leaves = S->pg_spec_id >= 0 && lpt == 8 && mode != 0 && (mode != 1 || g_int) && P <= DMAX + 1 && !std::getenv("SRS_NO_SWEEP");
     // ---- uniform tables per gate / leaf point
     uint32_t max_slots = 1;
     std::vector<GateProg> gp(n_gates);
@@ -1989,14 +2035,24 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         gp[g].result = p.result;
         gp[g].n_uniform = (uint32_t)nu;
         gp[g].utab_off = (uint32_t)utab.size();
-        utab.resize(utab.size() + nu * leaf_pts);
+        utab.resize(utab.size() + nu * leaf_pts * (sweep_leaves ? lpt : 1u));
         for (uint32_t lp = 0; lp < leaf_pts; ++lp)
             if (!eval_uniform(p, f, ch_pt[lp].data(), n_ch, 0, false, 0, utab.data() + gp[g].utab_off + (size_t)lp * nu, err)) return 7;
+        if (sweep_leaves) {
+            // k_pg_leaves_sweep: one table per leaf slot l of a thread, the term coefficients times w_l = prod_{b in bits(l)} c_(TL + b)
+            const uint32_t TL = tile_log - 3;
+            for (uint32_t l = 1; l < lpt; ++l) {
+                fe_t wl = Fr::one();
+                for (uint32_t b = 0; b < 3; ++b)
+                    if ((l >> b) & 1u) wl = Fr::mul(wl, weights[(size_t)(TL + b) * wpts]);
+                fe_t *dst = utab.data() + gp[g].utab_off + (size_t)l * leaf_pts * nu;
+                std::memcpy(dst, utab.data() + gp[g].utab_off, (size_t)leaf_pts * nu * sizeof(fe_t));
+                for (uint32_t lp = 0; lp < leaf_pts; ++lp)
+                    for (int ci : p.sw_coef) dst[(size_t)lp * nu + ci] = Fr::mul(dst[(size_t)lp * nu + ci], wl);
+            }
+        }
     }
     if (max_slots > 32) { err = "row program needs more than 32 live registers"; return 4; }
-    // 8 leaves per thread once a gate has >= 1024 rows: 1024-leaf tiles, the first three tree levels in registers
-    const uint32_t lpt = S->k >= 10 ? 8u : 1u;
-    const uint32_t tile_log = lpt == 8 ? 10u : std::min<uint32_t>(7, S->k);
     const uint32_t tile = (1u << tile_log) / lpt, tiles_per_gate = (uint32_t)(S->rows >> tile_log);
     const size_t n_tiles_valid = (size_t)n_gates * tiles_per_gate;
     const size_t n_tiles_padded = sz.count_with_padding >> tile_log;
@@ -2045,7 +2101,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         for (uint32_t j = 0; j < 3; ++j) { lv.beta[j] = weights_in[TL + j]; lv.delta[j] = deltas[TL + j]; }
         {
             prof::Scope ps("pg_F_leaves", st, S->rows * n_gates);
-            if (S->pg_spec_id == 0) SRS_LAUNCH((k_pg_F_leaves<Fr, 1, 0>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+            if (S->pg_spec_id == 0) SRS_LAUNCH((k_pg_F_leaves<Fr, 2, 0>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
             else if (max_slots <= 8) SRS_LAUNCH((k_pg_F_leaves<Fr, 8, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
             else if (max_slots <= 16) SRS_LAUNCH((k_pg_F_leaves<Fr, 16, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
             else SRS_LAUNCH((k_pg_F_leaves<Fr, 32, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
@@ -2117,8 +2173,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     {
         prof::Scope ps(mode == 0 ? "pg_F_leaves" : (mode == 1 ? "pg_G_leaves" : "pg_e_leaves"), st, S->rows * n_gates);
         if (S->pg_spec_id >= 0 && lpt == 8)
-            launch_pg_spec(S->pg_spec_id, a, tiles_per_gate, n_gates, tile, st,
-                           wpts == 1 && P <= DMAX + 1 && a.ctx.wcoef == nullptr && !std::getenv("SRS_NO_SWEEP"));
+            launch_pg_spec(S->pg_spec_id, a, tiles_per_gate, n_gates, tile, st, sweep_leaves);
         else if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, lpt, st);

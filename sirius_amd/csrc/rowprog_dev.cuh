@@ -47,6 +47,7 @@ struct DevArgs {
     uint32_t npts;            // d + 1 (interpolate) or 1 (plain evaluation)
     uint32_t d;               // number of outputs in interpolate mode
     const fe_t *vinv;         // [d][npts]: T_k = sum_j vinv[(k-1)*npts + j] * P(j)
+    const fe_t *vinv29;       // the same matrix * 2^5: operands of the 2^261-radix multiplier (sweep form)
     fe_t *const *out;         // d (interpolate) or 1 (plain) output vectors of `rows`
 };
 
@@ -161,22 +162,55 @@ __device__ __forceinline__ void spec_kernel_body(const DevArgs &A, Eval eval) {
     }
 }
 
-// The same kernel body for a program in sweep form: `sweep(ctx, row, npts, utab, nu, acc)` leaves P(pt) in acc[pt * RP_THREADS].
+// ---- sweep form: per-point accumulators of a thread in LDS, limb-planar: word `limb` of point `pt` lives at
+// acc[(pt * 9 + limb) * RP_THREADS] (acc already offset by the thread index): conflict-free 4-byte lanes.  The values are LAZY
+// 9 x 29-bit sums (ABI form, i.e. value * 2^256, plus a few multiples of p); sw_fold brings one below 2p again (product with
+// 2^261 mod p, the radix' one), sw_finish turns it into the canonical 8 x 32 element.
+constexpr uint32_t SW_WORDS = 9;
+__device__ __forceinline__ f29_t sw_load(const uint32_t *acc, uint32_t pt) {
+    f29_t o;
+#pragma unroll
+    for (uint32_t i = 0; i < 9; ++i) o.v[i] = acc[(pt * SW_WORDS + i) * RP_THREADS];
+    return o;
+}
+__device__ __forceinline__ void sw_store(uint32_t *acc, uint32_t pt, const f29_t &x) {
+#pragma unroll
+    for (uint32_t i = 0; i < 9; ++i) acc[(pt * SW_WORDS + i) * RP_THREADS] = x.v[i];
+}
+template <class F>
+__device__ __forceinline__ void sw_fold(uint32_t *acc, uint32_t pt, const fe_t &one261) {
+    using G = Fp29<typename F::Params>;
+    sw_store(acc, pt, G::mul(sw_load(acc, pt), G::unpack(one261)));
+}
+template <class F>
+__device__ __forceinline__ fe_t sw_finish(const uint32_t *acc, uint32_t pt, const fe_t &one261) {
+    using G = Fp29<typename F::Params>;
+    return G::to_canonical_fe(G::mul(sw_load(acc, pt), G::unpack(one261)));
+}
+
+// The kernel body for a program in sweep form: `sweep(ctx, row, npts, utab, nu, acc, accumulate)`, `one_idx` = index of 2^261 mod p
+// in the uniform table.  The inverse Vandermonde step runs on the 9 x 29-bit multiplier as well: vinv29 = vinv * 2^5, so the
+// product of an ABI-form point value with it is ABI form again; the d sums are reduced once each.
 template <class F, class Sweep>
-__device__ __forceinline__ void sweep_kernel_body(const DevArgs &A, Sweep sweep) {
-    __shared__ fe_t Pv[(DMAX + 1) * RP_THREADS];
+__device__ __forceinline__ void sweep_kernel_body(const DevArgs &A, uint32_t one_idx, Sweep sweep) {
+    using G = Fp29<typename F::Params>;
+    __shared__ uint32_t acc_all[(DMAX + 1) * SW_WORDS * RP_THREADS];
+    uint32_t *acc = acc_all + threadIdx.x;
     bool live;
     const uint32_t row = shard_row(A.ctx, blockIdx.x * RP_THREADS + threadIdx.x, live);
-    sweep(A.ctx, row, A.npts, A.utab, A.n_uniform, Pv + threadIdx.x);
+    sweep(A.ctx, row, A.npts, A.utab, A.n_uniform, acc, false);
     if (!live) return;
+    const fe_t one261 = A.utab[one_idx];
     if (A.d == 0) {
-        A.out[0][row] = Pv[threadIdx.x];
+        A.out[0][row] = sw_finish<F>(acc, 0, one261);
         return;
     }
+    for (uint32_t pt = 0; pt < A.npts; ++pt) sw_fold<F>(acc, pt, one261);          // < 2p: d products each below
     for (uint32_t k = 0; k < A.d; ++k) {
-        fe_t T = F::zero();
-        for (uint32_t pt = 0; pt < A.npts; ++pt) T = F::add(T, F::mul(A.vinv[k * A.npts + pt], Pv[pt * RP_THREADS + threadIdx.x]));
-        A.out[k][row] = T;
+        f29_t T = G::mul(sw_load(acc, 0), G::unpack(A.vinv29[k * A.npts]));
+        for (uint32_t pt = 1; pt < A.npts; ++pt)
+            T = G::normalize(G::add_lazy(T, G::mul(sw_load(acc, pt), G::unpack(A.vinv29[k * A.npts + pt]))));   // <= 2 (d + 1) p <= 18 p
+        A.out[k][row] = G::to_canonical_fe(G::mul(T, G::unpack(one261)));
     }
 }
 
