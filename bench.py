@@ -201,8 +201,8 @@ class SangriaSide:
             for pt in commits:
                 ro.absorb_point(self.curve, pt)
             self.r = ro.squeeze(128, self.sf)
-            rv = from_mont(self.sf, self.r)
-            self.rpows = ints_to_mont(self.sf, [pow(rv, i + 1, MODULUS[self.sf]) for i in range(self.d)])
+            from sirius_amd.field import powers
+            self.rpows = powers(self.sf, self.r, self.d)
         acc = S.RelaxedPlonkWitness(self.field, [self.accW], self.accE).fold([self.inW], terms, self.r)
         self.accW, self.accE = acc.W[0], acc.E
         self.pending = (S.point_lincomb_async(self.curve, self.accCE, commits, self.rpows),

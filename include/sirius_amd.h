@@ -161,6 +161,9 @@ int srs_point_mul(int curve, const srs_fe *scalar, int repr, const srs_affine *p
  * RelaxedPlonkInstance::fold -- W_commitments (n = 1) and E_commitment (n = d) -- src/nifs/sangria/accumulator.rs:201-264. */
 int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n,
                       int repr, srs_affine *out);
+/* out[i] = r^(i+1), i < n (Montgomery in, Montgomery out): the powers of the folding challenge the instance fold multiplies the
+ * cross-term commitments with (src/nifs/sangria/accumulator.rs:240-244).  Host code. */
+int srs_fe_powers(int field, const srs_fe *r, size_t n, srs_fe *out);
 /* The same fold, off the caller's thread: nothing on the device waits for the folded instance, so a prover enqueues its next
  * commitment while this runs on the library's host workers (jobs complete in submission order).  acc / points / scalars are
  * copied before the call returns; `out` is written by the job and must stay valid until srs_job_wait(*job) returns.

@@ -55,6 +55,7 @@ def _prototypes():
         "srs_point_lincomb": (i32, [i32, vp, vp, vp, sz, i32, vp]),
         "srs_point_lincomb_async": (i32, [i32, vp, vp, vp, sz, i32, vp, C.POINTER(C.c_uint64)]),
         "srs_job_wait": (i32, [C.c_uint64]),
+        "srs_fe_powers": (i32, [i32, vp, sz, vp]),
         "srs_jit_selfcheck": (i32, [C.POINTER(sz), C.c_char_p, sz]),
         "srs_profile_enable": (None, [i32]),
         "srs_profile_reset": (None, []),
@@ -118,7 +119,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SRS_AMD_LIB") or LIB_PATH      # SRS_AMD_LIB: developer switch (A/B runs of library builds)
     if not os.path.exists(p):
         raise ImportError(
             f"{p} not found: build the HIP extension first (__graft_entry__.build()); "

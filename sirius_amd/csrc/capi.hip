@@ -1142,6 +1142,18 @@ static void point_lincomb_impl(int curve, const srs_affine *acc, const srs_affin
     if (curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
 }
 
+int srs_fe_powers(int field, const srs_fe *r, size_t n, srs_fe *out) {
+    if (!valid_field(field) || !r || (n && !out)) return fail(SRS_ERR_INVALID, "srs_fe_powers: bad argument");
+    fe_t x, acc;
+    std::memcpy(&x, r, 32);
+    acc = x;
+    for (size_t i = 0; i < n; ++i) {
+        std::memcpy(&out[i], &acc, 32);
+        acc = field == SRS_FIELD_FR ? Fr::mul(acc, x) : Fq::mul(acc, x);
+    }
+    return SRS_OK;
+}
+
 int srs_point_lincomb(int curve, const srs_affine *acc, const srs_affine *points, const srs_fe *scalars, size_t n, int repr,
                       srs_affine *out) {
     if (!valid_curve(curve) || !out || (n && (!points || !scalars))) return fail(SRS_ERR_INVALID, "srs_point_lincomb: bad argument");
@@ -1489,7 +1501,10 @@ void srs_poseidon_free(srs_poseidon *H) {
     delete H;
 }
 void srs_poseidon_reset(srs_poseidon *H) {
-    if (H) H->h->buf.clear();
+    if (!H) return;
+    H->h->buf.clear();
+    H->h->state.clear();
+    H->h->done = 0;
 }
 int srs_poseidon_absorb_field(srs_poseidon *H, const srs_fe *v, size_t n) {
     if (!H || (n && !v)) return fail(SRS_ERR_INVALID, "srs_poseidon_absorb_field: bad argument");

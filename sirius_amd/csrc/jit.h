@@ -21,8 +21,8 @@ bool compile(const std::string &source, const char *entry, Kernel &out, std::str
 // The hiprtc half alone (no device, nothing loaded): does `source` compile against the embedded headers?
 bool compile_only(const std::string &source, size_t *code_bytes, std::string &log);
 void release(Kernel &k);
-// grid x 128 threads, one struct argument passed by value
-bool launch(const Kernel &k, unsigned blocks, unsigned threads, const void *arg_struct, hipStream_t st);
+// grid x 128 threads, `smem_bytes` of dynamic LDS, one struct argument passed by value
+bool launch(const Kernel &k, unsigned blocks, unsigned threads, unsigned smem_bytes, const void *arg_struct, hipStream_t st);
 
 }  // namespace jit
 }  // namespace srs

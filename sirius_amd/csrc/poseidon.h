@@ -15,6 +15,8 @@ struct Hash {
     std::vector<fe_t> rc;                // [(r_f + r_p)][t] round constants, Montgomery
     std::vector<fe_t> mds;               // [t][t]
     std::vector<fe_t> buf;               // absorbed elements (kept across squeezes, like the reference)
+    std::vector<fe_t> state;             // sponge state after the first `done` elements (full chunks only); empty = fresh
+    size_t done = 0;
 };
 
 // Spec::new(r_f, r_p) (src/poseidon/spec.rs:14-16).  nullptr + err on bad parameters.

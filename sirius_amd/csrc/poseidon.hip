@@ -103,14 +103,28 @@ void permute(const Hash &h, std::vector<fe_t> &st) {
 }
 
 template <class F>
-fe_t run(const Hash &h) {
-    std::vector<fe_t> st(h.t, F::zero());
-    fe_t cap;
-    std::memset(&cap, 0, sizeof cap);
-    cap.v[2] = 1;                                            // 2^64  (poseidon::State::default())
-    st[0] = F::to_mont(cap);
+fe_t run(Hash &h) {
+    // The sponge state after the full RATE-sized chunks absorbed so far depends on those chunks only (padding touches the
+    // last, partial chunk): it is cached across squeezes, so a transcript that squeezes after every absorb (delta, alpha,
+    // gamma of ProtoGalaxy::prove: 2 + 32 + 256 elements) permutes every chunk once, not once per squeeze.  Same output
+    // as re-running the sponge over the whole buffer, which is what the reference does (poseidon_hash.rs:190-212).
+    if (h.state.empty()) {
+        h.state.assign(h.t, F::zero());
+        fe_t cap;
+        std::memset(&cap, 0, sizeof cap);
+        cap.v[2] = 1;                                        // 2^64  (poseidon::State::default())
+        h.state[0] = F::to_mont(cap);
+        h.done = 0;
+    }
     const size_t n = h.buf.size();
-    for (size_t at = 0; at <= n; at += h.rate) {
+    while (n - h.done > h.rate) {                            // chunks that are certainly not the last one
+        for (size_t i = 0; i < h.rate; ++i) h.state[1 + i] = F::add(h.state[1 + i], h.buf[h.done + i]);
+        permute<F>(h, h.state);
+        h.done += h.rate;
+    }
+    // the tail: at most one full chunk (then followed by the empty, padded chunk) or one partial chunk, on a copy of the state
+    std::vector<fe_t> st(h.state);
+    for (size_t at = h.done; at <= n; at += h.rate) {
         const size_t len = n - at < h.rate ? n - at : h.rate;
         if (at == n && n % h.rate != 0) break;               // the empty chunk exists only when the buffer is exact
         for (size_t i = 0; i < len; ++i) st[1 + i] = F::add(st[1 + i], h.buf[at + i]);

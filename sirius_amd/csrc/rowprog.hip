@@ -234,7 +234,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_spec(PgArgs A) {
 template <class F, int ID, uint32_t LPT>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     __shared__ fe_t red[RP_THREADS];
-    __shared__ uint32_t acc_all[(DMAX + 1) * SW_WORDS * RP_THREADS];
+    SRS_SWEEP_ACC(acc_all);                                 // sweep_smem_bytes(P) of dynamic LDS
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const GateProg G = A.gates[gate];
@@ -1861,7 +1861,10 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
         if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
 #if !defined(SRS_EMU)
         else if (p.jit.function) {
-            if (!jit::launch(p.jit, (a.ctx.local_rows + RP_THREADS - 1) / RP_THREADS, RP_THREADS, &a, st)) { err = "launch of the run-time compiled row program failed"; return 5; }
+            if (!jit::launch(p.jit, (a.ctx.local_rows + RP_THREADS - 1) / RP_THREADS, RP_THREADS, p.sweep_ok ? sweep_smem_bytes(a.npts) : 0u, &a, st)) {
+                err = "launch of the run-time compiled row program failed";
+                return 5;
+            }
         }
 #endif
         else if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);

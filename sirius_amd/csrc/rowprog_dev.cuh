@@ -167,6 +167,14 @@ __device__ __forceinline__ void spec_kernel_body(const DevArgs &A, Eval eval) {
 // 9 x 29-bit sums (ABI form, i.e. value * 2^256, plus a few multiples of p); sw_fold brings one below 2p again (product with
 // 2^261 mod p, the radix' one), sw_finish turns it into the canonical 8 x 32 element.
 constexpr uint32_t SW_WORDS = 9;
+// The accumulators are DYNAMIC shared memory, sized by the launch for the points actually evaluated (sweep_smem_bytes): at
+// 9 points they are 41.5 KB and only three workgroups fit a CU; the cross terms of the benchmark circuits have 6 - 7.
+SRS_HD constexpr uint32_t sweep_smem_bytes(uint32_t npts) { return npts * SW_WORDS * RP_THREADS * 4u; }
+#if defined(SRS_EMU)
+#define SRS_SWEEP_ACC(name) static uint32_t name[(DMAX + 1) * SW_WORDS * RP_THREADS]
+#else
+#define SRS_SWEEP_ACC(name) extern __shared__ uint32_t name[]
+#endif
 __device__ __forceinline__ f29_t sw_load(const uint32_t *acc, uint32_t pt) {
     f29_t o;
 #pragma unroll
@@ -194,7 +202,7 @@ __device__ __forceinline__ fe_t sw_finish(const uint32_t *acc, uint32_t pt, cons
 template <class F, class Sweep>
 __device__ __forceinline__ void sweep_kernel_body(const DevArgs &A, uint32_t one_idx, Sweep sweep) {
     using G = Fp29<typename F::Params>;
-    __shared__ uint32_t acc_all[(DMAX + 1) * SW_WORDS * RP_THREADS];
+    SRS_SWEEP_ACC(acc_all);
     uint32_t *acc = acc_all + threadIdx.x;
     bool live;
     const uint32_t row = shard_row(A.ctx, blockIdx.x * RP_THREADS + threadIdx.x, live);

@@ -25,3 +25,12 @@ def ints_to_mont(field, vals):
     for i, v in enumerate(vals):
         out[i] = to_mont(field, v)
     return out
+
+
+def powers(field, r, n):
+    """r^1 .. r^n as (n, 4) Montgomery limbs (library host code, srs_fe_powers): the scalars of the E-commitment fold."""
+    from . import _lib as L
+    rr = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    L.check(L.lib().srs_fe_powers(field, rr.ctypes.data, n, out.ctypes.data))
+    return out
