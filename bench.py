@@ -269,11 +269,7 @@ class PgPrimary:
         if ro_challenge:
             alpha = PGint(self.ro.absorb_field(poly_F).squeeze(128, 0))
         f_alpha = PG.poly_eval(poly_F, m([alpha])[0])
-        bs, d = [], delta                                             # BetaStrokeIter (poly/mod.rs:449-462)
-        for b in self.betas_i:
-            bs.append((b + alpha * d) % FR)
-            d = d * d % FR
-        betas_stroke = m(bs)
+        betas_stroke = PG.beta_stroke(self.betas, m([alpha])[0], m([delta])[0])     # BetaStrokeIter (poly/mod.rs:449-462)
         poly_G = PG.compute_G(ctx, betas_stroke, [self.accW, self.inW], reference_compat=self.compat)
         poly_K = PG.compute_K_from_G(ctx, poly_G, f_alpha)
         if ro_challenge:
@@ -283,7 +279,7 @@ class PgPrimary:
         self.e = PG.calculate_e(poly_F, poly_K, g, m([alpha])[0], ctx.lagrange_domain)
         self.accW = PG.fold_witness(0, [self.accW, self.inW], Ls)                        # device, stream-ordered
         self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), Ls[:2])   # fold_instance
-        self.betas_i, self.betas = bs, betas_stroke
+        self.betas = betas_stroke
 
     def witness_commit(self, S, D):
         """generate_plonk_trace -> run_sps_protocol_1: ck.commit(W1) of the NEW witness, host -> HBM inside the call."""

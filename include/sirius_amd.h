@@ -370,6 +370,8 @@ typedef struct {                       /* PolyContext (poly/mod.rs:205-269) */
     uint32_t fft_log_domain_size_K;    /* (points_G + 1 - instances_to_fold).next_power_of_two() -- a count used as a log (:263-268) */
 } srs_pg_context;
 int srs_pg_context_new(const srs_structure *S, size_t traces_len, srs_pg_context *out);
+/* PolyChallenges::iter_beta_stroke (poly/mod.rs:432-462): out[i] = betas[i] + alpha * delta^(2^i), i < n.  Host code (bn256::Fr). */
+int srs_pg_beta_stroke(const srs_fe *betas, size_t n, const srs_fe *alpha, const srs_fe *delta, srs_fe *out);
 /* compute_F (:68-203): poly_F[fft_points_count_F] = ifft_X( sum_i pow_i(betas + X*deltas) f_i(w) ), deltas_b = delta^(2^b) */
 int srs_pg_compute_F(srs_structure *S, const srs_fe *betas, size_t n_betas, const srs_fe *delta, const srs_fe *W,
                      const srs_fe *challenges, size_t n_challenges, int space, int reference_compat, void *stream,

@@ -1895,6 +1895,21 @@ int srs_pg_compute_K_from_G(const srs_fe *poly_G, size_t n_G, const srs_fe *poly
     });
 }
 
+int srs_pg_beta_stroke(const srs_fe *betas, size_t n, const srs_fe *alpha, const srs_fe *delta, srs_fe *out) {
+    if ((n && (!betas || !out)) || !alpha || !delta) return fail(SRS_ERR_INVALID, "srs_pg_beta_stroke: bad argument");
+    fe_t a, d;
+    std::memcpy(&a, alpha, 32);
+    std::memcpy(&d, delta, 32);
+    for (size_t i = 0; i < n; ++i) {                   // BetaStrokeIter: next = beta[i] + alpha * delta^(2^i)   (poly/mod.rs:449-462)
+        fe_t b;
+        std::memcpy(&b, &betas[i], 32);
+        b = Fr::add(b, Fr::mul(a, d));
+        std::memcpy(&out[i], &b, 32);
+        d = Fr::sqr(d);
+    }
+    return SRS_OK;
+}
+
 int srs_lagrange_eval(const srs_fe *X, uint32_t log_n, srs_fe *out) {
     if (!X || !out || log_n > ntt::FR_S) return fail(SRS_ERR_INVALID, "srs_lagrange_eval: bad argument");
     fe_t x;

@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <tuple>
 
 namespace srs {
@@ -2239,23 +2240,34 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
         // 760 dependent multiplications = 0.6 ms of pure latency on it.
         const fe_t zeta = ntt::zeta(), omega = ntt::omega(log_domain_K, false), one = Fr::one();
         const fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
-        std::vector<fe_t> g(count), xn1(count), xm1(count), pref(2 * count);
+        std::vector<fe_t> g(count), xn1(count), xm1(count), pref(2 * count), xs(count);
         fe_t X = zeta, acc = one;
+        for (size_t i = 0; i < count; ++i) { xs[i] = X; X = Fr::mul(X, omega); }
+        // the evaluations G(X_i) are independent: spread over a few host threads (8 x 256 Horner steps are ~0.1 ms on one core,
+        // on the critical path between compute_G and the gamma challenge)
+        {
+            const size_t nthr = std::min<size_t>(8, std::max<size_t>(1, count / 32));
+            std::vector<std::thread> pool;
+            auto work = [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    fe_t gi = Fr::zero();
+                    for (size_t k = nG; k-- > 0;) gi = Fr::add(Fr::mul(gi, xs[i]), polyG_host[k]);   // UnivariatePoly::eval (univariate.rs:67-75), Horner: same value
+                    g[i] = gi;
+                    xn1[i] = Fr::sub(Fr::pow_u64(xs[i], instances_to_fold), one);
+                    xm1[i] = Fr::sub(xs[i], one);
+                }
+            };
+            const size_t per = (count + nthr - 1) / nthr;
+            for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work, t * per, std::min(count, (t + 1) * per));
+            work(0, std::min(count, per));
+            for (auto &th : pool) th.join();
+        }
         for (size_t i = 0; i < count; ++i) {
-            fe_t gi = Fr::zero(), xp = one;
-            for (size_t k = 0; k < nG; ++k) {                  // UnivariatePoly::eval (univariate.rs:67-75)
-                gi = Fr::add(gi, Fr::mul(xp, polyG_host[k]));
-                xp = Fr::mul(xp, X);
-            }
-            g[i] = gi;
-            xn1[i] = Fr::sub(Fr::pow_u64(X, instances_to_fold), one);
-            xm1[i] = Fr::sub(X, one);
             if (Fr::is_zero(xn1[i])) { err = "Z(X) must be not equal to 0"; return 4; }     // X = 1 included (then X - 1 = 0 too)
             pref[2 * i] = acc;
             acc = Fr::mul(acc, xn1[i]);
             pref[2 * i + 1] = acc;
             acc = Fr::mul(acc, xm1[i]);
-            X = Fr::mul(X, omega);
         }
         fe_t inv = Fr::inv(acc);
         std::vector<fe_t> kp(count);

@@ -48,6 +48,14 @@ def compute_F(ctx, betas, delta, W, challenges=(), reference_compat=True):
     return out
 
 
+def beta_stroke(betas, alpha, delta):
+    """`PolyChallenges::iter_beta_stroke` (poly/mod.rs:432-462): betas[i] + alpha * delta^(2^i)."""
+    b, a, d = _fe(betas), _fe(alpha), _fe(delta)
+    out = np.zeros_like(b)
+    L.check(L.lib().srs_pg_beta_stroke(b.ctypes.data, b.shape[0], a.ctypes.data, d.ctypes.data, out.ctypes.data))
+    return out
+
+
 def compute_G(ctx, betas_stroke, Ws, challenges_list=None, reference_compat=True):
     bs = _fe(betas_stroke)
     bufs = [_buf(w, 4) for w in Ws]

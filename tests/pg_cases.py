@@ -37,6 +37,7 @@ def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
     eF = OPG.compute_F(oS, octx, betas, delta, Ws[0], [], compat)
     assert O.mont_to_ints(O.FR, pF) == eF, "compute_F"
     bs = OPG.beta_stroke(betas, alpha, delta)
+    assert O.mont_to_ints(O.FR, PG.beta_stroke(m(betas), m([alpha])[0], m([delta])[0])) == bs, "beta_stroke"
     pG = PG.compute_G(ctx, m(bs), Ws, reference_compat=compat)
     eG = OPG.compute_G(oS, octx, bs, Ws, [[] for _ in Ws], compat)
     assert O.mont_to_ints(O.FR, pG) == eG, "compute_G"
