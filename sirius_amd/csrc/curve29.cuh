@@ -19,6 +19,31 @@ struct xyzz29_t {
     f29_t x, y, zz, zzz;   // x < 9P norm; y < 5P, limbs < 2^31; zz, zzz < 2P norm; identity: zz == 0 exactly
 };
 
+// quad exchange of 9-limb values (see quad_bcast / quad_select in curve.cuh)
+template <int K>
+SRS_D f29_t quad_bcast29(const f29_t &x) {
+    f29_t o;
+#if defined(SRS_EMU)
+    __emu_quad_bcast_n(x.v, K, o.v, 9);
+#else
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.v[i] = quad_bcast_u32<K>(x.v[i]);
+#endif
+    return o;
+}
+SRS_D f29_t quad_select29(uint32_t q, f29_t a0, f29_t a1, f29_t a2, f29_t a3) {   // BY VALUE (see quad_select)
+    f29_t o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t x = a0.v[i];
+        x = q == 1 ? a1.v[i] : x;
+        x = q == 2 ? a2.v[i] : x;
+        x = q == 3 ? a3.v[i] : x;
+        o.v[i] = x;
+    }
+    return o;
+}
+
 template <class C>
 struct Ec29 {
     using P = typename C::F::Params;
@@ -137,6 +162,109 @@ struct Ec29 {
         o.y = F::template sub_lazy<3, 0>(m1, m2);                               // (P, 5P), limbs < 2^31
         o.zz = F::mul(a.zz, pp);
         o.zzz = F::mul(a.zzz, ppp);
+        return o;
+    }
+
+    // ---- the partial sums after level 0 stay in R'-form end to end (msm.hip): in memory a point is the usual 4 x 8 x u32 record
+    // holding CANONICAL R'-form coordinates; in registers it is lazy as above
+    SRS_HD static xyzz29_t unpack(const xyzz_t &p) {
+        xyzz29_t o;
+        o.x = F::unpack(p.x);
+        o.y = F::unpack(p.y);
+        o.zz = F::unpack(p.zz);
+        o.zzz = F::unpack(p.zzz);
+        return o;
+    }
+    SRS_HD static xyzz_t pack(const xyzz29_t &a) {      // x < 9P and y < 5P are folded below 2P by a product with the radix' one
+        xyzz_t o;
+        const f29_t one_ = one();
+        o.x = F::to_canonical_fe(F::mul(a.x, one_));
+        o.y = F::to_canonical_fe(F::mul(a.y, one_));
+        o.zz = F::to_canonical_fe(a.zz);
+        o.zzz = F::to_canonical_fe(a.zzz);
+        return o;
+    }
+    // 2 A for a lazy accumulator (dbl-2008-s-1)
+    SRS_HD static xyzz29_t dbl(const xyzz29_t &a) {
+        if (is_identity(a)) return a;
+        xyzz29_t o;
+        const f29_t yn = F::normalize(a.y);                                      // < 5P norm
+        const f29_t u = F::add_lazy(yn, yn);                                     // < 10P, limbs < 2^30
+        const f29_t v = F::sqr(u);                                               // 100 P^2
+        const f29_t w = F::mul(u, v);
+        const f29_t s = F::mul(a.x, v);                                          // 18 P^2
+        const f29_t xx = F::sqr(a.x);                                            // 81 P^2
+        const f29_t m = F::normalize(F::add_lazy(F::add_lazy(xx, xx), xx));      // < 6P norm
+        const f29_t mm = F::sqr(m);
+        o.x = F::normalize(F::template sub_lazy<5, 1>(mm, F::add_lazy(s, s)));   // (P, 7P) norm
+        const f29_t t = F::template sub_lazy<8, 0>(s, o.x);                      // (P, 10P), limbs < 2^31
+        const f29_t m1 = F::mul(t, m);
+        const f29_t m2 = F::mul(yn, w);
+        o.y = F::template sub_lazy<3, 0>(m1, m2);                                // (P, 5P), limbs < 2^31
+        o.zz = F::mul(v, a.zz);
+        o.zzz = F::mul(w, a.zzz);
+        return o;
+    }
+    // a + b, both lazy accumulators (add-2008-s), complete.  Products put the operand with wide limbs (a y) first.
+    SRS_HD static xyzz29_t add(const xyzz29_t &a, const xyzz29_t &b) {
+        if (is_identity(b)) return a;
+        if (is_identity(a)) return b;
+        const f29_t u1 = F::mul(a.x, b.zz);                                      // 18 P^2
+        const f29_t u2 = F::mul(b.x, a.zz);
+        const f29_t s1 = F::mul(a.y, b.zzz);                                     // 10 P^2
+        const f29_t s2 = F::mul(b.y, a.zzz);
+        const f29_t p = F::normalize(F::template sub_lazy<3, 0>(u2, u1));        // (P, 5P) norm
+        const f29_t r = F::normalize(F::template sub_lazy<3, 0>(s2, s1));
+        const f29_t pp = F::sqr(p);
+        const f29_t rr = F::sqr(r);
+        if (F::is_zero_mod(pp)) {
+            if (F::is_zero_mod(rr)) return dbl(a);
+            return identity();
+        }
+        const f29_t ppp = F::mul(p, pp);
+        const f29_t qv = F::mul(u1, pp);
+        xyzz29_t o;
+        o.x = F::normalize(F::template sub_lazy<7, 2>(rr, F::add_lazy(ppp, F::add_lazy(qv, qv))));   // (P, 9P) norm
+        const f29_t t = F::template sub_lazy<10, 0>(qv, o.x);                    // (P, 12P), limbs < 2^31
+        const f29_t m1 = F::mul(t, r);                                           // 60 P^2
+        const f29_t m2 = F::mul(s1, ppp);
+        o.y = F::template sub_lazy<3, 0>(m1, m2);                                // (P, 5P), limbs < 2^31
+        o.zz = F::mul(F::mul(a.zz, b.zz), pp);
+        o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
+        return o;
+    }
+
+    // a + b by the 4 lanes of a DPP quad (see Ec::add_quad, curve.cuh): the 14 products in 4 levels of <= 4 independent ones.
+    // Preconditions: the 4 lanes hold the same a and b, q = lane index inside the quad, the quad is convergent.
+    SRS_D static xyzz29_t add_quad(const xyzz29_t &a, const xyzz29_t &b, uint32_t q) {
+        const bool ia = is_identity(a), ib = is_identity(b);
+        xyzz29_t o;
+        if (ia || ib) {                            // a + O = a ; O + b = b   (quad-uniform)
+            o.x = F::select(ib, a.x, b.x);
+            o.y = F::select(ib, a.y, b.y);
+            o.zz = F::select(ib, a.zz, b.zz);
+            o.zzz = F::select(ib, a.zzz, b.zzz);
+            return o;
+        }
+        // level 1: u1 = X1 ZZ2 | u2 = X2 ZZ1 | s1 = Y1 ZZZ2 | s2 = Y2 ZZZ1      (first operand: the one that may have wide limbs)
+        const f29_t m1 = F::mul(quad_select29(q, a.x, b.x, a.y, b.y), quad_select29(q, b.zz, a.zz, b.zzz, a.zzz));
+        const f29_t u1 = quad_bcast29<0>(m1), u2 = quad_bcast29<1>(m1), s1 = quad_bcast29<2>(m1), s2 = quad_bcast29<3>(m1);
+        const f29_t p = F::normalize(F::template sub_lazy<3, 0>(u2, u1)), r = F::normalize(F::template sub_lazy<3, 0>(s2, s1));
+        // level 2: PP = P^2 | RR = R^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2
+        const f29_t m2 = F::mul(quad_select29(q, p, r, a.zz, a.zzz), quad_select29(q, p, r, b.zz, b.zzz));
+        const f29_t pp = quad_bcast29<0>(m2), rr = quad_bcast29<1>(m2), zzz12 = quad_bcast29<3>(m2);
+        // level 3: PPP = P PP | Q = U1 PP | ZZ3 = ZZ1 ZZ2 PP | (lane 3 repeats lane 0)
+        const f29_t m3 = F::mul(quad_select29(q, p, u1, m2, p), pp);
+        const f29_t ppp = quad_bcast29<0>(m3), qv = quad_bcast29<1>(m3), zz3 = quad_bcast29<2>(m3);
+        const f29_t x3 = F::normalize(F::template sub_lazy<7, 2>(rr, F::add_lazy(ppp, F::add_lazy(qv, qv))));
+        // level 4: (Q - X3) R | S1 PPP | ZZZ3 = ZZZ1 ZZZ2 PPP | (lane 3 repeats lane 1)
+        const f29_t m4 = F::mul(quad_select29(q, F::template sub_lazy<10, 0>(qv, x3), s1, zzz12, s1), quad_select29(q, r, ppp, ppp, ppp));
+        const f29_t t2 = quad_bcast29<0>(m4), t1 = quad_bcast29<1>(m4), zzz3 = quad_bcast29<2>(m4);
+        o.x = x3;
+        o.y = F::template sub_lazy<3, 0>(t2, t1);
+        o.zz = zz3;
+        o.zzz = zzz3;
+        if (F::is_zero_mod(pp)) o = F::is_zero_mod(rr) ? dbl(a) : identity();   // P2 = +-P1 (quad-uniform as well)
         return o;
     }
 

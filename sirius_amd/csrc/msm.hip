@@ -551,17 +551,30 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
 // level 0: thread t = (bucket, part): <= L0 gathered mixed adds  ->  parts0[t]  (XYZZ)
 // grid = (blocks, batch)
 // ---------------------------------------------------------------------------------------------
+// thread -> bucket map of level 0: tb[t] = b for tp0[b] <= t < tp0[b + 1].  k_accum0 used to find its bucket by a binary search
+// over the 2^15 prefix entries -- 15 DEPENDENT global loads (~15 us) in front of ~130 us of additions, in every thread.
+// One wavefront per bucket writes the (contiguous) range instead; the map is 2 bytes per thread.   grid = (NBUCKET / 4, batch)
+__global__ void SRS_KERNEL_BOUNDS(256, 1)
+    k_expand(const uint32_t *__restrict__ plan, size_t plan_stride, uint16_t *__restrict__ tb, size_t tb_stride) {
+    const uint32_t m = blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t *tp = plan + (size_t)m * plan_stride + (NBUCKET + 1);
+    uint16_t *out = tb + (size_t)m * tb_stride;
+    const uint32_t s = tp[b], e = tp[b + 1];
+    for (uint32_t t = s + lane; t < e; t += 64) out[t] = (uint16_t)b;
+}
+
 template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum0(const uint32_t *__restrict__ sorted, size_t sorted_stride, const uint32_t *__restrict__ plan,
-             size_t plan_stride, const affine_t *__restrict__ table, xyzz_t *__restrict__ parts,
-             size_t parts_stride, uint32_t l0) {
+             size_t plan_stride, const uint16_t *__restrict__ tb, size_t tb_stride, const affine_t *__restrict__ table,
+             xyzz_t *__restrict__ parts, size_t parts_stride, uint32_t l0) {
     uint32_t m = blockIdx.y;
     const uint32_t *off = plan + (size_t)m * plan_stride;
     const uint32_t *tp = off + (NBUCKET + 1);
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tp[NBUCKET]) return;
-    uint32_t b = upper_bucket(tp, t);
+    uint32_t b = tb[(size_t)m * tb_stride + t];
     uint32_t part = t - tp[b];
     uint32_t s = off[b] + part * l0;
     uint32_t e = off[b + 1];
@@ -585,7 +598,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
             p = pn;
         }
     }
-    parts[(size_t)m * parts_stride + t] = E29::to_xyzz(acc);
+    parts[(size_t)m * parts_stride + t] = E29::pack(acc);        // canonical R'-form: the later levels stay on the 29-bit multiplier
 }
 
 // level >= 1: (bucket, part) over the previous level's parts, <= L1 full adds each.
@@ -611,15 +624,16 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     uint32_t s = tp_prev[b] + part * l1;
     uint32_t e = tp_prev[b + 1];
     if (e > s + l1) e = s + l1;
+    using E29 = Ec29<C>;
     const xyzz_t *src = in + (size_t)m * in_stride;
-    xyzz_t acc = src[s];
+    xyzz29_t acc = E29::unpack(src[s]);
     if (quad) {
         const uint32_t q = threadIdx.x & 3u;
-        for (uint32_t j = s + 1; j < e; ++j) acc = Ec<C>::add_quad(acc, src[j], q);
-        if (q == 0) out[(size_t)m * out_stride + t] = acc;
+        for (uint32_t j = s + 1; j < e; ++j) acc = E29::add_quad(acc, E29::unpack(src[j]), q);
+        if (q == 0) out[(size_t)m * out_stride + t] = E29::pack(acc);
     } else {
-        for (uint32_t j = s + 1; j < e; ++j) acc = Ec<C>::add(acc, src[j]);
-        out[(size_t)m * out_stride + t] = acc;
+        for (uint32_t j = s + 1; j < e; ++j) acc = E29::add(acc, E29::unpack(src[j]));
+        out[(size_t)m * out_stride + t] = E29::pack(acc);
     }
 }
 
@@ -634,6 +648,20 @@ __device__ __forceinline__ xyzz_t shfl_down_point(const xyzz_t &p, unsigned delt
     uint32_t *d = reinterpret_cast<uint32_t *>(&o);
 #pragma unroll
     for (int i = 0; i < 32; ++i) d[i] = __shfl_down(s[i], delta, 64);
+    return o;
+}
+
+// 64-lane exchange of a point in 9-limb coordinates (36 words), inside groups of `width` lanes
+__device__ __forceinline__ xyzz29_t shfl_down_point29(const xyzz29_t &p, unsigned delta, int width) {
+    xyzz29_t o;
+#if defined(SRS_EMU)
+    __emu_shfl_down_bulk(&p, &o, delta, width, 36);
+    return o;
+#endif
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) d[i] = __shfl_down(s[i], delta, width);
     return o;
 }
 
@@ -659,13 +687,14 @@ __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
         if (lane == 0) dst[b] = src[s];
         return;
     }
-    xyzz_t acc = Ec<C>::identity();
-    for (uint32_t j = s + lane; j < e; j += 64) acc = Ec<C>::add(acc, src[j]);
+    using E29 = Ec29<C>;
+    xyzz29_t acc = E29::identity();
+    for (uint32_t j = s + lane; j < e; j += 64) acc = E29::add(acc, E29::unpack(src[j]));
     for (unsigned d = 32; d >= 1; d >>= 1) {
-        xyzz_t other = shfl_down_point(acc, d);
-        if (lane < d) acc = Ec<C>::add(acc, other);
+        xyzz29_t other = shfl_down_point29(acc, d, 64);
+        if (lane < d) acc = E29::add(acc, other);
     }
-    if (lane == 0) dst[b] = acc;
+    if (lane == 0) dst[b] = E29::pack(acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -711,43 +740,44 @@ __global__ void SRS_KERNEL_BOUNDS(128, 1)
     const uint32_t *hdr = plan + (size_t)m * plan_stride + plan_stride - 4;   // [0] levels run, [1] all buckets single
     const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + (size_t)m * ping_stride : pong + (size_t)m * pong_stride)
                              : buckets + (size_t)m * NBUCKET;
+    using E29 = Ec29<C>;
     xyzz_t *out = rc + (size_t)m * (RED_ROWS + RED_COLS);
     const bool is_row = blockIdx.x < RED_ROWS / 2;
-    xyzz_t acc;
+    xyzz29_t acc;
     if (is_row) {
         const uint32_t hi = blockIdx.x * 2 + wave;                               // 16 quads x 8 = 128 = RED_COLS
         const xyzz_t *src = B + (size_t)hi * RED_COLS + vl * SER;
-        acc = src[0];
+        acc = E29::unpack(src[0]);
         xyzz_t nx = src[1];
         for (uint32_t j = 1; j < SER; ++j) {             // next element is fetched behind the addition
             xyzz_t cur = nx;
             if (j + 1 < SER) nx = src[j + 1];
-            acc = Ec<C>::add_quad(acc, cur, q);
+            acc = E29::add_quad(acc, E29::unpack(cur), q);
         }
     } else {
         const uint32_t lo = blockIdx.x - RED_ROWS / 2, sub = wave * 16 + vl;     // 32 quads x 8 = 256 = RED_ROWS
         const xyzz_t *src = B + (size_t)(sub * SER) * RED_COLS + lo;
-        acc = src[0];
+        acc = E29::unpack(src[0]);
         xyzz_t nx = src[RED_COLS];
         for (uint32_t j = 1; j < SER; ++j) {
             xyzz_t cur = nx;
             if (j + 1 < SER) nx = src[(size_t)(j + 1) * RED_COLS];
-            acc = Ec<C>::add_quad(acc, cur, q);
+            acc = E29::add_quad(acc, E29::unpack(cur), q);
         }
     }
     for (unsigned d = 8; d >= 1; d >>= 1) {
-        xyzz_t o = shfl_down_point_w(acc, 4 * d, 64);
-        if (vl < d) acc = Ec<C>::add_quad(acc, o, q);
+        xyzz29_t o = shfl_down_point29(acc, 4 * d, 64);
+        if (vl < d) acc = E29::add_quad(acc, o, q);
     }
     if (is_row) {
-        if (lane == 0) out[blockIdx.x * 2 + wave] = acc;
+        if (lane == 0) out[blockIdx.x * 2 + wave] = E29::pack(acc);
         return;
     }
-    if (wave == 1 && lane == 0) half[0] = acc;
+    if (wave == 1 && lane == 0) half[0] = E29::pack(acc);
     __syncthreads();
     if (wave == 0 && vl == 0) {
-        acc = Ec<C>::add_quad(acc, half[0], q);
-        if (q == 0) out[RED_ROWS + (blockIdx.x - RED_ROWS / 2)] = acc;
+        acc = E29::add_quad(acc, E29::unpack(half[0]), q);
+        if (q == 0) out[RED_ROWS + (blockIdx.x - RED_ROWS / 2)] = E29::pack(acc);
     }
 }
 
@@ -761,32 +791,33 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
     k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
     constexpr uint32_t N = RED_COLS;                       // 128 elements per block
-    __shared__ xyzz_t v[N];
+    using E29 = Ec29<C>;
+    __shared__ xyzz_t v[N];                                // canonical R'-form records; registers hold the lazy 9-limb form
     const uint32_t m = blockIdx.y, t = threadIdx.x >> 2, q = threadIdx.x & 3u, which = blockIdx.x;
     const xyzz_t *rows = rc + (size_t)m * (RED_ROWS + RED_COLS), *cols = rows + RED_ROWS;
-    xyzz_t x;
-    if (which == 0) x = Ec<C>::add_quad(rows[2 * t], rows[2 * t + 1], q);
-    else if (which == 1) x = cols[t];
-    else x = rows[2 * t + 1];
+    xyzz29_t x;
+    if (which == 0) x = E29::add_quad(E29::unpack(rows[2 * t]), E29::unpack(rows[2 * t + 1]), q);
+    else if (which == 1) x = E29::unpack(cols[t]);
+    else x = E29::unpack(rows[2 * t + 1]);
     if (which != 2) {
-        if (q == 0) v[t] = x;
+        if (q == 0) v[t] = E29::pack(x);
         __syncthreads();
         for (uint32_t s = 1; s < N; s <<= 1) {             // suffix scan
             const bool has = t + s < N;
-            xyzz_t o = has ? v[t + s] : Ec<C>::identity();
+            xyzz29_t o = has ? E29::unpack(v[t + s]) : E29::identity();
             __syncthreads();
-            if (has) x = Ec<C>::add_quad(x, o, q);
-            if (q == 0) v[t] = x;
+            if (has) x = E29::add_quad(x, o, q);
+            if (q == 0) v[t] = E29::pack(x);
             __syncthreads();
         }
-        if (which == 0 && t == 0) x = Ec<C>::identity();
+        if (which == 0 && t == 0) x = E29::identity();
     }
-    if (q == 0) v[t] = x;
+    if (q == 0) v[t] = E29::pack(x);
     __syncthreads();
     for (uint32_t s = N >> 1; s >= 1; s >>= 1) {           // tree sum
-        if (t < s) {                                       // x == v[t] (kept in registers by all 4 lanes: the quad's own
-            x = Ec<C>::add_quad(x, v[t + s], q);           // slot is never re-read, so lane 0's store cannot race with it)
-            if (q == 0) v[t] = x;
+        if (t < s) {                                       // x is kept in registers by all 4 lanes: the quad's own
+            x = E29::add_quad(x, E29::unpack(v[t + s]), q);      // slot is never re-read, so lane 0's store cannot race with it
+            if (q == 0) v[t] = E29::pack(x);
         }
         __syncthreads();
     }
@@ -901,6 +932,7 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     per += 2 * Arena::pad(NBUCKET * sizeof(uint32_t));       // count, cursor
     per += Arena::pad(plan_stride * sizeof(uint32_t));
     per += Arena::pad(parts0 * sizeof(xyzz_t));              // ping
+    per += Arena::pad(parts0 * sizeof(uint16_t));            // thread -> bucket map of level 0
     per += Arena::pad(parts1 * sizeof(xyzz_t));              // pong
     per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
@@ -936,6 +968,7 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     uint32_t *cursor = A.take<uint32_t>((size_t)NBUCKET * batch);
     uint32_t *plan = A.take<uint32_t>(plan_stride * batch);
     xyzz_t *ping = A.take<xyzz_t>(parts0_cap * batch);
+    uint16_t *tb = A.take<uint16_t>(parts0_cap * batch);
     xyzz_t *pong = A.take<xyzz_t>(parts1_cap * batch);
     xyzz_t *buckets = A.take<xyzz_t>((size_t)NBUCKET * batch);
     xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
@@ -980,10 +1013,11 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
 
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap);
     {
         prof::Scope ps("msm_accum0", stream, units);
         SRS_LAUNCH((k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
-                   (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride,
+                   (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride, (const uint16_t *)tb, (size_t)parts0_cap,
                    (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log);
     }
     xyzz_t *cur = ping, *nxt = pong;
@@ -1020,7 +1054,18 @@ static void finish_t(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_
         for (uint32_t m = 0; m < batch; ++m) result_host[m] = Ec<C>::identity();
         return;
     }
-    const xyzz_t *two = static_cast<const xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
+    const xyzz_t *raw = static_cast<const xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
+    // the device sums arrive in the R' = 2^261 form of the 29-bit multiplier: times 2^-5 (as a Montgomery product) -> ABI form
+    using F = typename C::F;
+    fe_t c = F::one();
+    for (int d = 0; d < 5; ++d) c = F::halve(c);
+    std::vector<xyzz_t> two(3 * (size_t)batch);
+    for (size_t i = 0; i < two.size(); ++i) {
+        two[i].x = F::mul(raw[i].x, c);
+        two[i].y = F::mul(raw[i].y, c);
+        two[i].zz = F::mul(raw[i].zz, c);
+        two[i].zzz = F::mul(raw[i].zzz, c);
+    }
     for (uint32_t m = 0; m < batch; ++m) {
         xyzz_t a = Ec<C>::add(Ec<C>::dbl(two[3 * m]), two[3 * m + 2]);
         for (uint32_t j = 1; j < RED_COLS; j <<= 1) a = Ec<C>::dbl(a);

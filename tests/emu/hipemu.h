@@ -207,23 +207,46 @@ inline uint32_t __emu_quad_bcast(uint32_t v, int k) {
 inline void __emu_shfl_down_bulk128(const void *in, void *out, unsigned d, int width) {
     using namespace hipemu;
     unsigned wave = t_lin / 64, lane = t_lin % 64;
-    std::memcpy(&g_ctx.bulk_slots[(size_t)t_lin * 32], in, 128);
+    std::memcpy(&g_ctx.bulk_slots[(size_t)t_lin * 48], in, 128);
     yield_as(WAIT_WAVE);
     unsigned wave_n = std::min(64u, g_ctx.nthreads - wave * 64);
     int src = (int)lane + (int)d;
     if (src / width != (int)lane / width || (unsigned)src >= wave_n) src = (int)lane;
     uint32_t tmp[32];
-    std::memcpy(tmp, &g_ctx.bulk_slots[(size_t)(wave * 64 + (unsigned)src) * 32], 128);
+    std::memcpy(tmp, &g_ctx.bulk_slots[(size_t)(wave * 64 + (unsigned)src) * 48], 128);
     yield_as(WAIT_WAVE);
     std::memcpy(out, tmp, 128);
+}
+// the same for up to 48 dwords (a point in 9-limb coordinates is 36)
+inline void __emu_shfl_down_bulk(const void *in, void *out, unsigned d, int width, unsigned nwords) {
+    using namespace hipemu;
+    unsigned wave = t_lin / 64, lane = t_lin % 64;
+    std::memcpy(&g_ctx.bulk_slots[(size_t)t_lin * 48], in, nwords * 4);
+    yield_as(WAIT_WAVE);
+    unsigned wave_n = std::min(64u, g_ctx.nthreads - wave * 64);
+    int src = (int)lane + (int)d;
+    if (src / width != (int)lane / width || (unsigned)src >= wave_n) src = (int)lane;
+    uint32_t tmp[48];
+    std::memcpy(tmp, &g_ctx.bulk_slots[(size_t)(wave * 64 + (unsigned)src) * 48], nwords * 4);
+    yield_as(WAIT_WAVE);
+    std::memcpy(out, tmp, nwords * 4);
+}
+inline void __emu_quad_bcast_n(const uint32_t *v, int k, uint32_t *out, unsigned nwords) {
+    using namespace hipemu;
+    std::memcpy(&g_ctx.quad_slots[(size_t)t_lin * 12], v, nwords * 4);
+    yield_as(WAIT_QUAD);
+    uint32_t tmp[12];
+    std::memcpy(tmp, &g_ctx.quad_slots[(size_t)((t_lin & ~3u) + (unsigned)k) * 12], nwords * 4);
+    yield_as(WAIT_QUAD);
+    std::memcpy(out, tmp, nwords * 4);
 }
 // 8 dwords at once (one field element): a single barrier pair instead of 8
 inline void __emu_quad_bcast8(const uint32_t *v, int k, uint32_t *out) {
     using namespace hipemu;
-    std::memcpy(&g_ctx.quad_slots[(size_t)t_lin * 8], v, 32);
+    std::memcpy(&g_ctx.quad_slots[(size_t)t_lin * 12], v, 32);
     yield_as(WAIT_QUAD);
     uint32_t tmp[8];
-    std::memcpy(tmp, &g_ctx.quad_slots[(size_t)((t_lin & ~3u) + (unsigned)k) * 8], 32);
+    std::memcpy(tmp, &g_ctx.quad_slots[(size_t)((t_lin & ~3u) + (unsigned)k) * 12], 32);
     yield_as(WAIT_QUAD);
     std::memcpy(out, tmp, 32);
 }
@@ -362,8 +385,8 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t dyn_smem, A... args) 
         g_ctx.fibers[t].tid.z = t / (block.x * block.y);
     }
     g_ctx.wave_slots.assign((size_t)((nthreads + 63) / 64) * 64, 0);
-    g_ctx.quad_slots.assign((size_t)((nthreads + 63) / 64) * 64 * 8, 0);
-    g_ctx.bulk_slots.assign((size_t)((nthreads + 63) / 64) * 64 * 32, 0);
+    g_ctx.quad_slots.assign((size_t)((nthreads + 63) / 64) * 64 * 12, 0);
+    g_ctx.bulk_slots.assign((size_t)((nthreads + 63) / 64) * 64 * 48, 0);
     auto body = [&]() { kernel(args...); };
     using B = decltype(body);
     g_ctx.entry = [](void *p) { (*static_cast<B *>(p))(); };
