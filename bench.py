@@ -189,6 +189,19 @@ class SangriaSide:
     def prove(self, S, D, ro_challenge=False, count_nonzero=False):
         """VanillaFS::prove hot path (src/nifs/sangria/mod.rs:253-277)."""
         self.settle()
+        if D.world == 1 and not count_nonzero:
+            # one library call (srs_sangria_prove): cross terms + commitments, challenge, folds in place, instance fold on host workers
+            ro = None
+            if ro_challenge:      # generate_challenge (:162-179): the instances are absorbed here, the commitments inside the call
+                ro = self.ro.reset()
+                for pt in (self.accCW, self.accCE, self.inC):
+                    ro.absorb_point(self.curve, pt)
+            pr = S.sangria_prove(self.ck, self.S, self.u1c, self.u1u, self.accW, self.u2c, self.inW, self.accE,
+                                 np.stack([self.accCW, self.inC]), self.accCE, r=None if ro_challenge else self.r, ro=ro)
+            self.r = pr["r"]
+            self.pending = (pr["E_commitment"], pr["W_commitment"])
+            self._keep = pr
+            return
         terms, commits = S.VanillaFS.commit_cross_terms(self.ck, self.S, self.u1c, self.u1u, self.accW, self.u2c, self.inW)
         if count_nonzero:
             self.nz_terms = sum(int((t != 0).any(dim=1).sum().item()) for t in terms)
@@ -257,29 +270,20 @@ class PgPrimary:
 
     def prove(self, S, D, ro_challenge=False):
         """ProtoGalaxy::prove (src/nifs/protogalaxy/mod.rs:400-481)."""
-        PG, ctx, m, FR = self.PG, self.ctx, self.m, self.FR
+        PG, ctx, m = self.PG, self.ctx, self.m
         self.settle()
         delta, alpha, gamma = self.chal
-        if ro_challenge:      # Challenges::generate_one (mod.rs:80-133): absorb the accumulator and the incoming instance
+        ro = None
+        if ro_challenge:      # Challenges::generate_one (mod.rs:80-133): the accumulator and the incoming instance are absorbed here
             ro = self.ro.reset()
             ro.absorb_field(np.concatenate([self.accC.reshape(2, 4), self.inC.reshape(2, 4)]))
             ro.absorb_field(self.betas)
             delta = PGint(ro.squeeze(128, 0))
-        poly_F = PG.compute_F(ctx, self.betas, m([delta])[0], self.accW, reference_compat=self.compat)
-        if ro_challenge:
-            alpha = PGint(self.ro.absorb_field(poly_F).squeeze(128, 0))
-        f_alpha = PG.poly_eval(poly_F, m([alpha])[0])
-        betas_stroke = PG.beta_stroke(self.betas, m([alpha])[0], m([delta])[0])     # BetaStrokeIter (poly/mod.rs:449-462)
-        poly_G = PG.compute_G(ctx, betas_stroke, [self.accW, self.inW], reference_compat=self.compat)
-        poly_K = PG.compute_K_from_G(ctx, poly_G, f_alpha)
-        if ro_challenge:
-            gamma = PGint(self.ro.absorb_field(poly_K).squeeze(128, 0))
-        g = m([gamma])[0]
-        Ls = PG.eval_lagrange_poly_for_cyclic_group(g, ctx.lagrange_domain)
-        self.e = PG.calculate_e(poly_F, poly_K, g, m([alpha])[0], ctx.lagrange_domain)
-        self.accW = PG.fold_witness(0, [self.accW, self.inW], Ls)                        # device, stream-ordered
-        self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), Ls[:2])   # fold_instance
-        self.betas = betas_stroke
+        # one library call (srs_pg_prove): F -> alpha -> betas' -> G -> K -> gamma -> L(gamma), e, fold_witness
+        pr = PG.prove(ctx, self.betas, m([delta])[0], [self.accW, self.inW], ro=ro,
+                      alpha=None if ro else m([alpha])[0], gamma=None if ro else m([gamma])[0], reference_compat=self.compat)
+        self.e, self.accW, self.betas = pr["e"], pr["W"], pr["betas_stroke"]
+        self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), pr["lagrange"][:2])   # fold_instance
 
     def witness_commit(self, S, D):
         """generate_plonk_trace -> run_sps_protocol_1: ck.commit(W1) of the NEW witness, host -> HBM inside the call."""

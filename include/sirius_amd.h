@@ -352,6 +352,17 @@ int srs_fold_witness(int field, srs_fe *out, const srs_fe *w1, const srs_fe *w2,
 int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const *T, size_t n_terms,
                    const srs_fe *r, size_t n, int space, void *stream);
 
+/* VanillaFS::prove (src/nifs/sangria/mod.rs:253-277) as ONE call on device-resident traces: commit_cross_terms (T_dev = d device
+ * vectors of 2^k elements, kept in HBM), the challenge -- with a random oracle `ro` (over the curve's base field, already holding
+ * pp_digest, U1, U2) r = ro.absorb_point_iter(commits).squeeze(128) (:162-179) is derived inside and returned in *r_io, with
+ * ro = NULL *r_io is used as given --, RelaxedPlonkWitness::fold IN PLACE (W1 <- W1 + r W2, E <- E + sum r^k T_k,
+ * accumulator.rs:364-404) and the group half of RelaxedPlonkInstance::fold on the library's host workers:
+ * folded_commitments[0] = W_commitments[0] + r W_commitments[1], folded_commitments[1] = E_commitment + sum r^k commits[k]
+ * (accumulator.rs:201-264), valid after srs_job_wait(jobs[0]) / srs_job_wait(jobs[1]).  `challenges` as in srs_commit_cross_terms. */
+int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, const srs_fe *W2,
+                      srs_fe *E, void *stream, srs_fe *r_io, srs_fe *const *T_dev, srs_affine *cross_term_commits,
+                      const srs_affine *W_commitments, const srs_affine *E_commitment, srs_affine *folded_commitments, uint64_t *jobs);
+
 /* ---- ProtoGalaxy NIFS polynomials (src/nifs/protogalaxy/poly/mod.rs), bn256::Fr structures only ----
  * Leaves f_i = S.gates[i / 2^k] at row(i) (get_evaluate_witness_fn, src/plonk/mod.rs:683-718), i < n =
  * (gates * 2^k).next_power_of_two(), zero beyond gates * 2^k; pow_i(c) = prod_{b in bits(i)} c_b.
@@ -370,6 +381,17 @@ typedef struct {                       /* PolyContext (poly/mod.rs:205-269) */
     uint32_t fft_log_domain_size_K;    /* (points_G + 1 - instances_to_fold).next_power_of_two() -- a count used as a log (:263-268) */
 } srs_pg_context;
 int srs_pg_context_new(const srs_structure *S, size_t traces_len, srs_pg_context *out);
+/* ProtoGalaxy::prove (src/nifs/protogalaxy/mod.rs:400-481) as ONE call on device-resident witnesses W[0] = accumulator, W[1..] =
+ * incoming traces: compute_F -> alpha -> betas_stroke -> compute_G -> compute_K_from_G -> gamma -> L_j(gamma), calculate_e,
+ * fold_witness.  `delta` comes from the caller (Challenges::generate_one absorbs instance data the shim owns, :409-414); with a
+ * random oracle `ro` (over bn256::Fr, already holding that transcript) alpha = ro.absorb(poly_F).squeeze(MAX_BITS = 255) and
+ * gamma = ro.absorb(poly_K).squeeze(255) are derived inside (:424-427,445-448) and returned in alpha_gamma[0..1]; with ro = NULL
+ * alpha_gamma holds them on entry.  Outputs: poly_F[fft_points_count_F], poly_K[2^fft_log_domain_size_K], betas_stroke[betas_count],
+ * e, lagrange[n_instances] = L_j(gamma) (for fold_instance, which stays with the caller), W_folded (device, stream-ordered). */
+int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t n_betas, const srs_fe *delta,
+                 const srs_fe *const *W, const srs_fe *const *challenges, size_t n_challenges, size_t n_instances, int reference_compat,
+                 void *stream, srs_fe *alpha_gamma, srs_fe *poly_F, srs_fe *poly_K, srs_fe *betas_stroke, srs_fe *e, srs_fe *lagrange,
+                 srs_fe *W_folded);
 /* PolyChallenges::iter_beta_stroke (poly/mod.rs:432-462): out[i] = betas[i] + alpha * delta^(2^i), i < n.  Host code (bn256::Fr). */
 int srs_pg_beta_stroke(const srs_fe *betas, size_t n, const srs_fe *alpha, const srs_fe *delta, srs_fe *out);
 /* compute_F (:68-203): poly_F[fft_points_count_F] = ifft_X( sum_i pow_i(betas + X*deltas) f_i(w) ), deltas_b = delta^(2^b) */

@@ -14,7 +14,7 @@ from .commitment import CommitmentKey, HostBuffer, PendingPoint, concatenate_wit
 from . import fft  # noqa: F401,E402
 from . import distributed, expression, field, plonk, poseidon, protogalaxy  # noqa: F401,E402
 from .poseidon import PoseidonHash  # noqa: F401,E402
-from .plonk import PlonkStructure, RelaxedPlonkWitness, SparseMatrix, VanillaFS, batch_invert_assigned  # noqa: F401,E402
+from .plonk import PlonkStructure, RelaxedPlonkWitness, SparseMatrix, VanillaFS, batch_invert_assigned, sangria_prove  # noqa: F401,E402
 
 
 def profile_enable(on=True):

@@ -1941,6 +1941,128 @@ int srs_pg_calculate_e(const srs_fe *poly_F, size_t n_F, const srs_fe *poly_K, s
     return SRS_OK;
 }
 
+// ProtoGalaxy::prove (src/nifs/protogalaxy/mod.rs:400-481) as ONE call: the five polynomial / fold steps and the two challenges
+// between them without a round trip through the caller per step.
+int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t n_betas, const srs_fe *delta,
+                 const srs_fe *const *W, const srs_fe *const *challenges, size_t n_challenges, size_t n_instances, int reference_compat,
+                 void *stream, srs_fe *alpha_gamma, srs_fe *poly_F, srs_fe *poly_K, srs_fe *betas_stroke, srs_fe *e, srs_fe *lagrange,
+                 srs_fe *W_folded) {
+    if (!S || !betas || !delta || !W || !alpha_gamma || !poly_F || !poly_K || !betas_stroke || !e || !lagrange || !W_folded ||
+        (n_challenges && !challenges))
+        return fail(SRS_ERR_INVALID, "srs_pg_prove: bad argument");
+    if (n_instances < 2) return fail(SRS_ERR_INVALID, "You can't fold 0 traces");                // poly/mod.rs:27
+    if (n_instances & (n_instances - 1)) return fail(SRS_ERR_INVALID, "instances_to_fold must be a power of two");
+    if (ro && ro->h->field != SRS_FIELD_FR) return fail(SRS_ERR_INVALID, "srs_pg_prove: the oracle must be over bn256::Fr");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        rowprog::Structure *s = S->s;
+        rowprog::PgSizes z;
+        if (!rowprog::pg_sizes(s, n_instances - 1, z)) return fail(SRS_ERR_INVALID, "structure has no gates");
+        if (n_betas < z.betas_count) return fail(SRS_ERR_INVALID, "srs_pg_prove: not enough betas");
+        const size_t wlen = rowprog::num_witness_columns(s) * rowprog::rows(s);
+        std::vector<const fe_t *> dW(n_instances), ch(n_instances);
+        for (size_t j = 0; j < n_instances; ++j) {
+            dW[j] = reinterpret_cast<const fe_t *>(W[j]);
+            ch[j] = n_challenges ? reinterpret_cast<const fe_t *>(challenges[j]) : nullptr;
+        }
+        std::string err;
+        size_t n_out = 0;
+        // poly_F = compute_F(betas, delta, accumulator)                                                   :417-422
+        int erc = rowprog::pg_sum(s, 0, dW.data(), ch.data(), n_challenges, 1, reinterpret_cast<const fe_t *>(betas), n_betas,
+                                  reinterpret_cast<const fe_t *>(delta), reference_compat, st, reinterpret_cast<fe_t *>(poly_F), &n_out, err);
+        if (erc) return fail(erc, "srs_pg_prove (compute_F): " + err);
+        // alpha = ro.absorb(poly_F).squeeze(MAX_BITS)                                                     :424-427
+        fe_t alpha, gamma;
+        std::memcpy(&alpha, &alpha_gamma[0], 32);
+        std::memcpy(&gamma, &alpha_gamma[1], 32);
+        if (ro) {
+            poseidon::absorb(*ro->h, reinterpret_cast<const fe_t *>(poly_F), z.points_F);
+            if (!poseidon::squeeze(*ro->h, 255, SRS_FIELD_FR, alpha, err)) return fail(SRS_ERR_INVALID, "srs_pg_prove (alpha): " + err);
+        }
+        // betas_stroke (BetaStrokeIter :449-462), F(alpha)
+        std::vector<fe_t> bs(z.betas_count);
+        {
+            fe_t d;
+            std::memcpy(&d, delta, 32);
+            for (size_t i = 0; i < z.betas_count; ++i) {
+                fe_t b;
+                std::memcpy(&b, &betas[i], 32);
+                bs[i] = Fr::add(b, Fr::mul(alpha, d));
+                d = Fr::sqr(d);
+            }
+        }
+        const fe_t f_alpha = rowprog::poly_eval(reinterpret_cast<const fe_t *>(poly_F), z.points_F, alpha);
+        // poly_K = compute_K(F(alpha), betas_stroke, accumulator, incoming)                               :437-443
+        std::vector<fe_t> poly_G(z.points_G);
+        erc = rowprog::pg_sum(s, 1, dW.data(), ch.data(), n_challenges, n_instances, bs.data(), bs.size(), nullptr, reference_compat, st,
+                              poly_G.data(), &n_out, err);
+        if (erc) return fail(erc, "srs_pg_prove (compute_G): " + err);
+        erc = rowprog::pg_K_from_G(poly_G.data(), poly_G.size(), f_alpha, z.instances_to_fold, z.log_domain_K, st,
+                                   reinterpret_cast<fe_t *>(poly_K), err);
+        if (erc) return fail(erc, "srs_pg_prove (compute_K_from_G): " + err);
+        const size_t n_K = (size_t)1 << z.log_domain_K;
+        // gamma = ro.absorb(poly_K).squeeze(MAX_BITS)                                                     :445-448
+        if (ro) {
+            poseidon::absorb(*ro->h, reinterpret_cast<const fe_t *>(poly_K), n_K);
+            if (!poseidon::squeeze(*ro->h, 255, SRS_FIELD_FR, gamma, err)) return fail(SRS_ERR_INVALID, "srs_pg_prove (gamma): " + err);
+        }
+        // L_j(gamma), e = F(alpha) L_0(gamma) + Z(gamma) K(gamma)  (calculate_e :748-764), fold_witness :176-210
+        const std::vector<fe_t> L = rowprog::lagrange_eval(gamma, (uint32_t)z.lagrange_domain);
+        const fe_t zg = Fr::sub(Fr::pow_u64(gamma, (uint64_t)1 << z.lagrange_domain), Fr::one());
+        const fe_t kg = rowprog::poly_eval(reinterpret_cast<const fe_t *>(poly_K), n_K, gamma);
+        const fe_t ev = Fr::add(Fr::mul(f_alpha, L[0]), Fr::mul(zg, kg));
+        erc = rowprog::lincomb(SRS_FIELD_FR, reinterpret_cast<fe_t *>(W_folded), dW.data(), L.data(), n_instances, wlen, st, err);
+        if (erc) return fail(erc, "srs_pg_prove (fold_witness): " + err);
+        std::memcpy(&alpha_gamma[0], &alpha, 32);
+        std::memcpy(&alpha_gamma[1], &gamma, 32);
+        std::memcpy(betas_stroke, bs.data(), bs.size() * sizeof(fe_t));
+        std::memcpy(e, &ev, 32);
+        std::memcpy(lagrange, L.data(), n_instances * sizeof(fe_t));
+        return SRS_OK;
+    });
+}
+
+// VanillaFS::prove (src/nifs/sangria/mod.rs:253-277) as ONE call on device-resident traces: cross terms + their commitments, the
+// challenge, the witness / error folds (in place) and the instance fold (host workers, joined with srs_job_wait).
+int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, const srs_fe *W2,
+                      srs_fe *E, void *stream, srs_fe *r_io, srs_fe *const *T_dev, srs_affine *cross_term_commits,
+                      const srs_affine *W_commitments /* [2]: U1, U2 */, const srs_affine *E_commitment, srs_affine *folded_commitments /* [2]: W, E */,
+                      uint64_t *jobs /* [2] */) {
+    if (!S || !ck || !W1 || !W2 || !E || !r_io || !T_dev || !cross_term_commits || !W_commitments || !E_commitment || !folded_commitments || !jobs)
+        return fail(SRS_ERR_INVALID, "srs_sangria_prove: bad argument");
+    const int curve = ck->key.curve, sf = srs_scalar_field_of(curve);
+    if (ro && ro->h->field != (curve == SRS_CURVE_BN256 ? SRS_FIELD_FQ : SRS_FIELD_FR))
+        return fail(SRS_ERR_INVALID, "srs_sangria_prove: the oracle's field is not the curve's base field");
+    const size_t d = srs_structure_num_cross_terms(S), rows = rowprog::rows(S->s), wlen = rowprog::num_witness_columns(S->s) * rows;
+    int rc = srs_commit_cross_terms(S, ck, W1, W2, challenges, n_challenges, SRS_SPACE_DEVICE, stream, T_dev, cross_term_commits);
+    if (rc) return rc;
+    fe_t r;
+    std::memcpy(&r, r_io, 32);
+    if (ro) {       // generate_challenge (:162-179): the caller has absorbed pp_digest, U1, U2; the commitments and the squeeze happen here
+        for (size_t k = 0; k < d; ++k) {
+            rc = srs_poseidon_absorb_point(ro, curve, &cross_term_commits[k]);
+            if (rc) return rc;
+        }
+        rc = srs_poseidon_squeeze(ro, 128, sf, reinterpret_cast<srs_fe *>(&r));
+        if (rc) return rc;
+        std::memcpy(r_io, &r, 32);
+    }
+    // W' = W1 + r W2, E' = E + sum r^k T_k  (accumulator.rs:364-404): stream-ordered, in place
+    rc = srs_fold_witness(sf, W1, W1, W2, reinterpret_cast<const srs_fe *>(&r), wlen, SRS_SPACE_DEVICE, stream);
+    if (rc) return rc;
+    rc = srs_fold_error(sf, E, E, reinterpret_cast<const srs_fe *const *>(T_dev), d, reinterpret_cast<const srs_fe *>(&r), rows, SRS_SPACE_DEVICE, stream);
+    if (rc) return rc;
+    // U' (accumulator.rs:201-264): W_commitment' = C1 + r C2, E_commitment' = E_c + sum r^k T_c_k -- off the caller's thread
+    std::vector<srs_fe> rp(d ? d : 1);
+    srs_fe_powers(sf, reinterpret_cast<const srs_fe *>(&r), d, rp.data());
+    rc = srs_point_lincomb_async(curve, &W_commitments[0], &W_commitments[1], reinterpret_cast<const srs_fe *>(&r), 1, SRS_REPR_MONT,
+                                 &folded_commitments[0], &jobs[0]);
+    if (rc) return rc;
+    return srs_point_lincomb_async(curve, E_commitment, cross_term_commits, rp.data(), d, SRS_REPR_MONT, &folded_commitments[1], &jobs[1]);
+}
+
 int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n, int space, void *stream) {
     if (!valid_field(field) || !coefs || !W || (n && !out) || J == 0) return fail(SRS_ERR_INVALID, "srs_fold_lincomb: bad argument");
     if (n == 0) return SRS_OK;

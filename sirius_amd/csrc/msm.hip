@@ -792,7 +792,7 @@ __global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
     k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
     constexpr uint32_t N = RED_COLS;                       // 128 elements per block
     using E29 = Ec29<C>;
-    __shared__ xyzz_t v[N];                                // canonical R'-form records; registers hold the lazy 9-limb form
+    __shared__ xyzz29_t v[N];                              // lazy 9-limb coordinates: packing (two products) only for the final store
     const uint32_t m = blockIdx.y, t = threadIdx.x >> 2, q = threadIdx.x & 3u, which = blockIdx.x;
     const xyzz_t *rows = rc + (size_t)m * (RED_ROWS + RED_COLS), *cols = rows + RED_ROWS;
     xyzz29_t x;
@@ -800,28 +800,28 @@ __global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
     else if (which == 1) x = E29::unpack(cols[t]);
     else x = E29::unpack(rows[2 * t + 1]);
     if (which != 2) {
-        if (q == 0) v[t] = E29::pack(x);
+        if (q == 0) v[t] = x;
         __syncthreads();
         for (uint32_t s = 1; s < N; s <<= 1) {             // suffix scan
             const bool has = t + s < N;
-            xyzz29_t o = has ? E29::unpack(v[t + s]) : E29::identity();
+            xyzz29_t o = has ? v[t + s] : E29::identity();
             __syncthreads();
             if (has) x = E29::add_quad(x, o, q);
-            if (q == 0) v[t] = E29::pack(x);
+            if (q == 0) v[t] = x;
             __syncthreads();
         }
         if (which == 0 && t == 0) x = E29::identity();
     }
-    if (q == 0) v[t] = E29::pack(x);
+    if (q == 0) v[t] = x;
     __syncthreads();
     for (uint32_t s = N >> 1; s >= 1; s >>= 1) {           // tree sum
         if (t < s) {                                       // x is kept in registers by all 4 lanes: the quad's own
-            x = E29::add_quad(x, E29::unpack(v[t + s]), q);      // slot is never re-read, so lane 0's store cannot race with it
-            if (q == 0) v[t] = E29::pack(x);
+            x = E29::add_quad(x, v[t + s], q);             // slot is never re-read, so lane 0's store cannot race with it
+            if (q == 0) v[t] = x;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(size_t)m * 3 + which] = v[0];
+    if (threadIdx.x == 0) out[(size_t)m * 3 + which] = E29::pack(v[0]);
 }
 
 // ---------------------------------------------------------------------------------------------

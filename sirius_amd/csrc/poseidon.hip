@@ -153,10 +153,16 @@ Hash *create(int field, size_t t, size_t rate, size_t r_f, size_t r_p, std::stri
 void absorb(Hash &h, const fe_t *v, size_t n) { h.buf.insert(h.buf.end(), v, v + n); }
 
 bool squeeze(Hash &h, size_t num_bits, int out_field, fe_t &out, std::string &err) {
-    if (num_bits == 0 || num_bits > 253) { err = "num_bits must be in 1..253"; return false; }
+    if (num_bits == 0 || num_bits > 256) { err = "num_bits must be in 1..256"; return false; }
     fe_t canon = h.field == 0 ? run<Fr>(h) : run<Fq>(h);
     for (size_t b = num_bits; b < 256; ++b) canon.v[b >> 5] &= ~(1u << (b & 31));     // bits[..num_bits] (little endian)
-    out = out_field == 0 ? Fr::to_mont(canon) : Fq::to_mont(canon);                    // < 2^253 < both moduli
+    // bits_to_fe_le -> F1::from_repr(..).unwrap() (src/util/mod.rs:58-64): up to 253 bits fit both moduli; the reference's own
+    // MAX_BITS = 255 (src/constants.rs:4) keeps the whole element, which must then be a residue of the output field
+    if (num_bits > 253 && !(out_field == 0 ? less_than_p<Fr, FrP>(canon) : less_than_p<Fq, FqP>(canon))) {
+        err = "squeezed value is not a canonical element of the output field (the reference's from_repr(..).unwrap() panics here)";
+        return false;
+    }
+    out = out_field == 0 ? Fr::to_mont(canon) : Fq::to_mont(canon);
     return true;
 }
 

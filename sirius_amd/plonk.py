@@ -288,6 +288,33 @@ class VanillaFS:
         return terms, commits
 
 
+def sangria_prove(ck, S, U1_challenges, U1_u, W1, U2_challenges, W2, E, W_commitments, E_commitment, r=None, ro=None):
+    """`VanillaFS::prove` (src/nifs/sangria/mod.rs:253-277) as one library call (srs_sangria_prove) on device-resident traces:
+    W1 and E are folded IN PLACE.  r: the challenge (when `ro` is None) -- otherwise squeezed from `ro` (a PoseidonHash over the
+    curve's base field that has absorbed pp_digest, U1, U2) after the cross-term commitments.
+    -> dict(terms, commits, r, W_commitment: PendingPoint, E_commitment: PendingPoint)."""
+    from .commitment import PendingPoint
+    ch = VanillaFS.cross_term_challenges(U1_challenges, U1_u, U2_challenges, S.field)
+    a1, sp1, n1, k1 = _buf(W1, 4)
+    a2, sp2, n2, k2 = _buf(W2, 4)
+    ae, spe, ne, ke = _buf(E, 4)
+    assert n1 == n2 == S.num_witness_columns * S.rows and ne == S.rows
+    d = S.num_cross_terms
+    terms = [_alloc_like(W1, S.rows) for _ in range(d)]
+    tp = (C.c_void_p * max(d, 1))(*[(t.data_ptr() if _is_torch(t) else t.ctypes.data) for t in terms])
+    commits = np.zeros((d, 8), dtype=np.uint64)
+    rr = np.zeros(4, dtype=np.uint64) if r is None else np.ascontiguousarray(r, dtype=np.uint64).reshape(4).copy()
+    wc = np.ascontiguousarray(W_commitments, dtype=np.uint64).reshape(2, 8)
+    ec = np.ascontiguousarray(E_commitment, dtype=np.uint64).reshape(8)
+    folded = np.zeros((2, 8), dtype=np.uint64)
+    jobs = (C.c_uint64 * 2)()
+    lib = L.lib()
+    L.check(lib.srs_sangria_prove(S._h, ck._h, None if ro is None else ro._h, ch.ctypes.data, ch.shape[0], a1, a2, ae, _stream(), rr.ctypes.data, tp,
+                                  commits.ctypes.data, wc.ctypes.data, ec.ctypes.data, folded.ctypes.data, jobs))
+    return dict(terms=terms, commits=commits, r=rr, W_commitment=PendingPoint(jobs[0], folded[0], lib), E_commitment=PendingPoint(jobs[1], folded[1], lib),
+                _keep=(folded, wc, ec))
+
+
 class RelaxedPlonkWitness:
     """{ W: Vec<Vec<F>>, E: Box<[F]> }  (src/nifs/sangria/accumulator.rs:485-489)."""
 

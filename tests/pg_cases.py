@@ -54,6 +54,25 @@ def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
     Lg = P.eval_lagrange_poly_for_cyclic_group(gamma, octx.lagrange_domain())
     assert O.mont_to_ints(O.FR, PG.eval_lagrange_poly_for_cyclic_group(m([gamma])[0], ctx.lagrange_domain)) == Lg
     assert np.array_equal(PG.fold_witness(0, Ws, m(Lg)), OPG.fold_witness(O, Ws, Lg)), "fold_witness"
+    # ProtoGalaxy::prove as one call (srs_pg_prove) == the step-by-step results; with an oracle: alpha / gamma squeezed inside
+    if octx.fft_log_domain_size_K() <= 8:
+        import torch
+        dWs = [torch.from_numpy(w.view(np.int64)).cuda() for w in Ws] if torch.cuda.is_available() else Ws    # device-resident (emulator: host)
+        pr = PG.prove(ctx, m(betas), m([delta])[0], dWs, alpha=m([alpha])[0], gamma=m([gamma])[0], reference_compat=compat)
+        assert np.array_equal(pr["poly_F"], pF) and np.array_equal(pr["poly_K"], pK) and O.mont_to_ints(O.FR, pr["betas_stroke"]) == bs
+        assert np.array_equal(pr["e"], got) and np.array_equal(pr["lagrange"], m(Lg)[: len(Ws)])
+        Wf = pr["W"]
+        assert np.array_equal(Wf.cpu().numpy().view(np.uint64).reshape(-1, 4) if hasattr(Wf, "cpu") else Wf, OPG.fold_witness(O, Ws, Lg))
+        from oracle import poseidon as OP
+        ro, oro = S.PoseidonHash(0, 5, 4, 10, 10), OP.PoseidonHash(P.FR, 5, 4, 10, 10)
+        ro.absorb_field(m([delta])); oro.absorb_field_iter([delta])
+        pr2 = PG.prove(ctx, m(betas), m([delta])[0], dWs, ro=ro, reference_compat=compat)
+        a2 = oro.absorb_field_iter(O.mont_to_ints(O.FR, pr2["poly_F"])).squeeze(255)
+        assert O.mont_to_ints(O.FR, pr2["alpha"]) == [a2] and np.array_equal(pr2["poly_F"], pF)
+        g2 = oro.absorb_field_iter(O.mont_to_ints(O.FR, pr2["poly_K"])).squeeze(255)
+        assert O.mont_to_ints(O.FR, pr2["gamma"]) == [g2]
+        eG2 = OPG.compute_G(oS, octx, OPG.beta_stroke(betas, a2, delta), Ws, [[] for _ in Ws], compat)
+        assert O.mont_to_ints(O.FR, pr2["poly_K"]) == OPG.compute_K_from_G(octx, eG2, OPG.poly_eval(eF, a2))
     St.close()
     return ctx
 

@@ -401,3 +401,51 @@ def test_long_level0_parts_match_oracle(srs, oracle):
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0=l0), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (l0, r.stdout[-500:], r.stderr[-1500:])
+
+
+def _concat_ref(cols, pad):
+    """util::concatenate_with_padding (src/util/mod.rs:214-218): every vector followed by zeros up to pad_size."""
+    out = []
+    for c in cols:
+        out.append(np.asarray(c, dtype=np.uint64).reshape(-1, 4))
+        if out[-1].shape[0] < pad:
+            out.append(np.zeros((pad - out[-1].shape[0], 4), np.uint64))
+    return np.ascontiguousarray(np.concatenate(out)) if out else np.zeros((0, 4), np.uint64)
+
+
+def _concat_cases(S, O, cid, make_dev, k=11):
+    """The reference's own unit tests of concatenate_with_padding (src/util/mod.rs:233-290: empty input, padding of one vector,
+    perfect fit, several ragged vectors, pad_size = 1 with a longer vector) on the device, then the column-wise streamed
+    witness commit `ck.commit(&concatenate_with_padding(advice, 2^k))` (src/plonk/mod.rs:441-447) against the oracle, with columns
+    SHORTER than 2^k (and one empty), for several chunk layouts."""
+    sf = O.SCALAR_FIELD[cid]
+    fp = lambda *v: O.ints_to_mont(sf, list(v))
+    for cols, pad in (([], 4), ([fp(1, 2)], 4), ([fp(1, 2, 3, 4)], 4), ([fp(1, 2), fp(3), fp(4, 5, 6)], 4), ([fp(1), fp(2, 3)], 1)):
+        want = _concat_ref(cols, pad)
+        d = make_dev(want.shape[0])
+        S.concatenate_with_padding(cols, pad, d)
+        assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(-1, 4), want), (len(cols), pad)
+    rows = 1 << k
+    bases = O.make_bases(cid, 31, 5 * rows)
+    ck = S.CommitmentKey(cid, bases)
+    v = seeded_scalars(O, cid, 5 * rows, 41, "trace")
+    cols = [v[:rows], v[rows:rows + (3 * rows) // 4], v[3:3], v[2 * rows:3 * rows], v[4 * rows:4 * rows + 17]]      # full, short, empty, full, very short
+    W = _concat_ref(cols, rows)
+    want = O.msm(cid, W, bases[: W.shape[0]])
+    d = make_dev(W.shape[0])
+    assert np.array_equal(ck.commit_upload_columns(cols, rows, dev_copy=d), want)
+    assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(-1, 4), W)
+    assert np.array_equal(ck.commit_upload_columns(cols, rows), want)
+    assert np.array_equal(ck.commit(d), want)
+    with pytest.raises(S.TooLongInput):
+        ck.commit_upload_columns(cols + [v[:rows]], rows)
+    mk = S.CommitmentKey.create_multi(cid, bases, 3)
+    assert np.array_equal(mk.commit_upload_columns(cols, rows), want)
+    mk.close()
+    ck.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1])
+def test_concatenate_with_padding_and_column_commit(srs, oracle, cid):
+    import torch
+    _concat_cases(srs, oracle, cid, lambda n: torch.full((n, 4), 7, dtype=torch.int64, device="cuda"))

@@ -227,3 +227,10 @@ def test_emu_long_level0_parts():
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0="6"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_emu_concatenate_with_padding(emu, oracle):
+    """SURVEY A17 on the emulator: the reference's concatenate_with_padding unit tests + the column-wise witness commit."""
+    import torch
+    from test_commit_gpu import _concat_cases
+    _concat_cases(emu, oracle, 1, lambda n: torch.full((n, 4), 7, dtype=torch.int64), k=8)

@@ -246,6 +246,29 @@ def _fold_then_decide(S, O, field, curve, k, gate_T):
         rp.append(O.fe_mul(sf, rp[-1].reshape(1, 4), r.reshape(1, 4))[0])
     assert np.array_equal(ck.commit(acc.W[0]), S.point_lincomb(curve, ck.commit(W1), ck.commit(W2).reshape(1, 8), r.reshape(1, 4)))
     assert np.array_equal(ck.commit(acc.E), S.point_lincomb(curve, None, commits, np.stack(rp)))
+    # VanillaFS::prove as ONE call (srs_sangria_prove) on device-resident traces: same cross terms, commitments, folds (in place) and
+    # folded instance commitments; with an oracle the challenge is squeezed inside from the absorbed commitments
+    import torch
+    dv = (lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()) if torch.cuda.is_available() else (lambda a: np.ascontiguousarray(a).copy())
+    host = lambda t: t.cpu().numpy().view(np.uint64).reshape(-1, 4) if hasattr(t, "cpu") else t
+    cW1, cW2 = ck.commit(W1), ck.commit(W2)
+    dW1, dE = dv(W1), dv(zeroE)
+    pr = S.sangria_prove(ck, St, y1, one, dW1, y2, dv(W2), dE, np.stack([cW1, cW2]), np.zeros(8, np.uint64), r=r)
+    assert np.array_equal(pr["commits"], commits) and all(np.array_equal(host(a), b) for a, b in zip(pr["terms"], terms))
+    assert np.array_equal(host(dW1), acc.W[0]) and np.array_equal(host(dE), acc.E)
+    assert np.array_equal(pr["W_commitment"].wait(), ck.commit(acc.W[0])) and np.array_equal(pr["E_commitment"].wait(), ck.commit(acc.E))
+    from oracle import poseidon as OP
+    from oracle import pyref as P
+    bf = O.BASE_FIELD[curve]
+    ro, oro = S.PoseidonHash(bf, 5, 4, 10, 10), OP.PoseidonHash(P.MODULI[bf], 5, 4, 10, 10)
+    ro.absorb_point(curve, cW1); oro.absorb_point(tuple(O.mont_to_ints(bf, cW1.reshape(2, 4))))
+    dW1b, dEb = dv(W1), dv(zeroE)
+    pr2 = S.sangria_prove(ck, St, y1, one, dW1b, y2, dv(W2), dEb, np.stack([cW1, cW2]), np.zeros(8, np.uint64), ro=ro)
+    for c in commits:
+        oro.absorb_point(tuple(O.mont_to_ints(bf, c.reshape(2, 4))))
+    assert O.mont_to_ints(sf, pr2["r"]) == [oro.squeeze(128)]
+    assert np.array_equal(host(dW1b), O.fold_w(field, W1, W2, pr2["r"]))
+    pr2["W_commitment"].wait(); pr2["E_commitment"].wait()
     St.close()
 
 
