@@ -370,8 +370,7 @@ void free_shards(srs_ck *ck) {
         }
         (void)hipSetDevice(sh->device);
         if (sh->key.table) (void)hipFree(sh->key.table);
-        if (sh->key.h_result) (void)hipHostFree(sh->key.h_result);
-        sh->key.arena.release();
+        msm::release(sh->key);
         sh->staging.release();
         if (sh->stream) (void)hipStreamDestroy(sh->stream);
     }
@@ -770,8 +769,7 @@ void srs_ck_free(srs_ck *ck) {
     for (hipEvent_t e : ck->events) (void)hipEventDestroy(e);
     if (ck->copy_stream) (void)hipStreamDestroy(ck->copy_stream);
     if (ck->key.table) (void)hipFree(ck->key.table);
-    if (ck->key.h_result) (void)hipHostFree(ck->key.h_result);
-    ck->key.arena.release();
+    msm::release(ck->key);
     ck->staging.release();
     delete ck;
 }

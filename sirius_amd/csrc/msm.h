@@ -31,6 +31,17 @@ constexpr uint32_t ACC1_QUAD_MAX = 1u << 16;     // k_accum1 runs one quad per o
 constexpr uint32_t BATCH_ARGS = 16;    // MSMs per set of launches (batch descriptor = kernel argument); larger batches are chunked
 constexpr uint32_t LANDING_SLOTS = 16;  // sets of launches whose results may be in flight at once (chunked commits)
 constexpr uint32_t NORM_G = 16;           // points per inversion in the key-expansion normalise
+// Wide windows for large MSMs: 13 signed 20-bit digits per scalar instead of 16 signed 16-bit ones (19 % fewer bucket additions).
+// The 2^19 buckets are NSEG_W "virtual MSMs" of NBUCKET buckets each (bucket = seg * NBUCKET + lo): one MSD pass groups the
+// entries by segment, then every stage of the 16-bit pipeline runs on the 16 segments as a batch.
+constexpr int WBITS_W = 20;
+constexpr int NWIN_W = 13;                // ceil(254 / 20); the top digit has 14 bits + carry
+constexpr uint32_t NSEG_W = 16;           // 2^(WBITS_W - 1) / NBUCKET
+constexpr uint32_t WIDE_THREADS = 256, WIDE_PER = 2, WIDE_TILE = WIDE_THREADS * WIDE_PER;   // scalars per workgroup of the segment passes
+// Measured (profiles/r02_wide_windows.txt): the wide pipeline wins from ~8 M scalars (12 * 2^20 uniform: 20.3 vs 22.2 ms);
+// below, its 16 bucket reductions and the extra grouping pass cost more than the 3 / 16 of the additions it saves.
+constexpr uint32_t WIDE_MIN_KEY_LOG = 23; // keys from 2^23 bases get the second (13-window) table (SRS_MSM_WIDE=0 / 1: never / always)
+constexpr uint32_t WIDE_MIN_N_LOG = 23;   // MSMs from 2^23 scalars take the wide path (SRS_MSM_WIDE_MIN=<log2> overrides)
 
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
 static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
@@ -44,12 +55,16 @@ struct Key {
     uint32_t rank = 0, world = 1;
     bool compact_scalars = false;   // world > 1: the scalar vectors handed to run() hold ONLY this rank's stripes, gathered (multi-device keys)
     affine_t *table = nullptr;
+    affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (keys of >= 2^WIDE_MIN_KEY_LOG bases; owned by the key: release())
+    bool slot_wide[LANDING_SLOTS] = {};       // landing slot -> which pipeline produced it (finish() combines 3 or 4 partial sums)
     Arena arena;              // per-key scratch (grow-only)
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
 };
 
-// fills table[len .. 16*len) from table[0 .. len)
+// fills table[len .. 16*len) from table[0 .. len); keys of >= 2^WIDE_MIN_KEY_LOG bases also get table_w
 void build_table(Key &k, hipStream_t stream);
+// frees what the key owns besides `table`: table_w, the scratch arena, the landing buffer
+void release(Key &k);
 // fills table[0 .. len) with the synthetic key (see k_gen_bases)
 void generate_bases(Key &k, uint64_t seed, hipStream_t stream);
 

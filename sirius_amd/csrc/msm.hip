@@ -61,7 +61,7 @@ __device__ __forceinline__ size_t shard_global_index(size_t i, uint32_t rank, ui
 // key expansion: T[w][i] = 2^(16 w) P_i
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ void k_table_step(const affine_t *__restrict__ prev, xyzz_t *__restrict__ tmp, uint32_t n) {
+__global__ void k_table_step(const affine_t *__restrict__ prev, xyzz_t *__restrict__ tmp, uint32_t n, int nbits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     affine_t p = prev[i];
@@ -70,7 +70,7 @@ __global__ void k_table_step(const affine_t *__restrict__ prev, xyzz_t *__restri
         a = Ec<C>::identity();
     } else {
         a = Ec<C>::dbl_affine(p);
-        for (int k = 1; k < WBITS; ++k) a = Ec<C>::dbl(a);
+        for (int k = 1; k < nbits; ++k) a = Ec<C>::dbl(a);
     }
     tmp[i] = a;
 }
@@ -407,6 +407,239 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     });
 }
 
+// Wide windows: the NSEG_W virtual MSMs share ONE parts / map array per level parity instead of a worst-case stride each
+// (a witness of small values puts every entry into segment 0).  base[l][v] = first level-l part of segment v in the flat
+// thread space of level l (base[l][NSEG_W] = their number); in memory the parts of level l of segment v start at
+// base[l & 1][v] of ping (even l) / pong (odd l): a level never has more parts than the level two below it.
+struct Link {
+    uint32_t base[MAX_LEVELS + 1][NSEG_W + 1];
+};
+__device__ __forceinline__ uint32_t link_segment(const uint32_t *__restrict__ base, uint32_t t) {   // base[v] <= t < base[v + 1]
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t u = 1; u < NSEG_W; ++u) v += (t >= base[u]) ? 1u : 0u;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2b. wide windows: scalars -> 13 signed 20-bit digits -> entries grouped by segment (the top 4 bits of the bucket)
+// code = 0xFFFFFFFF (zero digit) | (|d| - 1) [19 bits] | sign << 31
+// ---------------------------------------------------------------------------------------------
+struct WideDesc {
+    const fe_t *ptr;
+    uint32_t n, base;               // scalars, first base inside the key
+    uint32_t rank, world;           // as k_digits
+    int is_mont;
+};
+
+template <class C>
+__device__ __forceinline__ void wide_codes(const WideDesc &wd, uint32_t i, uint32_t (&code)[NWIN_W]) {
+    using S = typename C::S;
+    if (i >= wd.n) {
+#pragma unroll
+        for (int w = 0; w < NWIN_W; ++w) code[w] = 0xFFFFFFFFu;
+        return;
+    }
+    fe_t s = wd.ptr[shard_global_index(i, wd.rank, wd.world)];
+    if (wd.is_mont) s = S::from_mont(s);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NWIN_W; ++w) {
+        const int bit = WBITS_W * w, limb = bit >> 5, sh = bit & 31;
+        uint64_t two = s.v[limb];
+        if (limb + 1 < 8) two |= (uint64_t)s.v[limb + 1] << 32;
+        const uint32_t v = ((uint32_t)(two >> sh) & 0xFFFFFu) + carry;
+        if (v > 0x80000u) {
+            code[w] = ((0x100000u - v) - 1u) | 0x80000000u;   // negative digit, magnitude 1..0x7FFFF (v = 2^20: zero digit, carry)
+            carry = 1;
+        } else {
+            code[w] = v ? (v - 1u) : 0xFFFFFFFFu;             // positive digit 1..0x80000, or zero
+            carry = 0;
+        }
+    }
+}
+
+// The two segment passes over the scalars (the digits are recomputed rather than stored: 32 B read per scalar instead of
+// 52 B written and read).  A workgroup takes WIDE_TILE scalars = up to 6656 entries; the 16 segment counters are kept per
+// wavefront in LDS (64 words = 64 banks), so an atomic only meets the lanes of its own wavefront.
+//   GROUP = false: tile_cnt[v][tile] = entries of the tile in segment v; seg_total[v] += the same
+//   GROUP = true : tile_cnt holds the scanned offsets (k_seg_scan): the tile's entries are ordered by segment in LDS (the
+//                  returning atomic is the entry's rank) and leave as 16 coalesced runs of
+//                  (key = low 15 bits of the bucket, payload = table index | sign << 31)
+template <class C, bool GROUP>
+__global__ void SRS_KERNEL_BOUNDS(WIDE_THREADS, 1)
+    k_seg_pass(WideDesc wd, uint32_t *__restrict__ tile_cnt, uint32_t T, uint32_t *__restrict__ seg_total,
+               uint16_t *__restrict__ gkey, uint32_t *__restrict__ gpay, uint32_t table_stride) {
+    constexpr uint32_t NW = WIDE_THREADS / 64, STAGE = GROUP ? WIDE_TILE * NWIN_W : 1;
+    __shared__ uint32_t wc[NW][NSEG_W];          // counts, then (GROUP) the next free staging slot of (wavefront, segment)
+    __shared__ uint32_t ss[NSEG_W + 1], goff[NSEG_W];
+    __shared__ uint16_t skey[STAGE];
+    __shared__ uint32_t spay[STAGE];
+    const uint32_t tile = blockIdx.x, wave = threadIdx.x >> 6;
+    if (threadIdx.x < NW * NSEG_W) (&wc[0][0])[threadIdx.x] = 0;
+    uint32_t code[WIDE_PER][NWIN_W];
+#pragma unroll
+    for (uint32_t k = 0; k < WIDE_PER; ++k) wide_codes<C>(wd, tile * WIDE_TILE + k * WIDE_THREADS + threadIdx.x, code[k]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < WIDE_PER; ++k) {
+#pragma unroll
+        for (int w = 0; w < NWIN_W; ++w) {
+            const uint32_t c = code[k][w];
+            if (c != 0xFFFFFFFFu) atomicAdd(&wc[wave][(c >> 15) & (NSEG_W - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NSEG_W) {
+        const uint32_t v = threadIdx.x;
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < NW; ++w) tot += wc[w][v];
+        if (!GROUP) {
+            tile_cnt[(size_t)v * T + tile] = tot;
+            if (tot) atomicAdd(&seg_total[v], tot);
+        } else {
+            ss[v + 1] = tot;
+            goff[v] = tile_cnt[(size_t)v * T + tile];
+        }
+    }
+    if (!GROUP) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t v = 0; v < NSEG_W; ++v) {
+            const uint32_t c = ss[v + 1];
+            ss[v] = run;
+            run += c;
+        }
+        ss[NSEG_W] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSEG_W) {                  // counts -> first staging slot of (wavefront, segment)
+        const uint32_t v = threadIdx.x;
+        uint32_t run = ss[v];
+        for (uint32_t w = 0; w < NW; ++w) {
+            const uint32_t c = wc[w][v];
+            wc[w][v] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < WIDE_PER; ++k) {
+        const uint32_t i = tile * WIDE_TILE + k * WIDE_THREADS + threadIdx.x;
+#pragma unroll
+        for (int w = 0; w < NWIN_W; ++w) {
+            const uint32_t c = code[k][w];
+            if (c != 0xFFFFFFFFu) {
+                const uint32_t pos = atomicAdd(&wc[wave][(c >> 15) & (NSEG_W - 1)], 1u);
+                skey[pos] = (uint16_t)(c & 0x7FFFu);
+                spay[pos] = ((uint32_t)w * table_stride + wd.base + i) | (c & 0x80000000u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = 0; v < NSEG_W; ++v) {
+        const uint32_t lo = ss[v], hi = ss[v + 1], g0 = goff[v];
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += WIDE_THREADS) {
+            gkey[g0 + (e - lo)] = skey[e];
+            gpay[g0 + (e - lo)] = spay[e];
+        }
+    }
+}
+
+// grid = NSEG_W: block v turns row v of tile_cnt into exclusive offsets into the grouped arrays (segment v starts where the
+// totals of segments < v end).  Block 0 also leaves seg_off[0..NSEG_W] and the tile space of the per-segment counting sort:
+// tile_base[v] = first workgroup of segment v when every segment is cut into tiles of `tile_g` entries.
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_seg_scan(uint32_t *__restrict__ tile_cnt, uint32_t T, const uint32_t *__restrict__ seg_total, uint32_t *__restrict__ seg_off,
+               uint32_t *__restrict__ tile_base /* [NSEG_W + 1], then the tile size */) {
+    __shared__ uint32_t lds[64];
+    const uint32_t v = blockIdx.x;
+    uint32_t base = 0;
+    for (uint32_t u = 0; u < v; ++u) base += seg_total[u];
+    if (v == 0 && threadIdx.x == 0) {
+        // tile size from the ACTUAL number of entries (zero digits are gone): <= SORT_TARGET_BLOCKS workgroups of 128 KiB LDS,
+        // i.e. one round over the CUs, whatever the share of zeros
+        uint32_t all = 0;
+        for (uint32_t u = 0; u < NSEG_W; ++u) all += seg_total[u];
+        uint32_t tile_g = (all + (SORT_TARGET_BLOCKS - NSEG_W) - 1) / (SORT_TARGET_BLOCKS - NSEG_W);
+        tile_g = (tile_g + 1023u) & ~1023u;
+        if (tile_g < SORT_TILE_MIN) tile_g = SORT_TILE_MIN;
+        tile_base[NSEG_W + 1] = tile_g;
+        uint32_t run = 0, tr = 0;
+        for (uint32_t u = 0; u < NSEG_W; ++u) {
+            seg_off[u] = run;
+            tile_base[u] = tr;
+            run += seg_total[u];
+            tr += (seg_total[u] + tile_g - 1) / tile_g;
+        }
+        seg_off[NSEG_W] = run;
+        tile_base[NSEG_W] = tr;
+    }
+    uint32_t *row = tile_cnt + (size_t)v * T;
+    uint32_t carry = 0;
+    for (uint32_t at = 0; at < T; at += blockDim.x) {
+        const uint32_t i = at + threadIdx.x;
+        const uint32_t c = i < T ? row[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(c, lds, &total);
+        if (i < T) row[i] = base + carry + ex;
+        carry += total;
+    }
+}
+
+// counting sort inside the segments, from the grouped (key, payload) arrays: same LDS histogram as k_hist / k_scatter,
+// one workgroup per tile of the flat tile space (tile_base)
+__device__ __forceinline__ bool wide_tile(const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ tile_base,
+                                          uint32_t &v, uint32_t &lo, uint32_t &hi) {
+    if (blockIdx.x >= tile_base[NSEG_W]) return false;
+    const uint32_t tile_g = tile_base[NSEG_W + 1];
+    v = link_segment(tile_base, blockIdx.x);
+    lo = seg_off[v] + (blockIdx.x - tile_base[v]) * tile_g;
+    hi = seg_off[v + 1];
+    if (hi > lo + tile_g) hi = lo + tile_g;
+    return true;
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_hist_g(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ tile_base,
+             uint32_t *__restrict__ count /* [NSEG_W][NBUCKET] */) {
+    __shared__ uint32_t h[NBUCKET];
+    uint32_t v, lo, hi;
+    if (!wide_tile(seg_off, tile_base, v, lo, hi)) return;
+    tile_histogram(h, gkey, lo, hi);
+    uint32_t *cnt = count + (size_t)v * NBUCKET;
+    for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) {
+        uint32_t c = h[b];
+        if (c) atomicAdd(&cnt[b], c);
+    }
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_scatter_g(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ gpay, const uint32_t *__restrict__ seg_off,
+                const uint32_t *__restrict__ tile_base, uint32_t *__restrict__ cursor /* [NSEG_W][NBUCKET], absolute */,
+                uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t h[NBUCKET];
+    uint32_t v, lo, hi;
+    if (!wide_tile(seg_off, tile_base, v, lo, hi)) return;
+    tile_histogram(h, gkey, lo, hi);
+    uint32_t *cur = cursor + (size_t)v * NBUCKET;
+    for (uint32_t b0 = threadIdx.x; b0 < NBUCKET; b0 += 4 * blockDim.x) {   // 4 reservations in flight per thread
+        uint32_t c[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = h[b0 + u * blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&cur[b0 + u * blockDim.x], c[u]) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (c[u]) h[b0 + u * blockDim.x] = r[u];
+    }
+    __syncthreads();
+    for_each_digit(gkey, lo, hi, [&](uint32_t i, uint32_t code) {
+        uint32_t pos = atomicAdd(&h[code & 0x7FFFu], 1u);
+        sorted[pos] = gpay[i];
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3. plan: bucket offsets + (bucket, part) -> thread maps for every accumulation level
 // grid = batch, block = PLAN_THREADS.   plan layout per MSM: (1 + nlevels) arrays of NBUCKET+1:
@@ -462,7 +695,8 @@ __device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t *lds) {
 //       and later k_accum1 launches exit immediately.
 __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     k_plan(const uint32_t *__restrict__ count, uint32_t *__restrict__ cursor, uint32_t *__restrict__ plan,
-           size_t plan_stride, int nlevels, uint32_t l0_log, uint32_t l1_log) {
+           size_t plan_stride, int nlevels, uint32_t l0_log, uint32_t l1_log,
+           const uint32_t *__restrict__ seg_off /* wide windows: entry offsets are absolute, segment m starts at seg_off[m] */) {
     // One workgroup scans all 2^15 buckets.  Thread t owns PER consecutive buckets (registers), but
     // global traffic goes through an LDS transposition so that every load/store instruction is
     // coalesced (a single CU issuing 4-byte accesses at 128-byte stride was 5x slower than the scan).
@@ -528,12 +762,13 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
         }
         __syncthreads();
         uint32_t *o = pl + (size_t)(level + 1) * (NBUCKET + 1);
+        const uint32_t shift = (level < 0 && seg_off) ? seg_off[m] : 0u;
         for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) {
-            uint32_t v = tile[i + i / PER];
+            uint32_t v = tile[i + i / PER] + shift;
             o[i] = v;
             if (level < 0) cur[i] = v;
         }
-        if (t == PLAN_THREADS - 1) o[NBUCKET] = total;
+        if (t == PLAN_THREADS - 1) o[NBUCKET] = total + shift;
     }
     // every bucket already a single part after the last level?  Then the wave-level pass is a pure copy:
     // k_accum_final exits and k_rowcol reads the last level's parts directly (part index == bucket index).
@@ -546,6 +781,26 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     }
 }
 
+// wide windows: base[l][v] from the level sizes the NSEG_W plans ended with (one wavefront)
+__global__ void k_link(const uint32_t *__restrict__ plan, size_t plan_stride, int nlevels, Link *__restrict__ link) {
+    const uint32_t t = threadIdx.x;
+    for (int l = 0; l < nlevels; ++l) {
+        uint32_t c = 0;
+        if (t < NSEG_W) {
+            const uint32_t *pl = plan + (size_t)t * plan_stride;
+            if ((uint32_t)l < pl[plan_stride - 4]) c = pl[(size_t)(l + 1) * (NBUCKET + 1) + NBUCKET];
+        }
+        uint32_t x = c;
+#pragma unroll
+        for (uint32_t d = 1; d < NSEG_W; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if (t >= d) x += y;
+        }
+        if (t < NSEG_W) link->base[l][t] = x - c;
+        if (t == NSEG_W - 1) link->base[l][NSEG_W] = x;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 4. bucket accumulation
 // level 0: thread t = (bucket, part): <= L0 gathered mixed adds  ->  parts0[t]  (XYZZ)
@@ -555,11 +810,12 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
 // over the 2^15 prefix entries -- 15 DEPENDENT global loads (~15 us) in front of ~130 us of additions, in every thread.
 // One wavefront per bucket writes the (contiguous) range instead; the map is 2 bytes per thread.   grid = (NBUCKET / 4, batch)
 __global__ void SRS_KERNEL_BOUNDS(256, 1)
-    k_expand(const uint32_t *__restrict__ plan, size_t plan_stride, uint16_t *__restrict__ tb, size_t tb_stride) {
+    k_expand(const uint32_t *__restrict__ plan, size_t plan_stride, uint16_t *__restrict__ tb, size_t tb_stride,
+             const Link *__restrict__ link) {
     const uint32_t m = blockIdx.y, lane = threadIdx.x & 63u;
     const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t *tp = plan + (size_t)m * plan_stride + (NBUCKET + 1);
-    uint16_t *out = tb + (size_t)m * tb_stride;
+    uint16_t *out = tb + (link ? (size_t)link->base[0][m] : (size_t)m * tb_stride);
     const uint32_t s = tp[b], e = tp[b + 1];
     for (uint32_t t = s + lane; t < e; t += 64) out[t] = (uint16_t)b;
 }
@@ -568,18 +824,27 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum0(const uint32_t *__restrict__ sorted, size_t sorted_stride, const uint32_t *__restrict__ plan,
              size_t plan_stride, const uint16_t *__restrict__ tb, size_t tb_stride, const affine_t *__restrict__ table,
-             xyzz_t *__restrict__ parts, size_t parts_stride, uint32_t l0) {
+             xyzz_t *__restrict__ parts, size_t parts_stride, uint32_t l0, const Link *__restrict__ link) {
     uint32_t m = blockIdx.y;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t slot;                                   // index of this thread's part (and map entry)
+    if (link) {                                    // wide windows: flat thread space over the segments, offsets are absolute
+        if (t >= link->base[0][NSEG_W]) return;
+        m = link_segment(link->base[0], t);
+        slot = t;
+        t -= link->base[0][m];
+    } else {
+        slot = (size_t)m * parts_stride + t;
+    }
     const uint32_t *off = plan + (size_t)m * plan_stride;
     const uint32_t *tp = off + (NBUCKET + 1);
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tp[NBUCKET]) return;
-    uint32_t b = tb[(size_t)m * tb_stride + t];
+    uint32_t b = tb[link ? slot : (size_t)m * tb_stride + t];
     uint32_t part = t - tp[b];
     uint32_t s = off[b] + part * l0;
     uint32_t e = off[b + 1];
     if (e > s + l0) e = s + l0;
-    const uint32_t *src = sorted + (size_t)m * sorted_stride;
+    const uint32_t *src = link ? sorted : sorted + (size_t)m * sorted_stride;
     // the additions run on the 9 x 29-bit limb form (curve29.cuh); the table is stored in its Montgomery form
     using E29 = Ec29<C>;
     xyzz29_t acc = E29::identity();
@@ -598,7 +863,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
             p = pn;
         }
     }
-    parts[(size_t)m * parts_stride + t] = E29::pack(acc);        // canonical R'-form: the later levels stay on the 29-bit multiplier
+    parts[slot] = E29::pack(acc);                                // canonical R'-form: the later levels stay on the 29-bit multiplier
 }
 
 // level >= 1: (bucket, part) over the previous level's parts, <= L1 full adds each.
@@ -609,15 +874,34 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
 template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum1(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
-             size_t plan_stride, int level, xyzz_t *__restrict__ out, size_t out_stride, uint32_t l1) {
+             size_t plan_stride, int level, xyzz_t *__restrict__ out, size_t out_stride, uint32_t l1,
+             const Link *__restrict__ link) {
     uint32_t m = blockIdx.y;
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t t;
+    bool quad;
+    size_t in_off, out_off;
+    if (link) {                                // wide windows: flat thread space of this level over the segments
+        const uint32_t n_all = link->base[level][NSEG_W];
+        quad = n_all <= ACC1_QUAD_MAX;
+        t = quad ? (lin >> 2) : lin;
+        if (t >= n_all) return;
+        m = link_segment(link->base[level], t);
+        t -= link->base[level][m];
+        in_off = link->base[(level - 1) & 1][m];
+        out_off = link->base[level & 1][m];
+    } else {
+        in_off = (size_t)m * in_stride;
+        out_off = (size_t)m * out_stride;
+    }
     if ((uint32_t)level >= plan[(size_t)m * plan_stride + plan_stride - 4]) return;   // level not needed (k_plan)
     const uint32_t *tp_prev = plan + (size_t)m * plan_stride + (size_t)level * (NBUCKET + 1);
     const uint32_t *tp = tp_prev + (NBUCKET + 1);
     const uint32_t n_out = tp[NBUCKET];
-    const bool quad = (uint64_t)n_out * gridDim.y <= ACC1_QUAD_MAX;   // whole batch: latency-bound only while the chip is not full
-    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t t = quad ? (lin >> 2) : lin;
+    if (!link) {
+        quad = (uint64_t)n_out * gridDim.y <= ACC1_QUAD_MAX;   // whole batch: latency-bound only while the chip is not full
+        t = quad ? (lin >> 2) : lin;
+    }
     if (t >= n_out) return;                    // in quad mode the 4 lanes of a quad leave together
     uint32_t b = upper_bucket(tp, t);
     uint32_t part = t - tp[b];
@@ -625,15 +909,15 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     uint32_t e = tp_prev[b + 1];
     if (e > s + l1) e = s + l1;
     using E29 = Ec29<C>;
-    const xyzz_t *src = in + (size_t)m * in_stride;
+    const xyzz_t *src = in + in_off;
     xyzz29_t acc = E29::unpack(src[s]);
     if (quad) {
         const uint32_t q = threadIdx.x & 3u;
         for (uint32_t j = s + 1; j < e; ++j) acc = E29::add_quad(acc, E29::unpack(src[j]), q);
-        if (q == 0) out[(size_t)m * out_stride + t] = E29::pack(acc);
+        if (q == 0) out[out_off + t] = E29::pack(acc);
     } else {
         for (uint32_t j = s + 1; j < e; ++j) acc = E29::add(acc, E29::unpack(src[j]));
-        out[(size_t)m * out_stride + t] = E29::pack(acc);
+        out[out_off + t] = E29::pack(acc);
     }
 }
 
@@ -671,7 +955,7 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
     k_accum_final(const xyzz_t *__restrict__ ping, size_t ping_stride, const xyzz_t *__restrict__ pong,
                   size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride,
-                  xyzz_t *__restrict__ buckets) {
+                  xyzz_t *__restrict__ buckets, const Link *__restrict__ link) {
     uint32_t m = blockIdx.y;
     if (plan[(size_t)m * plan_stride + plan_stride - 3]) return;              // all buckets single: nothing to combine
     const uint32_t level = plan[(size_t)m * plan_stride + plan_stride - 4];   // levels actually run
@@ -681,7 +965,7 @@ __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
     uint32_t lane = threadIdx.x & 63u;
     uint32_t b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t s = tp[b], e = tp[b + 1];
-    const xyzz_t *src = in + (size_t)m * in_stride;
+    const xyzz_t *src = in + (link ? (size_t)link->base[(level - 1u) & 1u][m] : (size_t)m * in_stride);
     xyzz_t *dst = buckets + (size_t)m * NBUCKET;
     if (e - s == 1) {                       // common case: the bucket is already one part
         if (lane == 0) dst[b] = src[s];
@@ -732,14 +1016,15 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(128, 1)
     k_rowcol(const xyzz_t *__restrict__ buckets, const xyzz_t *__restrict__ ping, size_t ping_stride,
              const xyzz_t *__restrict__ pong, size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride,
-             xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */) {
+             xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */, const Link *__restrict__ link) {
     constexpr uint32_t SER = 8;
     __shared__ xyzz_t half[1];
     const uint32_t m = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t q = lane & 3u, vl = lane >> 2;                                // quad role, quad index 0..15
     const uint32_t *hdr = plan + (size_t)m * plan_stride + plan_stride - 4;   // [0] levels run, [1] all buckets single
-    const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + (size_t)m * ping_stride : pong + (size_t)m * pong_stride)
-                             : buckets + (size_t)m * NBUCKET;
+    const size_t ping_off = link ? (size_t)link->base[0][m] : (size_t)m * ping_stride;
+    const size_t pong_off = link ? (size_t)link->base[1][m] : (size_t)m * pong_stride;
+    const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + ping_off : pong + pong_off) : buckets + (size_t)m * NBUCKET;
     using E29 = Ec29<C>;
     xyzz_t *out = rc + (size_t)m * (RED_ROWS + RED_COLS);
     const bool is_row = blockIdx.x < RED_ROWS / 2;
@@ -786,7 +1071,8 @@ __global__ void SRS_KERNEL_BOUNDS(128, 1)
 //   block 0: A' = sum_a a * (R_2a + R_2a+1)     (the 256 row sums taken in pairs; drop Suffix_0)
 //   block 1: B  = sum_lo (lo+1) * C_lo          (keep Suffix_0)
 //   block 2: Z  = sum_a R_2a+1                  (plain tree sum)
-// since sum_hi hi R_hi = 2 A' + Z, the host finishes  S = RED_COLS * (2 A' + Z) + B.   out[3m + {0,1,2}] = A', B, Z
+//   block 3: T  = sum_lo C_lo                   (plain tree sum; wide windows only: the segment's unweighted total)
+// since sum_hi hi R_hi = 2 A' + Z, the host finishes  S = RED_COLS * (2 A' + Z) + B.   out[gridDim.x * m + which] = A', B, Z (, T)
 template <class C>
 __global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
     k_reduce_final(const xyzz_t *__restrict__ rc, xyzz_t *__restrict__ out) {
@@ -797,9 +1083,9 @@ __global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
     const xyzz_t *rows = rc + (size_t)m * (RED_ROWS + RED_COLS), *cols = rows + RED_ROWS;
     xyzz29_t x;
     if (which == 0) x = E29::add_quad(E29::unpack(rows[2 * t]), E29::unpack(rows[2 * t + 1]), q);
-    else if (which == 1) x = E29::unpack(cols[t]);
+    else if (which == 1 || which == 3) x = E29::unpack(cols[t]);
     else x = E29::unpack(rows[2 * t + 1]);
-    if (which != 2) {
+    if (which < 2) {
         if (q == 0) v[t] = x;
         __syncthreads();
         for (uint32_t s = 1; s < N; s <<= 1) {             // suffix scan
@@ -821,7 +1107,30 @@ __global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(size_t)m * 3 + which] = E29::pack(v[0]);
+    if (threadIdx.x == 0) out[(size_t)m * gridDim.x + which] = E29::pack(v[0]);
+}
+
+// wide windows: the 4 x NSEG_W partial sums of the segments -> 4 points.  A', B, Z add up (the bucket reduction is linear);
+// bucket (v, lo) has weight v * NBUCKET + lo + 1, so the segment totals enter as U = sum_v v T_v (suffix sums, as above),
+// which the host multiplies by NBUCKET.   grid = 1, block = 256: wavefront `which`, quad v
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(256, 1)
+    k_wide_combine(const xyzz_t *__restrict__ in /* [NSEG_W][4] */, xyzz_t *__restrict__ out /* [4] */) {
+    using E29 = Ec29<C>;
+    const uint32_t which = threadIdx.x >> 6, lane = threadIdx.x & 63u, q = lane & 3u, vl = lane >> 2;
+    xyzz29_t x = E29::unpack(in[vl * 4 + which]);
+    if (which == 3) {
+        for (uint32_t s = 1; s < NSEG_W; s <<= 1) {        // suffix scan over the 16 quads
+            xyzz29_t o = shfl_down_point29(x, 4 * s, 64);
+            if (vl + s < NSEG_W) x = E29::add_quad(x, o, q);
+        }
+        if (vl == 0) x = E29::identity();
+    }
+    for (unsigned d = NSEG_W / 2; d >= 1; d >>= 1) {
+        xyzz29_t o = shfl_down_point29(x, 4 * d, 64);
+        if (vl < d) x = E29::add_quad(x, o, q);
+    }
+    if (lane == 0) out[which] = E29::pack(x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -829,18 +1138,42 @@ __global__ void SRS_KERNEL_BOUNDS(RED_THREADS, 1)
 // ---------------------------------------------------------------------------------------------
 static inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// windows 1 .. nwin-1 of a table whose window 0 (the bases, ABI form) is in place; `nbits` doublings between windows
+template <class C>
+static void expand_windows(affine_t *table, uint32_t n, int nwin, int nbits, xyzz_t *tmp, hipStream_t stream) {
+    for (int w = 1; w < nwin; ++w) {
+        const affine_t *prev = table + (size_t)(w - 1) * n;
+        affine_t *cur = table + (size_t)w * n;
+        SRS_LAUNCH((k_table_step<C>), (ceil_div(n, 256)), (256), 0, stream, prev, tmp, n, nbits);
+        SRS_LAUNCH((k_normalize<C>), (ceil_div(ceil_div(n, NORM_G), 128)), (128), 0, stream, (const xyzz_t *)tmp, cur, n);
+    }
+}
+
+static bool wants_wide_table(size_t len) {
+    static const int forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();   // 0: never, 1: always
+    if (forced == 0) return false;
+    if (forced == 1) return len > 0;
+    return len >= ((size_t)1 << WIDE_MIN_KEY_LOG);
+}
+
 template <class C>
 static void build_table_t(Key &k, hipStream_t stream) {
     const uint32_t n = (uint32_t)k.len;
+    if (k.table_w) {
+        SRS_HIP_CHECK(hipFree(k.table_w));
+        k.table_w = nullptr;
+    }
     if (n == 0) return;
     xyzz_t *tmp = nullptr;
     SRS_HIP_CHECK(hipMalloc((void **)&tmp, (size_t)n * sizeof(xyzz_t)));
-    for (int w = 1; w < NWIN; ++w) {
-        const affine_t *prev = k.table + (size_t)(w - 1) * n;
-        affine_t *cur = k.table + (size_t)w * n;
-        SRS_LAUNCH((k_table_step<C>), (ceil_div(n, 256)), (256), 0, stream, prev, tmp, n);
-        SRS_LAUNCH((k_normalize<C>), (ceil_div(ceil_div(n, NORM_G), 128)), (128), 0, stream, (const xyzz_t *)tmp, cur, n);
+    if (wants_wide_table(n)) {
+        SRS_HIP_CHECK(hipMalloc((void **)&k.table_w, (size_t)n * NWIN_W * sizeof(affine_t)));
+        SRS_HIP_CHECK(hipMemcpyAsync(k.table_w, k.table, (size_t)n * sizeof(affine_t), hipMemcpyDeviceToDevice, stream));
+        expand_windows<C>(k.table_w, n, NWIN_W, WBITS_W, tmp, stream);
+        const size_t total_w = (size_t)n * NWIN_W;
+        SRS_LAUNCH((k_table_form<C>), (ceil_div(total_w, 256)), (256), 0, stream, k.table_w, total_w);
     }
+    expand_windows<C>(k.table, n, NWIN, WBITS, tmp, stream);
     const size_t total = (size_t)n * NWIN;
     SRS_LAUNCH((k_table_form<C>), (ceil_div(total, 256)), (256), 0, stream, k.table, total);
     SRS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -996,7 +1329,7 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
     SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
-               levels, l0_log, (uint32_t)ACC_L1_LOG);
+               levels, l0_log, (uint32_t)ACC_L1_LOG, (const uint32_t *)nullptr);
     if (two_pass) {
         const uint32_t T1 = tiles * NWIN;
         SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, plan_stride);
@@ -1013,12 +1346,13 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
 
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
-    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap);
+    const Link *no_link = nullptr;
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap, no_link);
     {
         prof::Scope ps("msm_accum0", stream, units);
         SRS_LAUNCH((k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                    (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride, (const uint16_t *)tb, (size_t)parts0_cap,
-                   (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log);
+                   (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log, no_link);
     }
     xyzz_t *cur = ping, *nxt = pong;
     size_t cur_stride = parts0_cap, nxt_stride = parts1_cap;
@@ -1027,7 +1361,7 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
         cap = cap / ACC_L1 + NBUCKET + 1;
         SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, ACC1_QUAD_MAX)), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                    (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, level, nxt, nxt_stride,
-                   (uint32_t)ACC_L1);
+                   (uint32_t)ACC_L1, no_link);
         std::swap(cur, nxt);
         std::swap(cur_stride, nxt_stride);
         // both buffers can hold any later level: parts shrink monotonically and pong >= level-1 cap
@@ -1036,14 +1370,132 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     (void)cur_stride;
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap,
-               (const uint32_t *)plan, plan_stride, buckets);
+               (const uint32_t *)plan, plan_stride, buckets, no_link);
     SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, batch), (128), 0, stream, (const xyzz_t *)buckets,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap, (const uint32_t *)plan,
-               plan_stride, rc);
+               plan_stride, rc, no_link);
     SRS_LAUNCH((k_reduce_final<C>), (3, batch), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_out);
     if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
     xyzz_t *two = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
     SRS_HIP_CHECK(hipMemcpyAsync(two, d_out, 3 * (size_t)batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
+    k.slot_wide[slot] = false;
+    return true;
+}
+
+// ---- the wide-window pipeline: ONE MSM of n >= 2^WIDE_MIN_N_LOG scalars over table_w -------------------------------------
+struct WideShape {
+    uint64_t M;                // entry capacity = n * NWIN_W
+    int levels;
+    uint32_t l0_log, T, tiles_g;
+    size_t plan_stride;
+    uint64_t parts0_cap, parts1_cap;
+};
+static WideShape wide_shape(uint32_t n) {
+    WideShape w;
+    w.M = (uint64_t)n * NWIN_W;
+    w.levels = levels_for(w.M);                              // worst case: every entry in one bucket of one segment
+    w.l0_log = l0_log_for(w.M);
+    w.plan_stride = (size_t)(w.levels + 1) * (NBUCKET + 1) + 4;
+    w.parts0_cap = (w.M >> w.l0_log) + (uint64_t)NSEG_W * (NBUCKET + 1);
+    w.parts1_cap = w.parts0_cap / ACC_L1 + (uint64_t)NSEG_W * (NBUCKET + 1);
+    w.T = ceil_div(n, WIDE_TILE);
+    w.tiles_g = SORT_TARGET_BLOCKS;                          // the tile size is chosen on the device (k_seg_scan) so that this many suffice
+    return w;
+}
+static size_t workspace_bytes_wide(uint32_t n) {
+    const WideShape w = wide_shape(n);
+    size_t b = 0;
+    b += Arena::pad((4 + 4 * NSEG_W) * sizeof(xyzz_t));                          // results
+    b += Arena::pad(w.M * sizeof(uint16_t)) + 2 * Arena::pad(w.M * sizeof(uint32_t));   // grouped keys / payloads, sorted
+    b += Arena::pad((size_t)NSEG_W * w.T * sizeof(uint32_t));                    // per-tile segment counts
+    b += Arena::pad(3 * (NSEG_W + 2) * sizeof(uint32_t)) + Arena::pad(sizeof(Link));
+    b += 2 * Arena::pad((size_t)NSEG_W * NBUCKET * sizeof(uint32_t));            // count, cursor
+    b += Arena::pad(w.plan_stride * NSEG_W * sizeof(uint32_t));
+    b += Arena::pad(w.parts0_cap * sizeof(xyzz_t)) + Arena::pad(w.parts0_cap * sizeof(uint16_t));   // ping, map
+    b += Arena::pad(w.parts1_cap * sizeof(xyzz_t));                              // pong
+    b += Arena::pad((size_t)NSEG_W * NBUCKET * sizeof(xyzz_t));                  // buckets
+    b += Arena::pad((size_t)NSEG_W * (RED_ROWS + RED_COLS) * sizeof(xyzz_t));
+    return b + 4096;
+}
+
+static bool use_wide(const Key &k, uint32_t n_max, uint32_t batch) {
+    static const int min_log = [] { const char *e = std::getenv("SRS_MSM_WIDE_MIN"); return e ? std::atoi(e) : (int)WIDE_MIN_N_LOG; }();
+    return k.table_w != nullptr && batch == 1 && n_max >= (1u << min_log);
+}
+
+template <class C>
+static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t stream, uint32_t slot) {
+    const WideShape w = wide_shape(n);
+    Arena &A = k.arena;
+    A.reserve(workspace_bytes_wide(n));
+    A.reset();
+    xyzz_t *d_out = A.take<xyzz_t>(4);
+    xyzz_t *d_seg = A.take<xyzz_t>(4 * NSEG_W);
+    uint16_t *gkey = A.take<uint16_t>(w.M);
+    uint32_t *gpay = A.take<uint32_t>(w.M);
+    uint32_t *sorted = A.take<uint32_t>(w.M);
+    uint32_t *tile_cnt = A.take<uint32_t>((size_t)NSEG_W * w.T);
+    uint32_t *seg3 = A.take<uint32_t>(3 * (NSEG_W + 2));
+    uint32_t *seg_total = seg3, *seg_off = seg3 + (NSEG_W + 2), *tile_base = seg3 + 2 * (NSEG_W + 2);
+    Link *link = A.take<Link>(1);
+    uint32_t *count = A.take<uint32_t>((size_t)NSEG_W * NBUCKET);
+    uint32_t *cursor = A.take<uint32_t>((size_t)NSEG_W * NBUCKET);
+    uint32_t *plan = A.take<uint32_t>(w.plan_stride * NSEG_W);
+    xyzz_t *ping = A.take<xyzz_t>(w.parts0_cap);
+    uint16_t *tb = A.take<uint16_t>(w.parts0_cap);
+    xyzz_t *pong = A.take<xyzz_t>(w.parts1_cap);
+    xyzz_t *buckets = A.take<xyzz_t>((size_t)NSEG_W * NBUCKET);
+    xyzz_t *rc = A.take<xyzz_t>((size_t)NSEG_W * (RED_ROWS + RED_COLS));
+
+    WideDesc wd;
+    wd.ptr = scalars_dev;
+    wd.n = n;
+    wd.base = base;
+    wd.rank = k.compact_scalars ? 0u : k.rank;
+    wd.world = k.compact_scalars ? 1u : k.world;
+    wd.is_mont = is_mont;
+    const uint32_t table_stride = (uint32_t)k.len;
+
+    // sort: segment counts -> offsets -> grouping (MSD pass), then the counting sort inside the segments
+    SRS_HIP_CHECK(hipMemsetAsync(seg_total, 0, (NSEG_W + 1) * sizeof(uint32_t), stream));
+    SRS_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)NSEG_W * NBUCKET * sizeof(uint32_t), stream));
+    SRS_LAUNCH((k_seg_pass<C, false>), (w.T), (WIDE_THREADS), 0, stream, wd, tile_cnt, w.T, seg_total, (uint16_t *)nullptr,
+               (uint32_t *)nullptr, table_stride);
+    SRS_LAUNCH(k_seg_scan, (NSEG_W), (1024), 0, stream, tile_cnt, w.T, (const uint32_t *)seg_total, seg_off, tile_base);
+    SRS_LAUNCH((k_seg_pass<C, true>), (w.T), (WIDE_THREADS), 0, stream, wd, tile_cnt, w.T, seg_total, gkey, gpay, table_stride);
+    SRS_LAUNCH(k_hist_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)seg_off,
+               (const uint32_t *)tile_base, count);
+    SRS_LAUNCH(k_plan, (NSEG_W), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, w.plan_stride, w.levels, w.l0_log,
+               (uint32_t)ACC_L1_LOG, (const uint32_t *)seg_off);
+    SRS_LAUNCH(k_scatter_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay,
+               (const uint32_t *)seg_off, (const uint32_t *)tile_base, cursor, sorted);
+    SRS_LAUNCH(k_link, (1), (64), 0, stream, (const uint32_t *)plan, w.plan_stride, w.levels, link);
+    const Link *lk = link;
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, NSEG_W), (256), 0, stream, (const uint32_t *)plan, w.plan_stride, tb, (size_t)0, lk);
+    {
+        prof::Scope ps("msm_accum0", stream, n);
+        SRS_LAUNCH((k_accum0<C>), (ceil_div(w.parts0_cap, ACC_THREADS)), (ACC_THREADS), 0, stream, (const uint32_t *)sorted, (size_t)0,
+                   (const uint32_t *)plan, w.plan_stride, (const uint16_t *)tb, (size_t)0, (const affine_t *)k.table_w, ping, (size_t)0,
+                   1u << w.l0_log, lk);
+    }
+    xyzz_t *cur = ping, *nxt = pong;
+    uint64_t cap = w.parts0_cap;
+    for (int level = 1; level < w.levels; ++level) {
+        cap = cap / ACC_L1 + (uint64_t)NSEG_W * (NBUCKET + 1);
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, ACC1_QUAD_MAX)), ACC_THREADS)), (ACC_THREADS), 0,
+                   stream, (const xyzz_t *)cur, (size_t)0, (const uint32_t *)plan, w.plan_stride, level, nxt, (size_t)0, (uint32_t)ACC_L1, lk);
+        std::swap(cur, nxt);
+    }
+    SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), NSEG_W), (FINAL_THREADS), 0, stream, (const xyzz_t *)ping, (size_t)0,
+               (const xyzz_t *)pong, (size_t)0, (const uint32_t *)plan, w.plan_stride, buckets, lk);
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, NSEG_W), (128), 0, stream, (const xyzz_t *)buckets, (const xyzz_t *)ping, (size_t)0,
+               (const xyzz_t *)pong, (size_t)0, (const uint32_t *)plan, w.plan_stride, rc, lk);
+    SRS_LAUNCH((k_reduce_final<C>), (4, NSEG_W), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_seg);
+    SRS_LAUNCH((k_wide_combine<C>), (1), (256), 0, stream, (const xyzz_t *)d_seg, d_out);
+    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
+    xyzz_t *land = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
+    SRS_HIP_CHECK(hipMemcpyAsync(land, d_out, 4 * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
+    k.slot_wide[slot] = true;
     return true;
 }
 
@@ -1059,7 +1511,7 @@ static void finish_t(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_
     using F = typename C::F;
     fe_t c = F::one();
     for (int d = 0; d < 5; ++d) c = F::halve(c);
-    std::vector<xyzz_t> two(3 * (size_t)batch);
+    std::vector<xyzz_t> two(3 * (size_t)batch + (k.slot_wide[slot] ? 1 : 0));
     for (size_t i = 0; i < two.size(); ++i) {
         two[i].x = F::mul(raw[i].x, c);
         two[i].y = F::mul(raw[i].y, c);
@@ -1071,6 +1523,11 @@ static void finish_t(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_
         for (uint32_t j = 1; j < RED_COLS; j <<= 1) a = Ec<C>::dbl(a);
         result_host[m] = Ec<C>::add(a, two[3 * m + 1]);
     }
+    if (k.slot_wide[slot]) {                                 // one MSM, 4 sums: + NBUCKET * U for the segment totals
+        xyzz_t u = two[3];
+        for (uint32_t j = 1; j < NBUCKET; j <<= 1) u = Ec<C>::dbl(u);
+        result_host[0] = Ec<C>::add(result_host[0], u);
+    }
 }
 
 bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch, int is_mont,
@@ -1079,18 +1536,34 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
         set_error("internal: msm::enqueue batch / slot out of range");
         throw DeviceError{5};
     }
+    if (batch == 1 && use_wide(k, n_host[0], 1)) {
+        const uint32_t base = base_host ? base_host[0] : 0;
+        return k.curve == 0 ? enqueue_wide_t<Bn256>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot)
+                            : enqueue_wide_t<Grumpkin>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot);
+    }
     return k.curve == 0 ? enqueue_t<Bn256>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot)
                         : enqueue_t<Grumpkin>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot);
 }
 void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host) {
     if (k.curve == 0) finish_t<Bn256>(k, batch, slot, launched, result_host); else finish_t<Grumpkin>(k, batch, slot, launched, result_host);
 }
-void reserve(Key &k, uint32_t n_max, uint32_t batch) { k.arena.reserve(workspace_bytes(n_max, batch)); }
+void reserve(Key &k, uint32_t n_max, uint32_t batch) {
+    k.arena.reserve(use_wide(k, n_max, batch) ? std::max(workspace_bytes_wide(n_max), workspace_bytes(n_max, batch)) : workspace_bytes(n_max, batch));
+}
+
+void release(Key &k) {
+    if (k.table_w) (void)hipFree(k.table_w);
+    k.table_w = nullptr;
+    if (k.h_result) (void)hipHostFree(k.h_result);
+    k.h_result = nullptr;
+    k.arena.release();
+}
 
 void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_t batch, int is_mont,
          hipStream_t stream, xyzz_t *result_host) {
-    for (uint32_t at = 0; at < batch; at += BATCH_ARGS) {          // the batch descriptor is a kernel argument of BATCH_ARGS slots
-        const uint32_t b = std::min<uint32_t>(BATCH_ARGS, batch - at);
+    for (uint32_t at = 0; at < batch;) {                           // the batch descriptor is a kernel argument of BATCH_ARGS slots
+        uint32_t b = std::min<uint32_t>(BATCH_ARGS, batch - at);
+        if (use_wide(k, n_host[at], 1)) b = 1;                     // large vectors go through the wide-window pipeline one by one
         const bool launched = enqueue(k, scalars_dev + at, n_host + at, nullptr, b, is_mont, stream, 0);
         if (launched) {
             SRS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1098,6 +1571,7 @@ void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_
         }
         finish(k, b, 0, launched, result_host + at);
         prof::collect();
+        at += b;
     }
 }
 

@@ -403,6 +403,71 @@ def test_long_level0_parts_match_oracle(srs, oracle):
         assert r.returncode == 0 and "ok" in r.stdout, (l0, r.stdout[-500:], r.stderr[-1500:])
 
 
+WIDE_CODE = (
+    "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+    "import oracle as O, sirius_amd as S\n"
+    "from oracle import pyref as P\n"
+    "from conftest import seeded_scalars\n"
+    "for cid, n, kind in ((0, 70000, 'uniform'), (1, 33333, 'trace'), (0, 5, 'uniform'), (1, 1, 'uniform')):\n"
+    "    bases = O.make_bases(cid, 4, n); ck = S.CommitmentKey(cid, bases)\n"
+    "    for j in range(2):\n"
+    "        v = seeded_scalars(O, cid, n, 9 + j, kind); assert np.array_equal(ck.commit(v), O.msm(cid, v, bases)), (cid, n, kind)\n"
+    "    if n > 1000: assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases))     # SRS_COMMIT_CHUNKS=3: chunks slide the base offset\n"
+    "for cid in (0, 1):\n"
+    "    q = P.CURVES[cid].q\n"
+    "    vals = [0, 1, 2, q - 1, q - 2, 1 << 19, (1 << 19) + 1, (1 << 19) - 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 1 << 253, (1 << 240) - 1,\n"
+    "            (1 << 40) - 1, ((1 << 20) - 1) << 20, (q - 1) // 2, (q + 1) // 2, 0x80000 << 20, 0x80001 << 40, 0x7ffff << 60] * 3\n"
+    "    v = O.ints_to_mont(O.SCALAR_FIELD[cid], vals)\n"
+    "    bases = O.make_bases(cid, 6, len(vals)); ck = S.CommitmentKey(cid, bases)\n"
+    "    assert np.array_equal(ck.commit(v), O.msm(cid, v, bases))\n"
+    "    for x in (0, 1, q - 1, 0x80000, 0x80001):           # every entry in ONE bucket of one segment\n"
+    "        v = O.ints_to_mont(O.SCALAR_FIELD[cid], [x] * 3000); b2 = O.make_bases(cid, 7, 3000); ck = S.CommitmentKey(cid, b2)\n"
+    "        assert np.array_equal(ck.commit(v), O.msm(cid, v, b2)), x\n"
+    "print('ok')\n")
+
+
+def test_wide_windows_match_oracle(srs, oracle):
+    """The 13 x 20-bit window pipeline of large MSMs (msm.hip, `wide`), forced on sizes the oracle can do (SRS_MSM_WIDE /
+    SRS_MSM_WIDE_MIN are read once per process -> subprocess): uniform and skewed scalars, both curves, digit-boundary values,
+    every entry in one bucket, chunked uploads (base offsets)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, "-c", WIDE_CODE], cwd=ROOT, env=dict(os.environ, SRS_MSM_WIDE="1", SRS_MSM_WIDE_MIN="0", SRS_COMMIT_CHUNKS="3"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_wide_windows_equal_narrow_at_scale(srs, oracle):
+    """3 * 2^20 + 77 trace-like scalars: the default (wide) pipeline in this process against the 16-bit-window pipeline
+    in a subprocess with SRS_MSM_WIDE=0 -- same seeded inputs, same affine point."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, '.')\n"
+        "import sirius_amd as S\n"
+        "n = (3 << 20) + 77\n"
+        "ck = S.CommitmentKey.setup_synthetic(0, n, seed=21)\n"
+        "g = torch.Generator(device='cuda').manual_seed(8)\n"
+        "v = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device='cuda', generator=g); v[:, 3] &= (1 << 60) - 1\n"
+        "v[torch.rand(n, device='cuda', generator=g) < 0.5] = 0\n"
+        "v[torch.rand(n, device='cuda', generator=g) < 0.2, 1:] = 0\n"
+        "print('C', ck.commit(v).tobytes().hex())\n")
+    outs = []
+    for wide in ("0", None):
+        env = dict(os.environ)
+        if wide is not None:
+            env["SRS_MSM_WIDE"] = wide
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("C ")][-1])
+    assert outs[0] == outs[1] and len(outs[0]) > 100
+
+
 def _concat_ref(cols, pad):
     """util::concatenate_with_padding (src/util/mod.rs:214-218): every vector followed by zeros up to pad_size."""
     out = []

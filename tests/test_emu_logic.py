@@ -228,6 +228,30 @@ def test_emu_long_level0_parts():
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_emu_wide_windows():
+    """msm.hip wide pipeline (13 x 20-bit windows, 16 segments of 2^15 buckets) forced on a small MSM: digit-boundary values,
+    zeros / bits / small values (every entry of a segment in a few buckets) and full-width scalars in one commit."""
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O, sirius_amd as S\n"
+        "from oracle import pyref as P\n"
+        "from sirius_amd import _lib\n"
+        "from conftest import seeded_scalars\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "q = P.CURVES[1].q\n"
+        "vals = [0, 1, 2, q - 1, q - 2, 1 << 19, (1 << 19) + 1, (1 << 19) - 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 1 << 253,\n"
+        "        (1 << 240) - 1, ((1 << 20) - 1) << 20, (q - 1) // 2, (q + 1) // 2, 0x80000 << 20, 0x80001 << 40, 0x7ffff << 60, 1, 1, 1]\n"
+        "v = np.concatenate([O.ints_to_mont(O.SCALAR_FIELD[1], vals), seeded_scalars(O, 1, 150, 9, 'trace'), seeded_scalars(O, 1, 40, 3, 'uniform')])\n"
+        "bases = O.make_bases(1, 4, len(v)); ck = S.CommitmentKey(1, bases)\n"
+        "assert np.array_equal(ck.commit(v), O.msm(1, v, bases))\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_WIDE="1", SRS_MSM_WIDE_MIN="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_concatenate_with_padding(emu, oracle):
     """SURVEY A17 on the emulator: the reference's concatenate_with_padding unit tests + the column-wise witness commit."""
     import torch
