@@ -440,8 +440,8 @@ def test_wide_windows_match_oracle(srs, oracle):
 
 
 def test_wide_windows_equal_narrow_at_scale(srs, oracle):
-    """3 * 2^20 + 77 trace-like scalars: the default (wide) pipeline in this process against the 16-bit-window pipeline
-    in a subprocess with SRS_MSM_WIDE=0 -- same seeded inputs, same affine point."""
+    """3 * 2^20 + 77 trace-like scalars: the wide pipeline (SRS_MSM_WIDE=1) against the 16-bit-window pipeline
+    (SRS_MSM_WIDE=0), one subprocess each -- same seeded inputs, same affine point."""
     import os
     import subprocess
     import sys
@@ -458,10 +458,8 @@ def test_wide_windows_equal_narrow_at_scale(srs, oracle):
         "v[torch.rand(n, device='cuda', generator=g) < 0.2, 1:] = 0\n"
         "print('C', ck.commit(v).tobytes().hex())\n")
     outs = []
-    for wide in ("0", None):
-        env = dict(os.environ)
-        if wide is not None:
-            env["SRS_MSM_WIDE"] = wide
+    for wide in ("0", "1"):
+        env = dict(os.environ, SRS_MSM_WIDE=wide, SRS_MSM_WIDE_MIN="20")
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("C ")][-1])
