@@ -1997,8 +1997,9 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
         const fe_t f_alpha = rowprog::poly_eval(reinterpret_cast<const fe_t *>(poly_F), z.points_F, alpha);
         // poly_K = compute_K(F(alpha), betas_stroke, accumulator, incoming)                               :437-443
         std::vector<fe_t> poly_G(z.points_G);
+        // G(1) = F(alpha) by definition (rowprog.hip, pg_sum): one evaluation point less for the leaf kernel
         erc = rowprog::pg_sum(s, 1, dW.data(), ch.data(), n_challenges, n_instances, bs.data(), bs.size(), nullptr, reference_compat, st,
-                              poly_G.data(), &n_out, err);
+                              poly_G.data(), &n_out, err, &f_alpha);
         if (erc) return fail(erc, "srs_pg_prove (compute_G): " + err);
         erc = rowprog::pg_K_from_G(poly_G.data(), poly_G.size(), f_alpha, z.instances_to_fold, z.log_domain_K, st,
                                    reinterpret_cast<fe_t *>(poly_K), err);

@@ -47,7 +47,7 @@ std::vector<fe_t> lagrange_eval(const fe_t &X, uint32_t log_n);
 fe_t poly_eval(const fe_t *coeffs, size_t n, const fe_t &x);
 int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
            const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
-           size_t *n_out, std::string &err);
+           size_t *n_out, std::string &err, const fe_t *g_at_one = nullptr);
 int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t instances_to_fold, uint32_t log_domain_K,
                 hipStream_t st, fe_t *out_host, std::string &err);
 int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err);

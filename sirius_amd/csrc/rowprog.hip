@@ -1570,6 +1570,30 @@ static std::vector<fe_t> inverse_vandermonde(const FieldOps &f, size_t d) {
     return out;
 }
 
+// the same for the nodes first .. first + d, all rows: out[k * (d + 1) + j] = coefficient of X^k in L_j(X), k = 0..d
+static std::vector<fe_t> inverse_vandermonde_at(const FieldOps &f, size_t d, uint64_t first) {
+    const size_t m = d + 1;
+    std::vector<fe_t> out(m * m);
+    for (size_t j = 0; j < m; ++j) {
+        std::vector<fe_t> poly(1, f.one());        // prod_{t != j} (X - x_t)
+        fe_t denom = f.one();
+        for (size_t t = 0; t < m; ++t) {
+            if (t == j) continue;
+            const fe_t ft = f.from_u64(first + t);
+            std::vector<fe_t> nx(poly.size() + 1, f.zero());
+            for (size_t i = 0; i < poly.size(); ++i) {
+                nx[i + 1] = f.add(nx[i + 1], poly[i]);
+                nx[i] = f.sub(nx[i], f.mul(poly[i], ft));
+            }
+            poly.swap(nx);
+            denom = f.mul(denom, f.sub(f.from_u64(first + j), ft));
+        }
+        const fe_t di = f.inv(denom);
+        for (size_t k = 0; k <= d; ++k) out[k * m + j] = f.mul(poly[k], di);
+    }
+    return out;
+}
+
 static void upload_program(Program &p, Structure &S) {
     if (p.insns.empty()) return;
     SRS_HIP_CHECK(hipMalloc((void **)&p.d_insns, p.insns.size() * sizeof(Insn)));
@@ -1843,6 +1867,7 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
     a.ctx.J = mode == 0 ? 2 : 1;
     a.ctx.wcoef = nullptr;
     a.ctx.half = 0;
+    a.ctx.pt0 = 0;
     // only the cross terms are sharded (their consumers, the sharded MSM and the error fold, touch this rank's stripes
     // only); the deciders' plain evaluations always cover every row
     a.ctx.shard_rank = mode == 0 ? S->shard_rank : 0;
@@ -1967,7 +1992,7 @@ static void launch_pg_leaves(const PgArgs &A, uint32_t tiles, uint32_t gates, ui
 // out_host: points_F / points_G coefficients (after ifft) or the single value e.
 int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
            const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
-           size_t *n_out, std::string &err) {
+           size_t *n_out, std::string &err, const fe_t *g_at_one) {
     if (S->field != 0) { err = "ProtoGalaxy polynomials need the 2-adic field bn256::Fr"; return 4; }
     if (J == 0 || J > JMAX) { err = "unsupported number of traces"; return 4; }
     PgSizes sz;
@@ -1982,7 +2007,16 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     // Vandermonde matrix: the same polynomial, hence the same coefficients (exact arithmetic), ~35 % less work.
     const bool g_int = mode == 1 && J == 2 && !std::getenv("SRS_PG_G_FFT");
     const uint32_t dG = (uint32_t)S->max_gate_degree;
-    const uint32_t P = g_int ? dG + 1 : P_out;                 // evaluation points actually used
+    // ... and one of the d_G + 1 values is free for a caller that has F: at X = 1 the fold IS the accumulator (L_0(1) = 1), the
+    // weights are betas_stroke = beta + alpha delta^(2^b), so G(1) = sum_i pow_i(betas_stroke) f_i(acc) = F(alpha) -- an
+    // identity of the definitions, whatever the traces hold.  ProtoGalaxy::prove has F(alpha) (it is compute_K's first
+    // argument): with `g_at_one` the leaves are evaluated at X = 2 .. d_G + 1 only (d_G points), and the interpolation
+    // nodes are 1 .. d_G + 1.  Needs the sweep-form leaf kernel (below); otherwise all d_G + 1 points are evaluated.
+    const uint32_t lpt_probe = S->k >= 10 ? 8u : 1u;
+    const bool skip_one = g_int && g_at_one != nullptr && dG >= 2 && S->pg_spec_id >= 0 && lpt_probe == 8 && dG + 1 <= DMAX + 1 &&
+                          !std::getenv("SRS_NO_SWEEP") && !std::getenv("SRS_PG_G_ALL_POINTS");
+    const uint32_t pt0 = skip_one ? 2u : 0u;
+    const uint32_t P = g_int ? (skip_one ? dG : dG + 1) : P_out;   // evaluation points actually used
     const uint32_t leaf_pts = mode == 1 ? P : 1u;
     const uint32_t wpts = mode == 0 ? P : 1u;
     const uint32_t levels = (uint32_t)sz.betas_count;
@@ -1991,7 +2025,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     std::vector<fe_t> weights((size_t)levels * wpts);
     std::vector<fe_t> pts;                                     // evaluation points X_p (F: w_t'^p ; G: w_G^p)
     if (g_int) {
-        for (uint32_t p = 0; p < P; ++p) pts.push_back(Fr::from_u64(p));
+        for (uint32_t p = 0; p < P; ++p) pts.push_back(Fr::from_u64(pt0 + p));
     } else if (mode != 2) {
         fe_t w = ntt::omega(ilog2(P), false), x = Fr::one();
         for (uint32_t p = 0; p < P; ++p) { pts.push_back(x); x = Fr::mul(x, w); }     // iter_cyclic_subgroup
@@ -2090,6 +2124,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         a.ctx.J = 1;
         a.ctx.wcoef = nullptr;
         a.ctx.half = 0;
+        a.ctx.pt0 = 0;
         a.ctx.shard_rank = 0;
         a.ctx.shard_world = 1;
         a.ctx.local_rows = a.ctx.rows;
@@ -2166,6 +2201,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     a.ctx.shard_rank = 0;
     a.ctx.shard_world = 1;
     a.ctx.local_rows = a.ctx.rows;
+    a.ctx.pt0 = pt0;
     a.compat = compat;
     a.leaf_pts = leaf_pts;
     a.P = P;
@@ -2203,8 +2239,21 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         SRS_HIP_CHECK(hipStreamSynchronize(st));
         SRS_HIP_CHECK(hipGetLastError());
         prof::collect();
-        const std::vector<fe_t> vinv = dG ? inverse_vandermonde(f, dG) : std::vector<fe_t>();    // [dG][dG + 1], rows k = 1..dG
         for (uint32_t m = 0; m < P_out; ++m) out_host[m] = Fr::zero();
+        if (skip_one) {                                          // values at the nodes 1 .. dG + 1: G(1) = F(alpha), then the evaluated ones
+            std::vector<fe_t> at(dG + 1);
+            at[0] = *g_at_one;
+            for (uint32_t j = 0; j < P; ++j) at[j + 1] = val[j];
+            const std::vector<fe_t> vall = inverse_vandermonde_at(f, dG, 1);              // [dG + 1][dG + 1], rows k = 0..dG
+            for (uint32_t k = 0; k <= dG && k < P_out; ++k) {
+                fe_t acc = Fr::zero();
+                for (uint32_t j = 0; j <= dG; ++j) acc = Fr::add(acc, Fr::mul(vall[(size_t)k * (dG + 1) + j], at[j]));
+                out_host[k] = acc;
+            }
+            *n_out = P_out;
+            return 0;
+        }
+        const std::vector<fe_t> vinv = dG ? inverse_vandermonde(f, dG) : std::vector<fe_t>();    // [dG][dG + 1], rows k = 1..dG
         out_host[0] = val[0];                                                                       // G(0)
         for (uint32_t k = 1; k <= dG && k < P_out; ++k) {
             fe_t acc = Fr::zero();

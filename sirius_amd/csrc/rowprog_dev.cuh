@@ -35,6 +35,8 @@ struct RowCtx {
                               //   (2^ROW_STRIPE_LOG rows each, the stripes of the sharded commitment key); world == 1: all rows
     uint32_t half;            // J == 2, wcoef == nullptr: (W[0] + W[1]) / 2 + pt * (W[0] - W[1]) / 2, i.e. the Lagrange fold
                               //   L_0(X) W[0] + L_1(X) W[1] over the domain {1, -1} at the integer point X = pt (compute_G, L = 1)
+    uint32_t pt0;             // sweep form only: the first evaluation point is X = pt0 instead of X = 0 (compute_G skips X = 1 when the
+                              //   caller knows G(1) = F(alpha) and X = 0 with it: the points are 2 .. d + 1)
 };
 
 struct DevArgs {
@@ -118,6 +120,7 @@ __device__ __forceinline__ void adv_affine(const RowCtx &C, uint32_t col, uint32
             step = w1;
         }
     }
+    for (uint32_t i = 0; i < C.pt0; ++i) cur = F::add(cur, step);
 }
 
 constexpr uint32_t ROW_STRIPE_LOG = 10;   // == msm::STRIPE_LOG: rows and key entries are sharded alike
