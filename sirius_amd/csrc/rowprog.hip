@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <tuple>
 
@@ -1505,6 +1506,7 @@ struct Structure {
     std::vector<Program> gate_progs;   // S.gates one by one (ProtoGalaxy leaves, plonk/mod.rs:697-701)
     int pg_spec_id = -1;           // ahead-of-time specialised leaf kernel for this gate set, or -1
     size_t max_gate_degree = 0;    // max_i gates[i].degree()  (get_points_count, poly/mod.rs:535-545)
+    std::vector<fe_t> vinv_g, vinv_g1;   // compute_G at integer points: inverse Vandermonde of the nodes 0..d_G (rows 1..d_G) / 1..d_G+1 (all rows)
     GateProg *d_gate_progs = nullptr;
     std::vector<fe_t> vinv;        // [degree][degree+1]
     // device data
@@ -1647,6 +1649,10 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     for (size_t g = 0; g < roots.size(); ++g) {
         if (!build_program(ast, roots[g], f, ctx, false, S->gate_progs[g], err)) { rc = 7; return nullptr; }
         S->max_gate_degree = std::max(S->max_gate_degree, expr_degree(ast, roots[g], ctx));
+    }
+    if (field == 0 && S->max_gate_degree >= 1 && S->max_gate_degree <= 64) {     // 6 inversions each: once per structure, not per prove
+        S->vinv_g = inverse_vandermonde(f, S->max_gate_degree);
+        S->vinv_g1 = inverse_vandermonde_at(f, S->max_gate_degree, 1);
     }
     for (size_t e = 0; e < sizeof(kPgSpecs) / sizeof(kPgSpecs[0]); ++e) {
         if ((size_t)kPgSpecs[e].n_gates != S->gate_progs.size()) continue;
@@ -2244,7 +2250,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
             std::vector<fe_t> at(dG + 1);
             at[0] = *g_at_one;
             for (uint32_t j = 0; j < P; ++j) at[j + 1] = val[j];
-            const std::vector<fe_t> vall = inverse_vandermonde_at(f, dG, 1);              // [dG + 1][dG + 1], rows k = 0..dG
+            const std::vector<fe_t> vall = !S->vinv_g1.empty() ? S->vinv_g1 : inverse_vandermonde_at(f, dG, 1);   // [dG + 1][dG + 1], rows k = 0..dG
             for (uint32_t k = 0; k <= dG && k < P_out; ++k) {
                 fe_t acc = Fr::zero();
                 for (uint32_t j = 0; j <= dG; ++j) acc = Fr::add(acc, Fr::mul(vall[(size_t)k * (dG + 1) + j], at[j]));
@@ -2253,7 +2259,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
             *n_out = P_out;
             return 0;
         }
-        const std::vector<fe_t> vinv = dG ? inverse_vandermonde(f, dG) : std::vector<fe_t>();    // [dG][dG + 1], rows k = 1..dG
+        const std::vector<fe_t> vinv = !S->vinv_g.empty() ? S->vinv_g : (dG ? inverse_vandermonde(f, dG) : std::vector<fe_t>());    // [dG][dG + 1], rows k = 1..dG
         out_host[0] = val[0];                                                                       // G(0)
         for (uint32_t k = 1; k <= dG && k < P_out; ++k) {
             fe_t acc = Fr::zero();
@@ -2287,11 +2293,50 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
         // The K domain is tiny (256 points in every configuration, quirk Q2): the points are computed on the host with ONE
         // inversion for all denominators (Montgomery's trick).  A GPU thread per point spends two Fermat inversions =
         // 760 dependent multiplications = 0.6 ms of pure latency on it.
-        const fe_t zeta = ntt::zeta(), omega = ntt::omega(log_domain_K, false), one = Fr::one();
-        const fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
-        std::vector<fe_t> g(count), xn1(count), xm1(count), pref(2 * count), xs(count);
-        fe_t X = zeta, acc = one;
-        for (size_t i = 0; i < count; ++i) { xs[i] = X; X = Fr::mul(X, omega); }
+        // Everything that depends on the domain only -- the points X_i = zeta omega^i, 1 / Z(X_i) and L_0(X_i) = Z(X_i) / (n (X_i - 1))
+        // (lagrange.rs:50-75) -- is computed once per (domain, n) and kept: two inversions and 2 x 256 products less per prove.
+        struct KDomain { std::vector<fe_t> xs, l0, inv_z; bool zero_z = false; };
+        static std::mutex mu;
+        static std::map<std::pair<uint32_t, size_t>, KDomain> cache;
+        const KDomain *dom;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = cache.find({log_domain_K, instances_to_fold});
+            if (it == cache.end()) {
+                KDomain d;
+                const fe_t zeta = ntt::zeta(), omega = ntt::omega(log_domain_K, false), one = Fr::one();
+                const fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
+                d.xs.resize(count); d.l0.resize(count); d.inv_z.resize(count);
+                std::vector<fe_t> xn1(count), xm1(count), pref(2 * count);
+                fe_t X = zeta, acc = one;
+                for (size_t i = 0; i < count; ++i) { d.xs[i] = X; X = Fr::mul(X, omega); }
+                for (size_t i = 0; i < count; ++i) {
+                    xn1[i] = Fr::sub(Fr::pow_u64(d.xs[i], instances_to_fold), one);
+                    xm1[i] = Fr::sub(d.xs[i], one);
+                    if (Fr::is_zero(xn1[i])) d.zero_z = true;                                  // X = 1 included (then X - 1 = 0 too)
+                }
+                if (!d.zero_z) {
+                    for (size_t i = 0; i < count; ++i) {
+                        pref[2 * i] = acc;
+                        acc = Fr::mul(acc, xn1[i]);
+                        pref[2 * i + 1] = acc;
+                        acc = Fr::mul(acc, xm1[i]);
+                    }
+                    fe_t inv = Fr::inv(acc);
+                    for (size_t i = count; i-- > 0;) {
+                        const fe_t inv_xm1 = Fr::mul(inv, pref[2 * i + 1]);
+                        inv = Fr::mul(inv, xm1[i]);
+                        d.inv_z[i] = Fr::mul(inv, pref[2 * i]);
+                        inv = Fr::mul(inv, xn1[i]);
+                        d.l0[i] = Fr::mul(inv_n, Fr::mul(xn1[i], inv_xm1));
+                    }
+                }
+                it = cache.emplace(std::make_pair(log_domain_K, instances_to_fold), std::move(d)).first;
+            }
+            dom = &it->second;
+        }
+        if (dom->zero_z) { err = "Z(X) must be not equal to 0"; return 4; }
+        std::vector<fe_t> kp(count);
         // the evaluations G(X_i) are independent: spread over a few host threads (8 x 256 Horner steps are ~0.1 ms on one core,
         // on the critical path between compute_G and the gamma challenge)
         {
@@ -2300,33 +2345,14 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
             auto work = [&](size_t lo, size_t hi) {
                 for (size_t i = lo; i < hi; ++i) {
                     fe_t gi = Fr::zero();
-                    for (size_t k = nG; k-- > 0;) gi = Fr::add(Fr::mul(gi, xs[i]), polyG_host[k]);   // UnivariatePoly::eval (univariate.rs:67-75), Horner: same value
-                    g[i] = gi;
-                    xn1[i] = Fr::sub(Fr::pow_u64(xs[i], instances_to_fold), one);
-                    xm1[i] = Fr::sub(xs[i], one);
+                    for (size_t k = nG; k-- > 0;) gi = Fr::add(Fr::mul(gi, dom->xs[i]), polyG_host[k]);   // UnivariatePoly::eval (univariate.rs:67-75), Horner: same value
+                    kp[i] = Fr::mul(Fr::sub(gi, Fr::mul(f_alpha, dom->l0[i])), dom->inv_z[i]);
                 }
             };
             const size_t per = (count + nthr - 1) / nthr;
             for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work, t * per, std::min(count, (t + 1) * per));
             work(0, std::min(count, per));
             for (auto &th : pool) th.join();
-        }
-        for (size_t i = 0; i < count; ++i) {
-            if (Fr::is_zero(xn1[i])) { err = "Z(X) must be not equal to 0"; return 4; }     // X = 1 included (then X - 1 = 0 too)
-            pref[2 * i] = acc;
-            acc = Fr::mul(acc, xn1[i]);
-            pref[2 * i + 1] = acc;
-            acc = Fr::mul(acc, xm1[i]);
-        }
-        fe_t inv = Fr::inv(acc);
-        std::vector<fe_t> kp(count);
-        for (size_t i = count; i-- > 0;) {
-            const fe_t inv_xm1 = Fr::mul(inv, pref[2 * i + 1]);
-            inv = Fr::mul(inv, xm1[i]);
-            const fe_t inv_xn1 = Fr::mul(inv, pref[2 * i]);
-            inv = Fr::mul(inv, xn1[i]);
-            const fe_t l0 = Fr::mul(inv_n, Fr::mul(xn1[i], inv_xm1));                        // lagrange.rs:50-75
-            kp[i] = Fr::mul(Fr::sub(g[i], Fr::mul(f_alpha, l0)), inv_xn1);
         }
         SRS_HIP_CHECK(hipMemcpyAsync(d_out, kp.data(), count * sizeof(fe_t), hipMemcpyHostToDevice, st));
         ntt::run(d_out, log_domain_K, count, 1, true, true, st);     // UnivariatePoly::coset_ifft

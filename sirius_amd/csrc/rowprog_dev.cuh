@@ -174,7 +174,7 @@ constexpr uint32_t SW_WORDS = 9;
 // 9 points they are 41.5 KB and only three workgroups fit a CU; the cross terms of the benchmark circuits have 6 - 7.
 SRS_HD constexpr uint32_t sweep_smem_bytes(uint32_t npts) { return npts * SW_WORDS * RP_THREADS * 4u; }
 #if defined(SRS_EMU)
-#define SRS_SWEEP_ACC(name) static uint32_t name[(DMAX + 1) * SW_WORDS * RP_THREADS]
+#define SRS_SWEEP_ACC(name) static thread_local uint32_t name[(DMAX + 1) * SW_WORDS * RP_THREADS]
 #else
 #define SRS_SWEEP_ACC(name) extern __shared__ uint32_t name[]
 #endif

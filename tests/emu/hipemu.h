@@ -9,9 +9,15 @@
 // Model: blocks run one after another inside one OS thread; the threads of a block are ucontext
 // fibers, so __syncthreads and wave shuffles have true barrier semantics (a fiber that reaches a
 // barrier yields until every live thread of the block / lane of the wave has arrived);
-// `__shared__` is a plain `static` (one block alive at a time).  Wave = 64 lanes.
+// `__shared__` is a `static thread_local` (one block alive at a time per host worker).  Wave = 64 lanes.
+// Large grids are spread over a few host threads (blocks are independent; global atomics are real atomics).
 #pragma once
 #include <ucontext.h>
+#include <thread>
+#include <cstdlib>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 
 #include <algorithm>
 #include <cstdint>
@@ -25,7 +31,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define __restrict__
 #define __launch_bounds__(...)
 #define __constant__ static
@@ -40,8 +46,8 @@ struct dim3 {
 struct uint3_ {
     unsigned x, y, z;
 };
-inline uint3_ threadIdx, blockIdx;
-inline dim3 blockDim, gridDim;
+inline thread_local uint3_ threadIdx, blockIdx;
+inline thread_local dim3 blockDim, gridDim;
 static constexpr int warpSize = 64;
 
 namespace hipemu {
@@ -63,8 +69,8 @@ struct BlockCtx {
     void (*entry)(void *) = nullptr;
     void *entry_arg = nullptr;
 };
-inline BlockCtx g_ctx;
-inline unsigned t_lin = 0;   // linear thread id of the running fiber
+inline thread_local BlockCtx g_ctx;
+inline thread_local unsigned t_lin = 0;   // linear thread id of the running fiber
 inline constexpr size_t kStack = 512 * 1024;
 
 inline void yield_as(int wait) {
@@ -298,9 +304,9 @@ inline unsigned __brev(unsigned x) {
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 
 template <class T>
-inline T atomicAdd(T *p, T v) { return ({ T o_ = *p; *p = o_ + v; o_; }); }
+inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 template <class T>
-inline T atomicSub(T *p, T v) { return ({ T o_ = *p; *p = o_ - v; o_; }); }
+inline T atomicSub(T *p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); }
 template <class T>
 inline T atomicMax(T *p, T v) {
     T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
@@ -366,10 +372,10 @@ inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t
 }
 
 namespace hipemu {
-// Run kernel(args...) over grid x block: blocks sequentially, threads of a block as fibers.
+// Run kernel(args...) over grid x block: the threads of a block are fibers; the blocks of a large grid are dealt to a few
+// host threads (every piece of emulator state is thread_local), a small grid runs on the calling thread.
 template <class K, class... A>
-inline void launch(K kernel, dim3 grid, dim3 block, size_t dyn_smem, A... args) {
-    (void)dyn_smem;
+inline void run_blocks(K kernel, dim3 grid, dim3 block, size_t first, size_t stride, A... args) {
     unsigned nthreads = block.x * block.y * block.z;
     blockDim = block;
     gridDim = grid;
@@ -392,11 +398,93 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t dyn_smem, A... args) 
     g_ctx.entry = [](void *p) { (*static_cast<B *>(p))(); };
     g_ctx.entry_arg = &body;
     size_t nblocks = (size_t)grid.x * grid.y * grid.z;
-    for (size_t b = 0; b < nblocks; ++b) {
+    for (size_t b = first; b < nblocks; b += stride) {
         blockIdx.x = (unsigned)(b % grid.x);
         blockIdx.y = (unsigned)((b / grid.x) % grid.y);
         blockIdx.z = (unsigned)(b / ((size_t)grid.x * grid.y));
         run_block();
     }
+}
+inline unsigned host_workers() {
+    static const unsigned n = [] {
+        const char *e = std::getenv("HIPEMU_THREADS");
+        unsigned v = e ? (unsigned)std::atoi(e) : std::thread::hardware_concurrency();
+        return v < 1 ? 1u : (v > 16 ? 16u : v);
+    }();
+    return n;
+}
+// persistent host workers (their fiber stacks live as long as the process): one job at a time; a launch that finds the pool
+// busy (another host thread is launching) simply runs on its own thread
+struct Pool {
+    std::mutex job_mu;                      // held by the launching thread for the whole job
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::vector<std::thread> threads;
+    std::function<void(unsigned)> job;
+    unsigned long gen = 0;
+    unsigned pending = 0;
+    bool quit = false;
+    void start(unsigned n) {
+        for (unsigned w = 1; w < n; ++w)
+            threads.emplace_back([this, w]() {
+                unsigned long seen = 0;
+                for (;;) {
+                    std::function<void(unsigned)> j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return quit || gen != seen; });
+                        if (quit) return;
+                        seen = gen;
+                        j = job;
+                    }
+                    j(w);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) done_cv.notify_all();
+                    }
+                }
+            });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+inline Pool &pool() {
+    static Pool p;
+    static std::once_flag once;
+    std::call_once(once, [] { p.start(host_workers()); });
+    return p;
+}
+template <class K, class... A>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t dyn_smem, A... args) {
+    (void)dyn_smem;
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    const size_t work = nblocks * block.x * block.y * block.z;
+    const unsigned W = host_workers();
+    if (W <= 1 || nblocks < 2 || work < 4096) {
+        run_blocks(kernel, grid, block, 0, 1, args...);
+        return;
+    }
+    Pool &P = pool();
+    std::unique_lock<std::mutex> job_lk(P.job_mu, std::try_to_lock);
+    if (!job_lk.owns_lock()) {
+        run_blocks(kernel, grid, block, 0, 1, args...);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.job = [=](unsigned w) { run_blocks(kernel, grid, block, w, W, args...); };
+        P.pending = W - 1;
+        ++P.gen;
+    }
+    P.cv.notify_all();
+    run_blocks(kernel, grid, block, 0, W, args...);
+    std::unique_lock<std::mutex> lk(P.mu);
+    P.done_cv.wait(lk, [&] { return P.pending == 0; });
 }
 }  // namespace hipemu

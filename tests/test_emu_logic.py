@@ -104,7 +104,8 @@ def test_emu_key_file_and_deciders(emu, oracle, tmp_path):
 
 def test_emu_fold_then_decider(emu, oracle):
     from test_sangria_gpu import _fold_then_decide
-    _fold_then_decide(emu, oracle, 1, 1, 3, (2,))          # the (5, 3) workload runs on the GPU (tests/test_sangria_gpu.py)
+    _fold_then_decide(emu, oracle, 0, 0, 4, (5, 3))
+    _fold_then_decide(emu, oracle, 1, 1, 3, (2,))
 
 
 def test_emu_protogalaxy_fold_identity(emu, oracle):
@@ -220,7 +221,7 @@ def test_emu_long_level0_parts():
         "from conftest import seeded_scalars\n"
         f"_lib.load({EMU_LIB!r})\n"
         "bases = O.make_bases(1, 4, 400); ck = S.CommitmentKey(1, bases)\n"
-        "for kind in ('trace',):\n"
+        "for kind in ('uniform', 'trace'):\n"
         "    v = seeded_scalars(O, 1, 400, 9, kind); assert np.array_equal(ck.commit(v), O.msm(1, v, bases))\n"
         "print('ok')\n")
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
