@@ -22,8 +22,9 @@ memory traffic); the default `true` reads the leaf's own row -- the heavier, int
 reported as a secondary object next to the 2^24 MSM / NTT microbenchmark (configs[4]), each with its own roofline.
 
 Multi-GPU (torchrun, one rank per GPU): every MSM is sharded block-cyclically over the ranks, the 64-byte partial commitments
-are all-gathered over RCCL and summed on the host; the row programs are replicated (support-circuit cross terms row-sharded).
-One IVC chain is sequential, so this is STRONG scaling of a single step.
+are all-gathered over RCCL and summed on the host; the row programs are sharded by the same row stripes (cross terms; the
+ProtoGalaxy leaves: partial F / G polynomials all-gathered and added), the witness upload is 1 / world per rank; K, the transcript
+and the folds over whole vectors stay replicated.  One IVC chain is sequential, so this is STRONG scaling of a single step.
 
 Prints ONE JSON line (rank 0).  `roofline`: dominant kernel = MSM bucket accumulation; achieved = 96 B x scalars / launch time
 (HIP events on the launch stream, inside the library).  `cpu_baseline`: the CPU oracle (oracle/, a C port of the reference's
@@ -115,6 +116,12 @@ class Dist:
             return partial
         from sirius_amd.distributed import all_gather_commitments
         return all_gather_commitments(curve, partial, device=self.dev if self.dist.get_backend() == "nccl" else None)
+
+    def sum_field(self, field, partial):
+        if self.world == 1:
+            return partial
+        from sirius_amd.distributed import all_gather_field_sum
+        return all_gather_field_sum(field, partial, device=self.dev if self.dist.get_backend() == "nccl" else None)
 
     def barrier(self):
         import torch
@@ -244,6 +251,11 @@ class PgPrimary:
         w = make_structure_inputs("primary", k, seed=0x5349524955530000 + 3)
         self.w, self.k, self.rows = w, k, w["rows"]
         self.S = S.PlonkStructure(0, k, [], w["fixed"], w["num_advice"], w["gates"])
+        # process-per-GPU: the leaves are sharded by the key's row stripes (true leaf rows only: the reference's row-0 quirk pins
+        # every leaf to rank 0's stripe), so F / G / e come out as partial polynomials and the witness upload is 1 / world each
+        self.sharded = D.world > 1 and not compat and ((1 << k) >> 10) % D.world == 0     # row stripes == key stripes of every column
+        if self.sharded:
+            self.S.set_shard(D.rank, D.world)
         self.ctx = PG.PolyContext(self.S, 1)
         n = w["num_advice"] * self.rows
         assert n <= (1 << log_key)
@@ -279,11 +291,33 @@ class PgPrimary:
             ro.absorb_field(np.concatenate([self.accC.reshape(2, 4), self.inC.reshape(2, 4)]))
             ro.absorb_field(self.betas)
             delta = PGint(ro.squeeze(128, 0))
+        if self.sharded:
+            return self.prove_sharded(S, D, ro, m([delta])[0], alpha, gamma)
         # one library call (srs_pg_prove): F -> alpha -> betas' -> G -> K -> gamma -> L(gamma), e, fold_witness
         pr = PG.prove(ctx, self.betas, m([delta])[0], [self.accW, self.inW], ro=ro,
                       alpha=None if ro else m([alpha])[0], gamma=None if ro else m([gamma])[0], reference_compat=self.compat)
         self.e, self.accW, self.betas = pr["e"], pr["W"], pr["betas_stroke"]
         self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), pr["lagrange"][:2])   # fold_instance
+
+    def prove_sharded(self, S, D, ro, delta_m, alpha, gamma):
+        """The same prove with the leaves sharded over the ranks: every rank evaluates the tiles of ITS stripes, the partial
+        polynomials (33 / 8 coefficients) are all-gathered and added; K, e and the transcript are replicated host work."""
+        PG, ctx, m = self.PG, self.ctx, self.m
+        pF = D.sum_field(0, PG.compute_F(ctx, self.betas, delta_m, self.accW, reference_compat=False))
+        if ro:
+            ro.absorb_field(pF)
+        alpha_m = ro.squeeze(255, 0) if ro else m([alpha])[0]
+        bs = PG.beta_stroke(self.betas, alpha_m, delta_m)
+        pG = D.sum_field(0, PG.compute_G(ctx, bs, [self.accW, self.inW], reference_compat=False))
+        pK = PG.compute_K_from_G(ctx, pG, PG.poly_eval(pF, alpha_m))
+        if ro:
+            ro.absorb_field(pK)
+        gamma_m = ro.squeeze(255, 0) if ro else m([gamma])[0]
+        self.e = PG.calculate_e(pF, pK, gamma_m, alpha_m, ctx.lagrange_domain)
+        lag = PG.eval_lagrange_poly_for_cyclic_group(gamma_m, ctx.lagrange_domain)
+        self.accW = PG.fold_witness(0, [self.accW, self.inW], lag)     # all rows; the rank only ever reads its own stripes of the result
+        self.betas = bs
+        self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), lag[:2])       # fold_instance
 
     def witness_commit(self, S, D):
         """generate_plonk_trace -> run_sps_protocol_1: ck.commit(W1) of the NEW witness, host -> HBM inside the call."""
@@ -534,6 +568,12 @@ def main():
                 st = S.profile_get(name)
                 if st and st["launches"]:
                     prof[name + "_ms"] = round(st["total_ms"] / st["launches"], 4)
+            import hashlib
+            pri.settle(); sup.settle()
+            # what the chain has folded so far (the primary's e and instance commitments, the support accumulator's commitments): the
+            # same for every --gpus N, which is how the tests compare the sharded step with the single-process one
+            digest = hashlib.sha256(b"".join(np.ascontiguousarray(x, dtype=np.uint64).tobytes() for x in
+                                             (pri.e, pri.accC, pri.inC, sup.accCW, sup.accCE, sup.inC))).hexdigest()
             out = {
                 "metric": "IVC fold-steps/s (CycleFold IVC::next hot path, Poseidon-shaped synthetic trace, 2^k rows)",
                 "value": round(args.steps / dt, 4), "unit": "fold-steps/s", "n_gpus": D.world, "steps": args.steps,
@@ -545,10 +585,10 @@ def main():
                                       f"12*2^{k} witness commit with the witness uploaded from host memory inside the step",
                            "support": f"Sangria prove on the support circuit: k={ks}, 3 advice / 4 fixed / 1 selector, 2 cross terms; 3*2^{ks} witness commit",
                            "leaf_rows": args.leaf_rows, "challenges": "poseidon-ro" if args.ro_challenge else "seeded",
-                           "parallelism": f"msm-shard{D.world}" if D.world > 1 else "single-gpu"},
+                           "parallelism": (f"msm+leaf-shard{D.world}" if getattr(pri, "sharded", False) else f"msm-shard{D.world}") if D.world > 1 else "single-gpu"},
                 "msm_scalars_per_s": round(scalars_per_step * args.steps / dt, 1),
                 "witness_upload_bytes_per_step": int(pri.w["num_advice"] * pri.rows * 32 + 3 * sup.rows * 32),
-                "roofline": roof, "kernel_ms": prof,
+                "roofline": roof, "kernel_ms": prof, "state_digest": digest,
             }
             if D.world == 1 and not args.no_cpu_baseline:
                 try:

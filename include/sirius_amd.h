@@ -123,7 +123,9 @@ int srs_commit_batch(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, 
  * a device copy behind for the prover calls that follow (VanillaFS::prove / ProtoGalaxy::prove take it with
  * SRS_SPACE_DEVICE).  The vector goes up in a few chunks on an internal copy stream and the MSM of chunk j runs while chunk
  * j+1 is still on the bus; the partial sums are added on the host.  dev_copy: n elements of HBM (srs_dev_alloc) or NULL
- * (library staging, no copy kept).  Same result and errors as srs_commit. */
+ * (library staging, no copy kept).  Same result and errors as srs_commit.  On a key sharded over processes (srs_ck_create_sharded)
+ * only THIS rank's stripes of the vector go up (n * 32 / world bytes) and only they are written in dev_copy -- the rank's partial
+ * MSM, its rows of the cross terms and its tiles of the ProtoGalaxy leaves read nothing else. */
 int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *dev_copy, int repr, void *stream,
                       srs_affine *out);
 
@@ -236,7 +238,14 @@ void srs_structure_free(srs_structure *S);
 /* Multi-GPU (one process per GPU, keys from srs_ck_create_sharded): with a shard set, srs_cross_terms /
  * srs_commit_cross_terms evaluate the cross terms only on the rows of THIS rank's block-cyclic stripes (2^10 rows each, the
  * stripes of the sharded key) -- the only rows the rank's partial commitment and its part of the error fold read.  Rows of
- * T_out outside those stripes are left untouched (device buffers) / returned as zero (host buffers).  The deciders (srs_eval_gates, srs_is_sat_gates) always cover every row. */
+ * T_out outside those stripes are left untouched (device buffers) / returned as zero (host buffers).  The deciders (srs_eval_gates, srs_is_sat_gates) always cover every row.
+ * The ProtoGalaxy sums of a sharded structure (srs_pg_compute_F / _G / srs_pg_evaluate_e) cover the leaves of the rank's stripes only
+ * (a 1024-leaf tile of the leaf kernels is a stripe; structures of fewer than 2^10 rows: rank 0 evaluates everything): every rank
+ * gets a PARTIAL polynomial / value, the results of all ranks add up (coefficient-wise, e.g. srs_fold_lincomb on host vectors) to
+ * the polynomial of the reference.  Row stripes coincide with the key's stripes of every witness column when 2^k / 2^10 is a
+ * multiple of `world` (what the sharded srs_commit_upload relies on).  The witness rows of other ranks' stripes are never read (unless reference_compat pins every
+ * leaf to row 0, which belongs to rank 0's stripe).  The whole-prove entries (srs_pg_prove, srs_sangria_prove) refuse sharded handles:
+ * the challenges depend on the exchanged sums. */
 int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world);
 size_t srs_structure_num_witness_columns(const srs_structure *S);   /* num_advice + 5 * num_lookups */
 size_t srs_structure_num_cross_terms(const srs_structure *S);   /* d = grouped().len() - 1 */

@@ -946,9 +946,29 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
     int rc = ensure_device();
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (ck->shards.empty() && ck->key.world > 1 && n && dev_copy) {
+        // sharded (process-per-GPU) key: the rank's kernels -- its partial MSM, its rows of the cross terms, its tiles of the
+        // ProtoGalaxy leaves -- read only the rank's block-cyclic stripes of any vector, so only those go up: n * 32 / world
+        // bytes over this GPU's link (one strided copy + the ragged tail); the other stripes of dev_copy are left as they are
+        rc = guarded([&]() -> int {
+            const size_t S = (size_t)1 << msm::STRIPE_LOG, W = ck->key.world, R = ck->key.rank;
+            const fe_t *src = reinterpret_cast<const fe_t *>(scalars_host);
+            fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
+            const size_t full = n / S;                                   // complete stripes
+            const size_t mine = full > R ? (full - R + W - 1) / W : 0;   // complete stripes of this rank
+            if (mine)
+                SRS_HIP_CHECK(hipMemcpy2DAsync(dst + R * S, W * S * sizeof(fe_t), src + R * S, W * S * sizeof(fe_t), S * sizeof(fe_t), mine,
+                                               hipMemcpyHostToDevice, st));
+            if (n % S && full % W == R)                                  // the ragged last stripe is this rank's
+                SRS_HIP_CHECK(hipMemcpyAsync(dst + full * S, src + full * S, (n % S) * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            return SRS_OK;
+        });
+        if (rc) return rc;
+        return srs_commit(ck, dev_copy, n, SRS_SPACE_DEVICE, repr, stream, out);
+    }
     if (!ck->shards.empty() || ck->key.world != 1 || n == 0) {
         // multi-device key: every shard pulls its stripes from the host buffer over its own link; sharded (process-per-GPU)
-        // key: the kernels pick this rank's stripes out of the full vector.  The device copy is a plain upload.
+        // key without a device copy: the kernels pick this rank's stripes out of the full vector.
         if (dev_copy && n) {
             rc = guarded([&]() -> int {
                 SRS_HIP_CHECK(hipMemcpyAsync(dev_copy, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
@@ -1954,6 +1974,8 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
     if (n_instances < 2) return fail(SRS_ERR_INVALID, "You can't fold 0 traces");                // poly/mod.rs:27
     if (n_instances & (n_instances - 1)) return fail(SRS_ERR_INVALID, "instances_to_fold must be a power of two");
     if (ro && ro->h->field != SRS_FIELD_FR) return fail(SRS_ERR_INVALID, "srs_pg_prove: the oracle must be over bn256::Fr");
+    if (rowprog::shard_world(S->s) > 1)   // the polynomials of a sharded structure are PARTIAL sums: alpha / gamma need the exchanged ones
+        return fail(SRS_ERR_INVALID, "srs_pg_prove: structure is row-sharded (srs_structure_set_shard); use the step-wise calls and add the ranks' polynomials");
     int rc = ensure_device();
     if (rc) return rc;
     return guarded([&]() -> int {
@@ -2037,6 +2059,8 @@ int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_
     const int curve = ck->key.curve, sf = srs_scalar_field_of(curve);
     if (ro && ro->h->field != (curve == SRS_CURVE_BN256 ? SRS_FIELD_FQ : SRS_FIELD_FR))
         return fail(SRS_ERR_INVALID, "srs_sangria_prove: the oracle's field is not the curve's base field");
+    if (rowprog::shard_world(S->s) > 1 || ck->key.world > 1)   // partial cross-term commitments: the challenge needs the exchanged ones
+        return fail(SRS_ERR_INVALID, "srs_sangria_prove: structure / key is sharded over processes; use the step-wise calls and add the ranks' partial commitments");
     const size_t d = srs_structure_num_cross_terms(S), rows = rowprog::rows(S->s), wlen = rowprog::num_witness_columns(S->s) * rows;
     int rc = srs_commit_cross_terms(S, ck, W1, W2, challenges, n_challenges, SRS_SPACE_DEVICE, stream, T_dev, cross_term_commits);
     if (rc) return rc;

@@ -141,7 +141,16 @@ struct PgArgs {
     uint32_t wpts;            // P (F) or 1 (G, e)
     uint32_t tile_log;        // leaves per workgroup = 2^tile_log (<= 7)
     fe_t *partial;            // [n_gates * tiles_per_gate][P]
+    uint32_t shard_rank, shard_world;   // process-per-GPU runs (set_shard): a 1024-leaf tile IS a key stripe (ROW_STRIPE_LOG), this rank
+                              //   evaluates the tiles t % world == rank and leaves zeros for the others: its result is a PARTIAL sum
 };
+__device__ __forceinline__ bool pg_tile_is_mine(const PgArgs &A, uint32_t tile) {
+    return A.shard_world <= 1 || tile % A.shard_world == A.shard_rank;
+}
+// a tile of another rank: zero partial sums (block-uniform exit before any barrier)
+__device__ __forceinline__ void pg_zero_partial(const PgArgs &A, uint32_t gate, uint32_t tile) {
+    for (uint32_t p = threadIdx.x; p < A.P; p += blockDim.x) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = Fr::zero();
+}
 
 // binary-tree combine of blockDim.x values: v[2t] + v[2t+1] * w[level]; result in red[0]
 template <class F>
@@ -167,6 +176,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_leaves(PgArgs A) {
     __shared__ fe_t red[RP_THREADS];
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x;
+    if (!pg_tile_is_mine(A, tile)) { pg_zero_partial(A, gate, tile); return; }
     const GateProg G = A.gates[gate];
     const uint32_t TL = A.tile_log - LPT_LOG;                          // log2(blockDim.x)
     const uint32_t row0 = (tile << A.tile_log) + threadIdx.x;          // < rows (rows is a multiple of the tile)
@@ -201,6 +211,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_spec(PgArgs A) {
     __shared__ fe_t red[RP_THREADS];
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x;
+    if (!pg_tile_is_mine(A, tile)) { pg_zero_partial(A, gate, tile); return; }
     const GateProg G = A.gates[gate];
     const uint32_t TL = A.tile_log - LPT_LOG;
     const uint32_t row0 = (tile << A.tile_log) + threadIdx.x;
@@ -239,6 +250,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     SRS_SWEEP_ACC(acc_all);                                 // sweep_smem_bytes(P) of dynamic LDS
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    if (!pg_tile_is_mine(A, tile)) { pg_zero_partial(A, gate, tile); return; }
     const GateProg G = A.gates[gate];
     const uint32_t TL = A.tile_log - LPT_LOG;
     const uint32_t row0 = (tile << A.tile_log) + tid;
@@ -272,6 +284,11 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
     __shared__ fe_t slots[NSLOT * RP_THREADS];
     constexpr uint32_t LPT = 8, LPT_LOG = 3;
     const uint32_t gate = blockIdx.y, tile = blockIdx.x;
+    if (!pg_tile_is_mine(A, tile)) {                       // another rank's tile: zero cubic
+        const uint32_t node = (gate * gridDim.x + tile) * blockDim.x + threadIdx.x;
+        for (uint32_t m = 0; m < 4; ++m) nodes[(size_t)m * n_nodes + node] = F::zero();
+        return;
+    }
     const GateProg G = A.gates[gate];
     const uint32_t TL = A.tile_log - LPT_LOG;
     const uint32_t row0 = (tile << A.tile_log) + threadIdx.x;
@@ -1615,7 +1632,9 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     if (num_lookups && !parse_gates(lookup_exprs, lookup_words, 2 * num_lookups, ast, lroots, err)) return nullptr;
     if (!num_lookups && has_vector_lookup) { err = "has_vector_lookup without lookups"; return nullptr; }
     if (num_selectors + num_fixed == 0) { err = "Fixed & Selectors can't be empty in one time"; return nullptr; }   // eval.rs:47-54
-    std::unique_ptr<Structure> S(new Structure());
+    // destroy(), not delete: an exception half-way (e.g. hipMalloc of the fixed columns at a large k) must free the device
+    // allocations and the run-time compiled module the structure already owns
+    std::unique_ptr<Structure, void (*)(Structure *)> S(new Structure(), &destroy);
     S->field = field;
     S->k = k;
     S->rows = (size_t)1 << k;
@@ -2142,6 +2161,8 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         a.wpts = 1;
         a.tile_log = tile_log;
         a.partial = nullptr;
+        a.shard_rank = S->shard_rank;                      // lpt == 8 here: tile_log == ROW_STRIPE_LOG
+        a.shard_world = S->shard_world;
         PgFLevels lv;
         for (uint32_t j = 0; j < 3; ++j) { lv.beta[j] = weights_in[TL + j]; lv.delta[j] = deltas[TL + j]; }
         {
@@ -2216,6 +2237,10 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     a.wpts = wpts;
     a.tile_log = tile_log;
     a.partial = buf0;
+    // partial sums of a sharded structure: by tiles when a tile is a stripe (k >= 10), else rank 0 evaluates everything
+    if (tile_log == ROW_STRIPE_LOG) { a.shard_rank = S->shard_rank; a.shard_world = S->shard_world; }
+    else if (S->shard_world > 1 && S->shard_rank != 0) { a.shard_rank = 0xFFFFFFFFu; a.shard_world = 2; }     // no tile is mine
+    else { a.shard_rank = 0; a.shard_world = 1; }
     {
         prof::Scope ps(mode == 0 ? "pg_F_leaves" : (mode == 1 ? "pg_G_leaves" : "pg_e_leaves"), st, S->rows * n_gates);
         if (S->pg_spec_id >= 0 && lpt == 8)

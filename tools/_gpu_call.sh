@@ -1,14 +1,10 @@
 exec < /dev/null
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r02p; mkdir -p $O; cd $R
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
-timeout 900 python bench.py > $O/bench_full.json 2> $O/bench_full.err; tail -c 600 $O/bench_full.json
-cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 2 > $O/kt.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pf -- python $R/bench.py --no-extras --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pw -- python $R/bench.py --no-extras --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
-cd $R
-ff=$(find $O/pmc_fetch -name '*counter_collection.csv' | head -1); fw=$(find $O/pmc_write -name '*counter_collection.csv' | head -1)
-if [ -n "$ff" ] && [ -n "$fw" ]; then python tools/pmc_kernels.py "$ff" "$fw" 63668224 > $O/pmc_accum0.json 2>$O/pmc_err.txt; head -c 300 $O/pmc_accum0.json; rm -f "$ff" "$fw"; fi
-find $O -name '*.db' -delete
-ls $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r02q; mkdir -p $O; cd $R
+pick() { python -c "
+import json,sys
+d=json.loads(open('$1').read().strip().splitlines()[-1])
+print('$2', 'ms/step', d['ms_per_step'])"; }
+timeout 200 python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 2 > $O/c20_a.json 2>$O/err.txt; pick $O/c20_a.json "k20 default"
+SRS_MSM_SORT=2 timeout 200 python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 2 > $O/c20_b.json 2>$O/err.txt; pick $O/c20_b.json "k20 two-pass sort"
+PROBE_TAG=sort1 SRS_MSM_WIDE=0 SRS_MSM_SORT=1 timeout 200 python tools/msm_probe.py 24 1048576 3145728 5242880 12582912 > $O/p1.txt 2>&1; grep "n=" $O/p1.txt
+PROBE_TAG=sort2 SRS_MSM_WIDE=0 SRS_MSM_SORT=2 timeout 200 python tools/msm_probe.py 24 1048576 3145728 5242880 12582912 > $O/p2.txt 2>&1; grep "n=" $O/p2.txt
