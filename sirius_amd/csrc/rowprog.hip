@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -1017,7 +1018,7 @@ struct Program {
     int result_vreg = -1;
     // "sweep" form (plan_sweep): the expression as a sum of terms coef * body, evaluated for ALL points per column load
     struct SweepTerm { int node; int coef; int sign; int level; };   // node: vreg, or -(u)-1 for a row-independent term; coef: uniform index (pre-scaled)
-    struct SweepCluster { std::vector<int> terms, body, loads; };     // body / loads: vregs in SSA order
+    struct SweepCluster { std::vector<int> terms, body, loads; bool linear = false; };     // body / loads: vregs in SSA order; linear: see plan_sweep
     std::vector<SweepTerm> sw_terms;
     std::vector<SweepCluster> sw_clusters;
     std::vector<int> sw_level;      // per vreg: power of 2^-5 its 9 x 29-bit value carries (field29.cuh: R' = 2^261 vs the ABI's 2^256)
@@ -1220,6 +1221,28 @@ static void plan_sweep(Program &p, const FieldOps &f) {
         for (int x : {in.a, in.b})
             if (x < 0) p.sw_uat[{-x - 1, p.sw_level[in.dst]}] = B.u_scaled(-x - 1, -p.sw_level[in.dst]);
     }
+    // Terms that are AFFINE in the evaluation point -- a product chain with at most one advice leaf and point-independent
+    // coefficients (no challenge in the uniform program: the ProtoGalaxy gate polynomials) -- need no evaluation per point: their
+    // clusters compute the value at the first point and the slope (the same chain with the leaf's step in place of its value)
+    // once, and every further point is one lazy addition.  chain(v) = number of advice leaves of a pure product chain, -1 otherwise.
+    bool const_u = !std::getenv("SRS_SWEEP_NO_LINEAR");
+    for (const UOp &u : p.uops) const_u = const_u && u.op != 1;
+    std::function<int(int)> chain = [&](int v) -> int {
+        if (v < 0) return 0;
+        const VInsn &in = p.vins[B.def[v]];
+        if (in.op == I_LD_ADV) return 1;
+        if (in.op == I_LD_SEL || in.op == I_LD_FIX) return 0;
+        if (in.op != I_MUL) return -1;
+        const int a = chain(in.a), b = chain(in.b);
+        return (a < 0 || b < 0) ? -1 : a + b;
+    };
+    std::vector<char> term_linear(p.sw_terms.size(), 0);
+    for (size_t ti = 0; ti < p.sw_terms.size(); ++ti) {
+        if (!const_u) break;
+        const auto &t = p.sw_terms[ti];
+        const int c = t.node < 0 ? 0 : chain(t.node);
+        term_linear[ti] = c == 0 || c == 1;
+    }
     // clusters: terms in expression order; a term joins the open cluster while the hoisted columns fit the budget
     const size_t nv = B.def.size();
     std::vector<char> in_cluster(nv, 0);
@@ -1235,7 +1258,11 @@ static void plan_sweep(Program &p, const FieldOps &f) {
         cost = 0;
         std::fill(in_cluster.begin(), in_cluster.end(), 0);
     };
+    for (int pass = 0; pass < 2; ++pass) {                   // the per-point clusters first, then the affine ones
+    flush();
     for (size_t ti = 0; ti < p.sw_terms.size(); ++ti) {
+        if ((int)term_linear[ti] != pass) continue;
+        cur.linear = pass == 1;
         const auto &t = p.sw_terms[ti];
         if (t.node < 0) { cur.terms.push_back((int)ti); continue; }
         std::vector<char> seen(nv, 0);
@@ -1246,7 +1273,9 @@ static void plan_sweep(Program &p, const FieldOps &f) {
         if (!cur.terms.empty() && cost + extra > SWEEP_LOAD_BUDGET) flush();
         for (int v : loads) if (!in_cluster[v]) { in_cluster[v] = 1; cur.loads.push_back(v); cost += load_cost(v); }
         for (int v : body) if (!in_cluster[v]) { in_cluster[v] = 1; cur.body.push_back(v); }
+        cur.linear = pass == 1;
         cur.terms.push_back((int)ti);
+    }
     }
     flush();
     p.sweep_ok = !p.sw_clusters.empty();
@@ -1278,9 +1307,17 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
     o += "    using G = Fp29<typename F::Params>;\n    const uint32_t mask = C.rows - 1; (void)mask;\n";
     bool first = true;
     double acc_bound = 2.0;                                      // an accumulator handed in by the caller is folded: < 2p
+    // number of advice leaves of a product chain (the affine clusters hold nothing else)
+    std::function<int(int)> chain = [&](int v) -> int {
+        if (v < 0) return 0;
+        const VInsn &in = p.vins[def[v]];
+        if (in.op == I_LD_ADV) return 1;
+        if (in.op == I_LD_SEL || in.op == I_LD_FIX) return 0;
+        return chain(in.a) + chain(in.b);
+    };
     for (size_t ci = 0; ci < p.sw_clusters.size(); ++ci) {
         const auto &cl = p.sw_clusters[ci];
-        o += "    {   // cluster " + S((int)ci) + "\n";
+        o += std::string("    {   // cluster ") + S((int)ci) + (cl.linear ? " (affine in the point)\n" : "\n");
         for (int v : cl.loads) {
             const VInsn &in = p.vins[def[v]];
             const std::string rr = "(row + " + std::to_string((uint32_t)in.b) + "u) & mask";
@@ -1288,14 +1325,18 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
             else if (in.op == I_LD_FIX) o += "        const fe_t l" + S(v) + " = ld_fix<F>(C, " + S(in.a) + ", " + rr + ");\n";
             else o += "        fe_t l" + S(v) + ", s" + S(v) + "; adv_affine<F>(C, " + S(in.a) + ", " + rr + ", l" + S(v) + ", s" + S(v) + ");\n";
         }
-        o += "        for (uint32_t pt = 0; pt < npts; ++pt) {\n";
-        o += "            const fe_t *__restrict__ U = Uall + (size_t)pt * nu; (void)U;\n";
+        std::vector<char> is_load(def.size(), 0);            // column values are unpacked where they are used: a 9-limb copy of
+        for (int v : cl.loads) is_load[v] = 1;               // every hoisted column, live across the loop body, spills
+        // One evaluation of the cluster's terms.  IN: indentation; X: name prefix of the temporaries; slope: the advice leaves
+        // enter with their STEP and the terms without an advice leaf are left out (affine clusters).  -> expression of the lazy
+        // sum and its bound in units of p (empty: nothing to add).
+        auto gen = [&](const std::string &IN, const std::string &X, bool slope, double &total_b) -> std::string {
         std::map<int, double> bound;                           // static bound of a value in units of p (normalised limbs)
+        for (int v : cl.loads) bound[v] = 1.0;
         auto bnd = [&](int x) { return x >= 0 ? bound[x] : 1.0; };
         auto lvl = [&](int x) { return x >= 0 ? p.sw_level[x] : 0; };
-        std::vector<char> is_load(def.size(), 0);            // column values are unpacked where they are used: a 9-limb copy of
-        for (int v : cl.loads) { is_load[v] = 1; bound[v] = 1.0; }   // every hoisted column, live across the loop body, spills
         int tmp = 0;
+        const std::string D = IN + "const f29_t ";
         // operand x at `level` with a bound <= max_bound: the expression text; b_out = its bound
         auto prep = [&](int x, int level, double max_bound, double &b_out) -> std::string {
             if (x < 0) {                                         // row-independent operand: the host keeps a copy at every level needed
@@ -1305,26 +1346,44 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
                 auto it = p.sw_uat.find({u, level});
                 return "G::unpack(U[" + S(it == p.sw_uat.end() ? u : it->second) + "])";
             }
-            std::string e = is_load[x] ? "G::unpack(l" + S(x) + ")" : "x" + S(x);
+            std::string e;
+            if (is_load[x]) e = std::string("G::unpack(") + ((slope && p.vins[def[x]].op == I_LD_ADV) ? "s" : "l") + S(x) + ")";
+            else e = X + "x" + S(x);
             double b = bnd(x);
             if (lvl(x) < level) {                                // product with the raw constant 2^(261 - 5 delta): + delta levels
-                const std::string t = "r" + S(tmp++);
-                o += "            const f29_t " + t + " = " + MUL + e + ", G::unpack(U[" + S(p.sw_raise[level - lvl(x)]) + "]));\n";
+                const std::string t = X + "r" + S(tmp++);
+                o += D + t + " = " + MUL + e + ", G::unpack(U[" + S(p.sw_raise[level - lvl(x)]) + "]));\n";
                 e = t;
                 b = 2.0;
             }
             if (b > max_bound) {                                 // product with 2^261 mod p: the same value, below 2p again
-                const std::string t = "r" + S(tmp++);
-                o += "            const f29_t " + t + " = " + MUL + e + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
+                const std::string t = X + "r" + S(tmp++);
+                o += D + t + " = " + MUL + e + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
                 e = t;
                 b = 2.0;
             }
             b_out = b;
             return e;
         };
+        // in slope mode only the values the degree-1 terms need are computed
+        std::vector<char> want(def.size(), 1);
+        if (slope) {
+            std::fill(want.begin(), want.end(), 0);
+            std::function<void(int)> mark = [&](int v) {
+                if (v < 0 || want[v]) return;
+                want[v] = 1;
+                const VInsn &in = p.vins[def[v]];
+                if (in.op > I_LD_ADV) { mark(in.a); if (in.op <= I_MUL) mark(in.b); }
+            };
+            for (int ti : cl.terms) {
+                const auto &t = p.sw_terms[ti];
+                if (t.node >= 0 && chain(t.node) == 1) mark(t.node);
+            }
+        }
         for (int v : cl.body) {
+            if (!want[v]) continue;
             const VInsn &in = p.vins[def[v]];
-            const std::string d = "            const f29_t x" + S(v) + " = ";
+            const std::string d = D + X + "x" + S(v) + " = ";
             double ba, bb;
             switch (in.op) {
             case I_MUL: {
@@ -1375,17 +1434,18 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
         std::map<int, std::vector<int>> groups;
         for (int ti : cl.terms) {
             const auto &t = p.sw_terms[ti];
+            if (slope && (t.node < 0 || chain(t.node) != 1)) continue;
             if (!groups.count(t.coef)) order.push_back(t.coef);
             groups[t.coef].push_back(ti);
         }
         std::string total;
-        double total_b = 0;
+        total_b = 0;
         auto lazy_add = [&](std::string &sum, double &b, const std::string &e, double be, bool minus) {
-            const std::string r = "r" + S(tmp++);
+            const std::string r = X + "r" + S(tmp++);
             if (sum.empty()) {
                 if (minus) {
                     const int cp = (int)be + 1;
-                    o += "            const f29_t " + r + " = G::normalize(G::template neg_lazy<" + S(cp) + ", 0>(" + e + "));\n";
+                    o += D + r + " = G::normalize(G::template neg_lazy<" + S(cp) + ", 0>(" + e + "));\n";
                     b = cp;
                 } else {
                     sum = e;
@@ -1394,18 +1454,18 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
                 }
             } else if (minus) {
                 const int cp = (int)be + 1;
-                o += "            const f29_t " + r + " = G::normalize(G::template sub_lazy<" + S(cp) + ", 0>(" + sum + ", " + e + "));\n";
+                o += D + r + " = G::normalize(G::template sub_lazy<" + S(cp) + ", 0>(" + sum + ", " + e + "));\n";
                 b += cp;
             } else {
-                o += "            const f29_t " + r + " = G::normalize(G::add_lazy(" + sum + ", " + e + "));\n";
+                o += D + r + " = G::normalize(G::add_lazy(" + sum + ", " + e + "));\n";
                 b += be;
             }
             sum = r;
         };
         auto fold = [&](std::string &sum, double &b, double limit) {
             if (b <= limit) return;
-            const std::string r = "r" + S(tmp++);
-            o += "            const f29_t " + r + " = " + MUL + sum + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
+            const std::string r = X + "r" + S(tmp++);
+            o += D + r + " = " + MUL + sum + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
             sum = r;
             b = 2.0;
         };
@@ -1428,27 +1488,61 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
                     lazy_add(sum, b, e, bj, (t.sign < 0) != negate);
                     fold(sum, b, 12.0);
                 }
-                const std::string r = "r" + S(tmp++);
-                o += "            const f29_t " + r + " = " + MUL + sum + ", G::unpack(U[" + S(t0.coef) + "]));\n";
+                const std::string r = X + "r" + S(tmp++);
+                o += D + r + " = " + MUL + sum + ", G::unpack(U[" + S(t0.coef) + "]));\n";
                 val = r;
                 vb = 2.0;
             }
             lazy_add(total, total_b, val, vb, negate);
             fold(total, total_b, 24.0);
         }
-        if (first) {
-            o += "            sw_store(acc, pt, accumulate ? G::normalize(G::add_lazy(sw_load(acc, pt), " + total + ")) : " + total + ");\n";
+        if (!total.empty() && slope) fold(total, total_b, 2.0);          // the step is added once per point: keep it below 2p
+        return total;
+        };   // gen
+
+        if (!cl.linear) {
+            o += "        for (uint32_t pt = 0; pt < npts; ++pt) {\n";
+            o += "            const fe_t *__restrict__ U = Uall + (size_t)pt * nu; (void)U;\n";
+            double total_b = 0;
+            const std::string total = gen("            ", "", false, total_b);
+            if (first) {
+                o += "            sw_store(acc, pt, accumulate ? G::normalize(G::add_lazy(sw_load(acc, pt), " + total + ")) : " + total + ");\n";
+            } else {
+                o += "            sw_store(acc, pt, G::normalize(G::add_lazy(sw_load(acc, pt), " + total + ")));\n";
+            }
+            acc_bound += total_b;
+            if (acc_bound > 100.0) {                                 // fold the accumulators before they outgrow the 261-bit limbs
+                o += "            sw_store(acc, pt, " + MUL + "sw_load(acc, pt), G::unpack(U[" + S(p.sw_one) + "])));\n";
+                acc_bound = 2.0;
+            }
+            for (int v : cl.loads)
+                if (p.vins[def[v]].op == I_LD_ADV) o += "            l" + S(v) + " = F::add(l" + S(v) + ", s" + S(v) + ");\n";
+            o += "        }\n    }\n";
         } else {
-            o += "            sw_store(acc, pt, G::normalize(G::add_lazy(sw_load(acc, pt), " + total + ")));\n";
+            // value at the first point + slope, then one lazy addition per further point (coefficients do not depend on the point)
+            o += "        const fe_t *__restrict__ U = Uall; (void)U;\n";
+            double vb = 0, sb = 0;
+            std::string val = gen("        ", "v", false, vb);
+            const std::string step = gen("        ", "d", true, sb);
+            if (val.empty()) { val = "G::unpack(F::zero())"; vb = 1.0; }
+            if (vb > 2.0) {
+                o += "        const f29_t vfold = " + MUL + val + ", G::unpack(U[" + S(p.sw_one) + "]));\n";
+                val = "vfold";
+                vb = 2.0;
+            }
+            o += "        f29_t cur = " + val + ";\n";
+            o += "        for (uint32_t pt = 0; pt < npts; ++pt) {\n";
+            if (first) o += "            sw_store(acc, pt, accumulate ? G::normalize(G::add_lazy(sw_load(acc, pt), cur)) : cur);\n";
+            else o += "            sw_store(acc, pt, G::normalize(G::add_lazy(sw_load(acc, pt), cur)));\n";
+            if (!step.empty()) o += "            cur = G::normalize(G::add_lazy(cur, " + step + "));\n";
+            const double worst = vb + (step.empty() ? 0.0 : sb * (double)DMAX);      // cur at the last of <= DMAX + 1 points
+            acc_bound += worst;
+            if (acc_bound > 100.0) {
+                o += "            sw_store(acc, pt, " + MUL + "sw_load(acc, pt), G::unpack(U[" + S(p.sw_one) + "])));\n";
+                acc_bound = 2.0;
+            }
+            o += "        }\n    }\n";
         }
-        acc_bound += total_b;
-        if (acc_bound > 100.0) {                                 // fold the accumulators before they outgrow the 261-bit limbs
-            o += "            sw_store(acc, pt, " + MUL + "sw_load(acc, pt), G::unpack(U[" + S(p.sw_one) + "])));\n";
-            acc_bound = 2.0;
-        }
-        for (int v : cl.loads)
-            if (p.vins[def[v]].op == I_LD_ADV) o += "            l" + S(v) + " = F::add(l" + S(v) + ", s" + S(v) + ");\n";
-        o += "        }\n    }\n";
         first = false;
     }
     o += "}\n";
