@@ -1327,6 +1327,41 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
         }
         std::vector<char> is_load(def.size(), 0);            // column values are unpacked where they are used: a 9-limb copy of
         for (int v : cl.loads) is_load[v] = 1;               // every hoisted column, live across the loop body, spills
+        // Hoisted affine factors (per-point clusters): q * (s * y) with q a fixed / selector column and s an advice leaf is computed as
+        // (q s) * y, and q s is affine in the point -- its value and step cost two products per row, every point one lazy addition
+        // instead of a product.  (The MainGate's q_5 s^5 terms: 3 instead of 4 products per state and point.)
+        struct Hoist { int v, a, b, c, u; };
+        std::vector<Hoist> hoists;
+        std::map<int, size_t> hoist_of;                       // v -> index
+        std::vector<char> hoisted_inner(def.size(), 0);
+        if (!cl.linear && !std::getenv("SRS_SWEEP_NO_HOIST")) {
+            std::vector<int> uses(def.size(), 0);
+            for (int v : cl.body) {
+                const VInsn &in = p.vins[def[v]];
+                if (in.a >= 0) ++uses[in.a];
+                if (in.op <= I_MUL && in.b >= 0) ++uses[in.b];
+            }
+            for (int ti : cl.terms) if (p.sw_terms[ti].node >= 0) ++uses[p.sw_terms[ti].node];
+            auto fixed_leaf = [&](int x) { return x >= 0 && is_load[x] && p.vins[def[x]].op != I_LD_ADV; };
+            auto adv_leaf = [&](int x) { return x >= 0 && is_load[x] && p.vins[def[x]].op == I_LD_ADV; };
+            for (int v : cl.body) {
+                const VInsn &in = p.vins[def[v]];
+                if (in.op != I_MUL) continue;
+                for (int o1 = 0; o1 < 2 && !hoist_of.count(v); ++o1) {
+                    const int a = o1 ? in.b : in.a, u = o1 ? in.a : in.b;
+                    if (!fixed_leaf(a) || u < 0 || is_load[u] || p.vins[def[u]].op != I_MUL || uses[u] != 1 || hoisted_inner[u]) continue;
+                    const VInsn &iu = p.vins[def[u]];
+                    for (int o2 = 0; o2 < 2; ++o2) {
+                        const int b = o2 ? iu.b : iu.a, c = o2 ? iu.a : iu.b;
+                        if (!adv_leaf(b) || c == b) continue;
+                        hoist_of[v] = hoists.size();
+                        hoists.push_back({v, a, b, c, u});
+                        hoisted_inner[u] = 1;
+                        break;
+                    }
+                }
+            }
+        }
         // One evaluation of the cluster's terms.  IN: indentation; X: name prefix of the temporaries; slope: the advice leaves
         // enter with their STEP and the terms without an advice leaf are left out (affine clusters).  -> expression of the lazy
         // sum and its bound in units of p (empty: nothing to add).
@@ -1381,10 +1416,17 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
             }
         }
         for (int v : cl.body) {
-            if (!want[v]) continue;
+            if (!want[v] || hoisted_inner[v]) continue;
             const VInsn &in = p.vins[def[v]];
             const std::string d = D + X + "x" + S(v) + " = ";
             double ba, bb;
+            if (hoist_of.count(v)) {                             // (q s) * y with the affine factor kept in `aff`
+                const Hoist &h = hoists[hoist_of[v]];
+                std::string c = prep(h.c, lvl(h.c), 12.0, bb);
+                o += d + MUL + "aff" + S(v) + ", " + c + ");\n";
+                bound[v] = 2.0;
+                continue;
+            }
             switch (in.op) {
             case I_MUL: {
                 std::string a = prep(in.a, lvl(in.a), 12.0, ba), b = prep(in.b, lvl(in.b), 12.0, bb);      // a uniform operand enters at level 0
@@ -1501,6 +1543,10 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
         };   // gen
 
         if (!cl.linear) {
+            for (const Hoist &h : hoists) {
+                o += "        f29_t aff" + S(h.v) + " = " + MUL + "G::unpack(l" + S(h.a) + "), G::unpack(l" + S(h.b) + "));\n";
+                o += "        const f29_t affs" + S(h.v) + " = npts > 1 ? " + MUL + "G::unpack(l" + S(h.a) + "), G::unpack(s" + S(h.b) + ")) : aff" + S(h.v) + ";\n";
+            }
             o += "        for (uint32_t pt = 0; pt < npts; ++pt) {\n";
             o += "            const fe_t *__restrict__ U = Uall + (size_t)pt * nu; (void)U;\n";
             double total_b = 0;
@@ -1517,6 +1563,8 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
             }
             for (int v : cl.loads)
                 if (p.vins[def[v]].op == I_LD_ADV) o += "            l" + S(v) + " = F::add(l" + S(v) + ", s" + S(v) + ");\n";
+            for (const Hoist &h : hoists)                         // < 2p (1 + points): fine as a multiplier operand (<= 20p * 2p < 165 p^2)
+                o += "            aff" + S(h.v) + " = G::normalize(G::add_lazy(aff" + S(h.v) + ", affs" + S(h.v) + "));\n";
             o += "        }\n    }\n";
         } else {
             // value at the first point + slope, then one lazy addition per further point (coefficients do not depend on the point)
