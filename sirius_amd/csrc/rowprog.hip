@@ -560,13 +560,22 @@ struct LincombArgs {
     fe_t coef[JMAX];
     uint32_t J;
 };
-template <class F>
+// AFFINE: the coefficients sum to one (Lagrange values, the only caller on the hot path: ProtoGalaxy::fold_witness), so
+// sum_j c_j w_j = w_0 + sum_{j>=1} c_j (w_j - w_0): one product less per element, the same field element.
+template <class F, bool AFFINE>
 __global__ void k_lincomb(fe_t *__restrict__ out, LincombArgs a, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        fe_t acc = F::mul(a.coef[0], a.w[0][i]);
-        for (uint32_t j = 1; j < a.J; ++j) acc = F::add(acc, F::mul(a.coef[j], a.w[j][i]));
+        fe_t acc;
+        if (AFFINE) {
+            const fe_t w0 = a.w[0][i];
+            acc = w0;
+            for (uint32_t j = 1; j < a.J; ++j) acc = F::add(acc, F::mul(a.coef[j], F::sub(a.w[j][i], w0)));
+        } else {
+            acc = F::mul(a.coef[0], a.w[0][i]);
+            for (uint32_t j = 1; j < a.J; ++j) acc = F::add(acc, F::mul(a.coef[j], a.w[j][i]));
+        }
         out[i] = acc;
     }
 }
@@ -2647,8 +2656,17 @@ int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, s
         a.coef[j] = j < J ? coefs[j] : Fr::zero();
     }
     uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, 256 * 16);
-    if (field == 0) SRS_LAUNCH((k_lincomb<Fr>), (blocks), (256), 0, st, out, a, n);
-    else SRS_LAUNCH((k_lincomb<Fq>), (blocks), (256), 0, st, out, a, n);
+    FieldOps f{field};
+    fe_t sum = f.zero();
+    for (size_t j = 0; j < J; ++j) sum = f.add(sum, coefs[j]);
+    const bool affine = J >= 2 && f.is_zero(f.sub(sum, f.one()));
+    if (field == 0) {
+        if (affine) SRS_LAUNCH((k_lincomb<Fr, true>), (blocks), (256), 0, st, out, a, n);
+        else SRS_LAUNCH((k_lincomb<Fr, false>), (blocks), (256), 0, st, out, a, n);
+    } else {
+        if (affine) SRS_LAUNCH((k_lincomb<Fq, true>), (blocks), (256), 0, st, out, a, n);
+        else SRS_LAUNCH((k_lincomb<Fq, false>), (blocks), (256), 0, st, out, a, n);
+    }
     return 0;
 }
 
