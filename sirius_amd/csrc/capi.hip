@@ -920,10 +920,11 @@ std::vector<size_t> commit_cuts(size_t n, size_t align) {
     chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
     auto up = [&](size_t x) { return std::min(n, (x + align - 1) / align * align); };
     std::vector<size_t> cut(1, 0);
-    if (!want && chunks < 4 && n >= ((size_t)1 << 19)) {       // 0.5 - 4 M scalars: a quarter first, so that 3/4 of the upload hides behind its MSM
+    static const bool tuned = std::getenv("SRS_COMMIT_CUTS") != nullptr;
+    if (!want && !tuned && chunks < 4 && n >= ((size_t)1 << 19)) {       // 0.5 - 4 M scalars: a quarter first, so that 3/4 of the upload hides behind its MSM
         const size_t c = up(n / 4);
         if (c > 0 && c < n) cut.push_back(c);
-    } else if (want || chunks < 4) {     // equal pieces
+    } else if (want || (chunks < 4 && !tuned)) {     // equal pieces
         const size_t per = up((n + chunks - 1) / chunks);
         for (size_t a = per; a < n; a += per) cut.push_back(a);
     } else {                             // a SHORT first chunk (its upload is the only one nothing overlaps), growing ones after it
