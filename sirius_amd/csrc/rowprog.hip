@@ -2513,22 +2513,12 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
         }
         if (dom->zero_z) { err = "Z(X) must be not equal to 0"; return 4; }
         std::vector<fe_t> kp(count);
-        // the evaluations G(X_i) are independent: spread over a few host threads (8 x 256 Horner steps are ~0.1 ms on one core,
-        // on the critical path between compute_G and the gamma challenge)
-        {
-            const size_t nthr = std::min<size_t>(8, std::max<size_t>(1, count / 32));
-            std::vector<std::thread> pool;
-            auto work = [&](size_t lo, size_t hi) {
-                for (size_t i = lo; i < hi; ++i) {
-                    fe_t gi = Fr::zero();
-                    for (size_t k = nG; k-- > 0;) gi = Fr::add(Fr::mul(gi, dom->xs[i]), polyG_host[k]);   // UnivariatePoly::eval (univariate.rs:67-75), Horner: same value
-                    kp[i] = Fr::mul(Fr::sub(gi, Fr::mul(f_alpha, dom->l0[i])), dom->inv_z[i]);
-                }
-            };
-            const size_t per = (count + nthr - 1) / nthr;
-            for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work, t * per, std::min(count, (t + 1) * per));
-            work(0, std::min(count, per));
-            for (auto &th : pool) th.join();
+        // 256 x (nG Horner steps + 2 products) = ~3 k field products = ~0.1 ms on one core: less than starting helper threads
+        // costs (the r01 / early r02 version spawned 8 std::threads per call: 0.2 ms of the gap after compute_G)
+        for (size_t i = 0; i < count; ++i) {
+            fe_t gi = Fr::zero();
+            for (size_t k = nG; k-- > 0;) gi = Fr::add(Fr::mul(gi, dom->xs[i]), polyG_host[k]);   // UnivariatePoly::eval (univariate.rs:67-75), Horner: same value
+            kp[i] = Fr::mul(Fr::sub(gi, Fr::mul(f_alpha, dom->l0[i])), dom->inv_z[i]);
         }
         SRS_HIP_CHECK(hipMemcpyAsync(d_out, kp.data(), count * sizeof(fe_t), hipMemcpyHostToDevice, st));
         ntt::run(d_out, log_domain_K, count, 1, true, true, st);     // UnivariatePoly::coset_ifft
