@@ -1258,6 +1258,24 @@ static void plan_sweep(Program &p, const FieldOps &f) {
     Program::SweepCluster cur;
     int cost = 0;
     auto load_cost = [&](int v) { return p.vins[B.def[v]].op == I_LD_ADV ? 16 : 8; };
+    // a term q * (s * y) keeps the hoisted affine factor q s and its step in registers across the point loop (emit_sweep_source):
+    // 18 VGPRs, while the fixed leaf q is only needed before the loop
+    static const int hoist_regs = [] { const char *e = std::getenv("SRS_SWEEP_HOIST_COST"); return e ? std::atoi(e) : 10; }();
+    auto hoist_cost = [&](int v) -> int {
+        if (v < 0) return 0;
+        const VInsn &in = p.vins[B.def[v]];
+        if (in.op != I_MUL) return 0;
+        for (int o1 = 0; o1 < 2; ++o1) {
+            const int a = o1 ? in.b : in.a, u = o1 ? in.a : in.b;
+            if (a < 0 || u < 0) continue;
+            const int oa = p.vins[B.def[a]].op, ou = p.vins[B.def[u]].op;
+            if ((oa != I_LD_FIX && oa != I_LD_SEL) || ou != I_MUL) continue;
+            const VInsn &iu = p.vins[B.def[u]];
+            for (int x : {iu.a, iu.b})
+                if (x >= 0 && p.vins[B.def[x]].op == I_LD_ADV) return hoist_regs;
+        }
+        return 0;
+    };
     auto flush = [&]() {
         if (cur.terms.empty()) return;
         std::sort(cur.body.begin(), cur.body.end());
@@ -1279,9 +1297,11 @@ static void plan_sweep(Program &p, const FieldOps &f) {
         B.collect(t.node, seen, body, loads);
         int extra = 0;
         for (int v : loads) if (!in_cluster[v]) extra += load_cost(v);
+        extra += hoist_cost(t.node);
         if (!cur.terms.empty() && cost + extra > SWEEP_LOAD_BUDGET) flush();
         for (int v : loads) if (!in_cluster[v]) { in_cluster[v] = 1; cur.loads.push_back(v); cost += load_cost(v); }
         for (int v : body) if (!in_cluster[v]) { in_cluster[v] = 1; cur.body.push_back(v); }
+        cost += hoist_cost(t.node);
         cur.linear = pass == 1;
         cur.terms.push_back((int)ti);
     }
