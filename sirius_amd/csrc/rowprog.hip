@@ -2154,16 +2154,30 @@ bool pg_sizes(const Structure *S, size_t traces_len, PgSizes &o) {
 // iter_eval_lagrange_poly_for_cyclic_group (src/polynomial/lagrange.rs:50-75), Fr, host
 std::vector<fe_t> lagrange_eval(const fe_t &X, uint32_t log_n) {
     const size_t n = (size_t)1 << log_n;
-    fe_t inv_n = Fr::inv(Fr::from_u64(n));
     fe_t w = ntt::omega(log_n, false);
     fe_t xn1 = Fr::sub(Fr::pow_u64(X, n), Fr::one());
-    std::vector<fe_t> out(n);
-    fe_t value = Fr::one();
+    std::vector<fe_t> out(n), val(n), den(n), pre(n + 1);
+    // one inversion for n and all the X - w^i (Montgomery's trick; a zero difference -- X on the domain -- is left out of the product)
+    fe_t value = Fr::one(), acc = Fr::from_u64(n);
+    pre[0] = acc;
     for (size_t i = 0; i < n; ++i) {
-        fe_t d = Fr::sub(X, value);
-        if (Fr::is_zero(xn1) && Fr::is_zero(d)) out[i] = Fr::one();
-        else out[i] = Fr::mul(Fr::mul(value, inv_n), Fr::mul(xn1, Fr::inv(d)));
+        val[i] = value;
+        den[i] = Fr::sub(X, value);
+        if (!Fr::is_zero(den[i])) acc = Fr::mul(acc, den[i]);
+        pre[i + 1] = acc;
         value = Fr::mul(value, w);
+    }
+    fe_t inv = Fr::inv(acc);
+    std::vector<fe_t> dinv(n);
+    for (size_t i = n; i-- > 0;) {
+        if (Fr::is_zero(den[i])) continue;
+        dinv[i] = Fr::mul(inv, pre[i]);
+        inv = Fr::mul(inv, den[i]);
+    }
+    const fe_t inv_n = inv;                                   // what is left: 1 / n
+    for (size_t i = 0; i < n; ++i) {
+        if (Fr::is_zero(den[i])) out[i] = Fr::is_zero(xn1) ? Fr::one() : Fr::zero();     // xn1 == 0 exactly when X is on the domain
+        else out[i] = Fr::mul(Fr::mul(val[i], inv_n), Fr::mul(xn1, dinv[i]));
     }
     return out;
 }
@@ -2240,7 +2254,8 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     std::vector<std::vector<fe_t>> ch_pt(leaf_pts, std::vector<fe_t>(n_ch ? n_ch : 1, Fr::zero()));
     if (mode == 1) {
         wcoef.resize((size_t)P * J);
-        for (uint32_t p = 0; p < P; ++p) {
+        // integer-point G folds the witnesses by halvings in the kernel: L_j(X_p) is only needed to fold challenges
+        for (uint32_t p = 0; p < P && (!g_int || n_ch); ++p) {
             std::vector<fe_t> L = lagrange_eval(pts[p], (uint32_t)sz.lagrange_domain);
             for (size_t j = 0; j < J; ++j) {
                 wcoef[(size_t)p * J + j] = L[j];

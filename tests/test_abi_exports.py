@@ -46,6 +46,21 @@ def test_host_only_entries():
         assert np.array_equal(S.point_sum(cid, np.zeros((0, 8), np.uint64)), np.zeros(8, np.uint64))
 
 
+def test_lagrange_values_on_and_off_the_domain():
+    """srs_lagrange_eval (host code, one batched inversion): iter_eval_lagrange_poly_for_cyclic_group (src/polynomial/lagrange.rs:50-75)
+    for challenges off the domain, ON the domain (X = w^i: the unit vector, the branch the reference special-cases) and X = 0."""
+    import oracle as O
+    from oracle import pyref as P
+    from sirius_amd import protogalaxy as PG
+    m = lambda v: O.ints_to_mont(O.FR, list(v))
+    for log_n in (0, 1, 2, 4):
+        n = 1 << log_n
+        w = pow(P.FR_ROOT_OF_UNITY, 1 << (P.FR_S - log_n), P.FR) if log_n else 1
+        for X in (0, 1, w, pow(w, n - 1, P.FR), 12345678901234567890, P.FR - 1, 7):
+            got = O.mont_to_ints(O.FR, PG.eval_lagrange_poly_for_cyclic_group(m([X])[0], log_n))
+            assert got == P.eval_lagrange_poly_for_cyclic_group(X, log_n), (log_n, X)
+
+
 def test_async_instance_fold_matches_the_blocking_one():
     """srs_point_lincomb_async / srs_job_wait (host workers): same points as srs_point_lincomb, any wait order, inputs may be
     released right after submission, a job can be waited for once."""
