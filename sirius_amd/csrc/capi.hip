@@ -880,6 +880,9 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
     SRS_HIP_CHECK(hipEventRecord(ck->events[chunks], st));
     SRS_HIP_CHECK(hipStreamWaitEvent(ck->copy_stream, ck->events[chunks], 0));
     std::vector<bool> launched(chunks, false);
+    // every chunk on the 16-bit windows: the chunks fold their buckets into one running set and only the last one is reduced
+    bool fold = chunks > 1 && !std::getenv("SRS_COMMIT_NO_FOLD");
+    for (size_t j = 0; j < chunks; ++j) fold = fold && msm::may_fold(ck->key, (uint32_t)(cut[j + 1] - cut[j]));
     auto upload = [&](size_t j) {
         upload_range(dst, segs, cut[j], cut[j + 1], ck->copy_stream);
         SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
@@ -888,7 +891,8 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
         SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
         const fe_t *ptr = dst + cut[j];
         const uint32_t nn = (uint32_t)(cut[j + 1] - cut[j]), base = (uint32_t)cut[j];
-        launched[j] = msm::enqueue(ck->key, &ptr, &nn, &base, 1, repr == SRS_REPR_MONT, st, (uint32_t)j);
+        const msm::Fold f = !fold ? msm::FOLD_NONE : (j == 0 ? msm::FOLD_FIRST : (j + 1 == chunks ? msm::FOLD_LAST : msm::FOLD_MIDDLE));
+        launched[j] = msm::enqueue(ck->key, &ptr, &nn, &base, 1, repr == SRS_REPR_MONT, st, (uint32_t)j, f);
     };
     // a pageable source makes hipMemcpyAsync block the caller: issue upload j+1 before MSM j so both are in flight either way
     upload(0);
@@ -901,7 +905,7 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
     auto go = [&](auto tag) {
         using C = decltype(tag);
         xyzz_t acc = Ec<C>::identity(), part;
-        for (size_t j = 0; j < chunks; ++j) {
+        for (size_t j = fold ? chunks - 1 : 0; j < chunks; ++j) {          // folded chunks: the last set holds the whole sum
             msm::finish(ck->key, 1, (uint32_t)j, launched[j], &part);
             acc = Ec<C>::add(acc, part);
         }

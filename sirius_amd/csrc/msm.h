@@ -56,6 +56,7 @@ struct Key {
     bool compact_scalars = false;   // world > 1: the scalar vectors handed to run() hold ONLY this rank's stripes, gathered (multi-device keys)
     affine_t *table = nullptr;
     affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (keys of >= 2^WIDE_MIN_KEY_LOG bases; owned by the key: release())
+    xyzz_t *fold_buckets = nullptr;   // running bucket sums of a chunked commit (enqueue(.., fold)); owned by the key
     bool slot_wide[LANDING_SLOTS] = {};       // landing slot -> which pipeline produced it (finish() combines 3 or 4 partial sums)
     Arena arena;              // per-key scratch (grow-only)
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
@@ -87,8 +88,14 @@ void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_
 // base_host == nullptr: the usual prefix); the partial sums land in page-locked slot `slot` in stream order.  After the
 // caller has synchronised the stream, finish() does the host end.  The scratch arena is shared: sets of launches on ONE
 // stream reuse it in stream order; reserve() sizes it up front (growing it later would free memory still in use).
+// `fold`: the sets of a chunked commit share ONE bucket set (the buckets are the digit values, whatever the base offset), and the
+// bucket reduction is linear: a set with FOLD_FIRST / FOLD_MIDDLE only adds its bucket sums into the key's running buckets (no
+// reduction, no result), the FOLD_LAST set adds its own and reduces the total -- one k_rowcol + k_reduce_final + host finish per commit
+// instead of one per chunk.  batch == 1, 16-bit-window sets only (may_fold()).
+enum Fold { FOLD_NONE = 0, FOLD_FIRST = 1, FOLD_MIDDLE = 2, FOLD_LAST = 3 };
+bool may_fold(const Key &k, uint32_t n);     // false when a set of n scalars would take the wide-window pipeline
 bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch, int is_mont,
-             hipStream_t stream, uint32_t slot);
+             hipStream_t stream, uint32_t slot, Fold fold = FOLD_NONE);
 void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host);
 void reserve(Key &k, uint32_t n_max, uint32_t batch);
 

@@ -981,6 +981,23 @@ __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
     if (lane == 0) dst[b] = E29::pack(acc);
 }
 
+// chunked commits: the finished buckets of this set (where k_rowcol would read them) go into the key's running buckets;
+// one thread per bucket.   grid = NBUCKET / 64
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(64, 1)
+    k_bucket_fold(const xyzz_t *__restrict__ buckets, const xyzz_t *__restrict__ ping, const xyzz_t *__restrict__ pong,
+                  const uint32_t *__restrict__ plan, size_t plan_stride, xyzz_t *__restrict__ total, int first) {
+    using E29 = Ec29<C>;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t *hdr = plan + plan_stride - 4;                              // [0] levels run, [1] all buckets single
+    const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping : pong) : buckets;
+    if (first) {
+        total[b] = B[b];
+    } else {
+        total[b] = E29::pack(E29::add(E29::unpack(total[b]), E29::unpack(B[b])));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 5. bucket reduction  S = sum_b (b+1) B_b,  b = hi * RED_COLS + lo
 //    S = RED_COLS * sum_hi hi * R_hi  +  sum_lo (lo+1) * C_lo
@@ -1016,7 +1033,7 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(128, 1)
     k_rowcol(const xyzz_t *__restrict__ buckets, const xyzz_t *__restrict__ ping, size_t ping_stride,
              const xyzz_t *__restrict__ pong, size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride,
-             xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */, const Link *__restrict__ link) {
+             xyzz_t *__restrict__ rc /* [batch][ROWS + COLS] */, const Link *__restrict__ link, int from_buckets) {
     constexpr uint32_t SER = 8;
     __shared__ xyzz_t half[1];
     const uint32_t m = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1024,7 +1041,7 @@ __global__ void SRS_KERNEL_BOUNDS(128, 1)
     const uint32_t *hdr = plan + (size_t)m * plan_stride + plan_stride - 4;   // [0] levels run, [1] all buckets single
     const size_t ping_off = link ? (size_t)link->base[0][m] : (size_t)m * ping_stride;
     const size_t pong_off = link ? (size_t)link->base[1][m] : (size_t)m * pong_stride;
-    const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + ping_off : pong + pong_off) : buckets + (size_t)m * NBUCKET;
+    const xyzz_t *B = (hdr[1] && !from_buckets) ? ((hdr[0] & 1u) ? ping + ping_off : pong + pong_off) : buckets + (size_t)m * NBUCKET;
     using E29 = Ec29<C>;
     xyzz_t *out = rc + (size_t)m * (RED_ROWS + RED_COLS);
     const bool is_row = blockIdx.x < RED_ROWS / 2;
@@ -1280,7 +1297,7 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
 // (page-locked host memory) in stream order.  Returns false when every MSM is empty (nothing was launched).
 template <class C>
 static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch,
-                      int is_mont, hipStream_t stream, uint32_t slot) {
+                      int is_mont, hipStream_t stream, uint32_t slot, Fold fold) {
     uint32_t n_max = 0;
     for (uint32_t m = 0; m < batch; ++m) n_max = std::max(n_max, n_host[m]);
     if (n_max == 0) return false;
@@ -1371,9 +1388,19 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap,
                (const uint32_t *)plan, plan_stride, buckets, no_link);
-    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, batch), (128), 0, stream, (const xyzz_t *)buckets,
+    const xyzz_t *red_from = buckets;
+    int from_buckets = 0;
+    if (fold != FOLD_NONE) {
+        if (!k.fold_buckets) SRS_HIP_CHECK(hipMalloc((void **)&k.fold_buckets, (size_t)NBUCKET * sizeof(xyzz_t)));
+        SRS_LAUNCH((k_bucket_fold<C>), (NBUCKET / 64), (64), 0, stream, (const xyzz_t *)buckets, (const xyzz_t *)ping, (const xyzz_t *)pong,
+                   (const uint32_t *)plan, plan_stride, k.fold_buckets, fold == FOLD_FIRST ? 1 : 0);
+        if (fold != FOLD_LAST) return true;                  // no reduction, no result for this set
+        red_from = k.fold_buckets;
+        from_buckets = 1;
+    }
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, batch), (128), 0, stream, red_from,
                (const xyzz_t *)ping, (size_t)parts0_cap, (const xyzz_t *)pong, (size_t)parts1_cap, (const uint32_t *)plan,
-               plan_stride, rc, no_link);
+               plan_stride, rc, no_link, from_buckets);
     SRS_LAUNCH((k_reduce_final<C>), (3, batch), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_out);
     if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
     xyzz_t *two = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
@@ -1489,7 +1516,7 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), NSEG_W), (FINAL_THREADS), 0, stream, (const xyzz_t *)ping, (size_t)0,
                (const xyzz_t *)pong, (size_t)0, (const uint32_t *)plan, w.plan_stride, buckets, lk);
     SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, NSEG_W), (128), 0, stream, (const xyzz_t *)buckets, (const xyzz_t *)ping, (size_t)0,
-               (const xyzz_t *)pong, (size_t)0, (const uint32_t *)plan, w.plan_stride, rc, lk);
+               (const xyzz_t *)pong, (size_t)0, (const uint32_t *)plan, w.plan_stride, rc, lk, 0);
     SRS_LAUNCH((k_reduce_final<C>), (4, NSEG_W), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_seg);
     SRS_LAUNCH((k_wide_combine<C>), (1), (256), 0, stream, (const xyzz_t *)d_seg, d_out);
     if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
@@ -1530,10 +1557,16 @@ static void finish_t(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_
     }
 }
 
+bool may_fold(const Key &k, uint32_t n) { return !use_wide(k, n, 1); }
+
 bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch, int is_mont,
-             hipStream_t stream, uint32_t slot) {
+             hipStream_t stream, uint32_t slot, Fold fold) {
     if (batch > BATCH_ARGS || slot >= LANDING_SLOTS) {
         set_error("internal: msm::enqueue batch / slot out of range");
+        throw DeviceError{5};
+    }
+    if (fold != FOLD_NONE && (batch != 1 || use_wide(k, n_host[0], 1))) {
+        set_error("internal: msm::enqueue fold needs one 16-bit-window MSM per set");
         throw DeviceError{5};
     }
     if (batch == 1 && use_wide(k, n_host[0], 1)) {
@@ -1541,8 +1574,8 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
         return k.curve == 0 ? enqueue_wide_t<Bn256>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot)
                             : enqueue_wide_t<Grumpkin>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot);
     }
-    return k.curve == 0 ? enqueue_t<Bn256>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot)
-                        : enqueue_t<Grumpkin>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot);
+    return k.curve == 0 ? enqueue_t<Bn256>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold)
+                        : enqueue_t<Grumpkin>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold);
 }
 void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host) {
     if (k.curve == 0) finish_t<Bn256>(k, batch, slot, launched, result_host); else finish_t<Grumpkin>(k, batch, slot, launched, result_host);
@@ -1554,6 +1587,8 @@ void reserve(Key &k, uint32_t n_max, uint32_t batch) {
 void release(Key &k) {
     if (k.table_w) (void)hipFree(k.table_w);
     k.table_w = nullptr;
+    if (k.fold_buckets) (void)hipFree(k.fold_buckets);
+    k.fold_buckets = nullptr;
     if (k.h_result) (void)hipHostFree(k.h_result);
     k.h_result = nullptr;
     k.arena.release();
