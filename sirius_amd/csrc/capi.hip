@@ -924,7 +924,8 @@ std::vector<size_t> commit_cuts(size_t n, size_t align) {
     chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
     auto up = [&](size_t x) { return std::min(n, (x + align - 1) / align * align); };
     std::vector<size_t> cut(1, 0);
-    static const bool tuned = std::getenv("SRS_COMMIT_CUTS") != nullptr;
+    static const bool tuned_env = std::getenv("SRS_COMMIT_CUTS") != nullptr;
+    const bool tuned = tuned_env && n >= ((size_t)1 << 20);     // the tuning switch leaves small commits (support circuit) alone
     if (!want && !tuned && chunks < 4 && n >= ((size_t)1 << 19)) {       // 0.5 - 4 M scalars: a quarter first, so that 3/4 of the upload hides behind its MSM
         const size_t c = up(n / 4);
         if (c > 0 && c < n) cut.push_back(c);
