@@ -81,6 +81,73 @@ void build(Hash &h) {
         for (size_t j = 0; j < h.t; ++j) h.mds[i * h.t + j] = F::inv(F::add(xs[i], ys[j]));
 }
 
+// One row of the MDS product, sum_j a[j] b[j] mod p (t <= 16 terms), with ONE Montgomery reduction: the t double-width products
+// are added up as a 576-bit integer first (4 x 64-bit limbs, 128-bit partial products), then reduced like a single product.  The
+// value is the same field element as the chain of F::add(F::mul(..)) it replaces; 25 of the 40 products of a full round (25 of 28
+// of a partial one) are row products, so a permutation costs ~30 % less host time.
+template <class PP>
+fe_t dot_row(const fe_t *a, const fe_t *b, size_t t) {
+    typedef unsigned __int128 u128;
+    uint64_t P[4];
+    for (int i = 0; i < 4; ++i) P[i] = (uint64_t)PP::p(2 * i) | ((uint64_t)PP::p(2 * i + 1) << 32);
+    uint64_t inv = (uint64_t)PP::INV;                    // -p^-1 mod 2^32 -> mod 2^64 by one Newton step (as Fp::mul does)
+    inv = inv * (2 + P[0] * inv);
+    uint64_t T[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t k = 0; k < t; ++k) {
+        uint64_t A[4], B[4];
+        for (int i = 0; i < 4; ++i) {
+            A[i] = (uint64_t)a[k].v[2 * i] | ((uint64_t)a[k].v[2 * i + 1] << 32);
+            B[i] = (uint64_t)b[k].v[2 * i] | ((uint64_t)b[k].v[2 * i + 1] << 32);
+        }
+        for (int i = 0; i < 4; ++i) {
+            u128 c = 0;
+            for (int j = 0; j < 4; ++j) {
+                c += (u128)A[j] * B[i] + T[i + j];
+                T[i + j] = (uint64_t)c;
+                c >>= 64;
+            }
+            for (int j = i + 4; c && j < 10; ++j) {         // carry into the upper limbs
+                c += T[j];
+                T[j] = (uint64_t)c;
+                c >>= 64;
+            }
+        }
+    }
+    for (int i = 0; i < 4; ++i) {                          // REDC: 4 steps, each clears the lowest live limb
+        const uint64_t m = T[i] * inv;
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) {
+            c += (u128)m * P[j] + T[i + j];
+            T[i + j] = (uint64_t)c;
+            c >>= 64;
+        }
+        for (int j = i + 4; c && j < 10; ++j) {
+            c += T[j];
+            T[j] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    // T[4..9) = (sum + m p) / 2^256 < (16 p^2 + p 2^256) / 2^256 < 5 p: a few conditional subtractions
+    uint64_t R[5] = {T[4], T[5], T[6], T[7], T[8]};
+    for (;;) {
+        uint64_t D[5];
+        u128 bw = 0;
+        for (int i = 0; i < 5; ++i) {
+            const u128 d = (u128)R[i] - (i < 4 ? P[i] : 0) - (uint64_t)bw;
+            D[i] = (uint64_t)d;
+            bw = (d >> 64) ? 1 : 0;
+        }
+        if (bw) break;                                     // R < p
+        for (int i = 0; i < 5; ++i) R[i] = D[i];
+    }
+    fe_t o;
+    for (int i = 0; i < 4; ++i) {
+        o.v[2 * i] = (uint32_t)R[i];
+        o.v[2 * i + 1] = (uint32_t)(R[i] >> 32);
+    }
+    return o;
+}
+
 template <class F>
 void permute(const Hash &h, std::vector<fe_t> &st) {
     const size_t t = h.t, half = h.r_f / 2;
@@ -93,11 +160,7 @@ void permute(const Hash &h, std::vector<fe_t> &st) {
         } else {
             st[0] = pow5(st[0]);
         }
-        for (size_t i = 0; i < t; ++i) {
-            fe_t acc = F::zero();
-            for (size_t j = 0; j < t; ++j) acc = F::add(acc, F::mul(h.mds[i * t + j], st[j]));
-            nx[i] = acc;
-        }
+        for (size_t i = 0; i < t; ++i) nx[i] = dot_row<typename F::Params>(&h.mds[i * t], st.data(), t);
         st.swap(nx);
     }
 }
