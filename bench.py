@@ -528,6 +528,29 @@ def extras_microbench(S, D, ck24, log_n=24, reps=3):
     return out
 
 
+def extras_msm_sharded(S, D, ck, log_n, reps=3):
+    """BASELINE configs[4] on N ranks: the 2^log_n-point MSM over the SHARDED key -- every rank adds up its block-cyclic stripes of the
+    same device-resident vector, the 64-byte partials are all-gathered and summed (inside the timed call).  scalars_per_s at
+    N = 1, 2, 4, 8 is the MSM scaling curve of the north star."""
+    from workloads import rand_fe
+    n = 1 << log_n
+    rng = np.random.default_rng(5)                 # the same vector on every rank
+    out = {"workload": f"2^{log_n}-point MSM (bn256 G1), key and work sharded over {D.world} ranks, device-resident"}
+    for kind in ("uniform", "trace"):
+        d = up(D, rand_fe(rng, n, zero_frac=0.55 if kind == "trace" else 0.0))
+        fn = lambda: D.combine(S.CURVE_BN256, ck.commit(d))
+        fn()
+        D.barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        D.barrier()
+        dt = D.max_over_ranks((time.perf_counter() - t) / reps)
+        out[f"msm_{kind}"] = {"ms": round(dt * 1e3, 3), "scalars_per_s": round(n / dt), "n_gpus": D.world}
+        del d
+    return out
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -612,6 +635,15 @@ def main():
             if D.rank == 0:
                 out["secondary"] = {"sangria_k17": sec_obj, "microbench_2p24": micro}
                 out["host_path_ms_per_step"] = sec_obj["host_path_ms_per_step"]
+        if not args.no_extras and D.world > 1 and (log_key == 24 or D.emu):
+            del pri.accW, pri.inW
+            for hb in pri.host_W:
+                hb.close()
+            if not D.emu:
+                torch.cuda.empty_cache()
+            micro = extras_msm_sharded(S, D, pri.ck, log_key, 3 if not D.emu else 1)
+            if D.rank == 0:
+                out["secondary"] = {"microbench_msm_sharded": micro}
     else:
         k = args.k or 17
         log_key = args.log_key or 21

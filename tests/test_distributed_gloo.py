@@ -215,9 +215,11 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
     assert r1.returncode == 0, r1.stderr[-3000:]
     one = json.loads(r1.stdout.strip().splitlines()[-1])
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                         "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo"] + common,
+                         "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo"] +
+                        [a for a in common if a != "--no-extras"],          # N > 1 secondary object: the sharded MSM microbenchmark
                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     two = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "msm+leaf-shard2"
     assert one["state_digest"] == two["state_digest"]
+    assert two["secondary"]["microbench_msm_sharded"]["msm_uniform"]["n_gpus"] == 2
