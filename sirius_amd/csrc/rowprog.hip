@@ -20,9 +20,7 @@
 #include "rowprog.h"
 #include "ntt.h"
 #include "prof.h"
-#if !defined(SRS_EMU)
 #include "jit.h"
-#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -1038,9 +1036,7 @@ struct Program {
     bool sweep_ok = false;
     uint64_t fingerprint = 0;       // FNV-1a of the SSA program
     int spec_id = -1;               // index into the ahead-of-time specialised kernels, or -1
-#if !defined(SRS_EMU)
     jit::Kernel jit;                // straight-line kernel compiled at structure creation (jit.hip), or empty
-#endif
 };
 
 static uint64_t fingerprint_of(const Program &p) {
@@ -1626,7 +1622,6 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
     return o;
 }
 
-#if !defined(SRS_EMU)
 // the translation unit hiprtc compiles: the emitted program `jit_fn` wrapped in the kernel body the ahead-of-time kernels use
 static std::string jit_translation_unit(const std::string &fn_source, int field, bool has_sweep = false) {
     const std::string fname = field == 0 ? "Fr" : "Fq";
@@ -1637,7 +1632,11 @@ static std::string jit_translation_unit(const std::string &fn_source, int field,
                "bool accumulate) { jit_fn_sweep<" + fname + ">(C, row, npts, U, nu, acc, accumulate); });\n        return;\n    }\n";
     return "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" + fn_source +
            "extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n" + body + "    spec_kernel_body<" + fname +
-           ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname + ">(C, row, pt, U); });\n}\n}\n}\n";
+           ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname + ">(C, row, pt, U); });\n}\n}\n}\n"
+           // the CPU logic emulator (tests/emu/jit_emu.cpp: g++ + dlopen instead of hiprtc) enters through this launcher, which
+           // runs the kernel on the emulator state of the loaded object
+           "#if defined(SRS_EMU)\nextern \"C\" void srs_jit_launch_emu(unsigned blocks, unsigned threads, unsigned smem, const void *a) {\n"
+           "    hipemu::launch(srs::rowprog::srs_jit_rowprog, dim3(blocks), dim3(threads), (size_t)smem, *static_cast<const srs::rowprog::DevArgs *>(a));\n}\n#endif\n";
 }
 
 // Host-only check of the run-time compilation path (no device): a small program in the emitted form -- column loads,
@@ -1676,7 +1675,6 @@ bool jit_selfcheck(size_t *code_bytes, std::string &log) {
     }
     return true;
 }
-#endif
 
 struct Structure {
     int field = 0;
@@ -1858,7 +1856,6 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         for (size_t i = 0; i < lroots.size(); ++i)
             if (!build_program(ast, lroots[i], f, lctx, false, S->lookup_progs[i], err)) { rc = 7; return nullptr; }
     }
-#if !defined(SRS_EMU)
     // ---- no ahead-of-time kernel for this gate set: compile the cross-term program now (jit.hip).  Worth it from 2^14
     //      rows on (one hiprtc compile ~ a second); single-pass degrees only (the kernel body parks d + 1 <= 9 points).
     if (S->cross.spec_id < 0 && S->degree >= 1 && S->degree <= DMAX && !S->cross.insns.empty() && jit::enabled() &&
@@ -1872,7 +1869,6 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         else if (std::getenv("SRS_DEBUG_ROWPROG"))
             std::fprintf(stderr, "rowprog: cross-term program compiled at run time in %.2f s\n", S->cross.jit.compile_seconds);
     }
-#endif
     // ---- device residency: programs, fixed columns, selectors
     rc = 5;
     for (auto &lp : S->lookup_progs) upload_program(lp, *S);
@@ -1916,9 +1912,7 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
 
 void destroy(Structure *S) {
     if (!S) return;
-#if !defined(SRS_EMU)
     jit::release(S->cross.jit);
-#endif
     for (void *p : S->owned) (void)hipFree(p);
     S->arena.release();
     delete S;
@@ -1995,9 +1989,7 @@ int kernel_kind(const Structure *S, int which) {
     if (which == 2) return S->pg_spec_id >= 0 ? 1 : 0;
     const Program &p = which == 0 ? S->cross : S->plain_compressed;
     if (p.spec_id >= 0) return 1;
-#if !defined(SRS_EMU)
     if (p.jit.function) return 2;
-#endif
     return 0;
 }
 
@@ -2008,9 +2000,7 @@ const char *spec_source(Structure *S, int which, uint64_t *fingerprint, int *spe
     buf += emit_sweep_source(p, "spec_fn_sweep", false);  // empty when the program has no sweep form
     if (fingerprint) *fingerprint = p.fingerprint;
     if (spec_id) *spec_id = p.spec_id;
-#if !defined(SRS_EMU)
     if (spec_id && p.spec_id < 0 && p.jit.function) *spec_id = -2;      // compiled at run time
-#endif
     return buf.c_str();
 }
 
@@ -2081,14 +2071,12 @@ static int evaluate_prog(Structure *S, Program &p, int mode, const fe_t *W1_dev,
         a.out = d_out + k0;
         prof::Scope ps(mode == 0 ? "rowprog_cross_terms" : "rowprog_eval", st, S->rows);
         if (p.spec_id >= 0) launch_spec(p.spec_id, S->field, a, st);
-#if !defined(SRS_EMU)
         else if (p.jit.function) {
             if (!jit::launch(p.jit, (a.ctx.local_rows + RP_THREADS - 1) / RP_THREADS, RP_THREADS, p.sweep_ok ? sweep_smem_bytes(a.npts) : 0u, &a, st)) {
                 err = "launch of the run-time compiled row program failed";
                 return 5;
             }
         }
-#endif
         else if (S->field == 0) launch_rowprog<Fr>(a, p.nslots, st); else launch_rowprog<Fq>(a, p.nslots, st);
     }
     if (!sync) return 0;
