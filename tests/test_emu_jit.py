@@ -122,3 +122,16 @@ def test_emu_jit_random_circuits(emu_jit, oracle):
         _check(emu_jit, oracle, rnd.choice([0, 1]), 3, gates, nfix, nadv, seed=attempts, nsel=nsel)
         done += 1
     assert done == 8
+
+
+def test_emu_jit_lookup_structure(emu_jit, oracle):
+    """a structure with lookup arguments: its lookup-extended cross-term program (multi-round witness columns) through the compiled kernel"""
+    from lookup_cases import run_lookup_case
+    run_lookup_case(emu_jit, oracle, "vector", 5)
+    run_lookup_case(emu_jit, oracle, "two", 4)
+
+
+def test_emu_jit_row_sharded(emu_jit, oracle):
+    """the compiled kernel under srs_structure_set_shard: only this rank's row stripes are evaluated"""
+    from test_sangria_gpu import _row_shard_case
+    _row_shard_case(emu_jit, oracle, 1, 1, 12, (2,), 2, with_commit=False)
