@@ -135,3 +135,55 @@ def test_emu_jit_row_sharded(emu_jit, oracle):
     """the compiled kernel under srs_structure_set_shard: only this rank's row stripes are evaluated"""
     from test_sangria_gpu import _row_shard_case
     _row_shard_case(emu_jit, oracle, 1, 1, 12, (2,), 2, with_commit=False)
+
+
+def test_emu_protogalaxy_random_circuits(emu_jit, oracle):
+    """ProtoGalaxy F / G / e of randomly generated gate sets (interpreter leaves: no ahead-of-time kernel exists for them) against the
+    oracle's literal restatement -- sizes, F, betas', G (one incoming trace), K, e."""
+    import random as _r
+    from oracle import expr as OE, protogalaxy as OPG, pyref as P
+    from sirius_amd import protogalaxy as PG
+    from workloads import rand_fe
+    O, S = oracle, emu_jit
+    rnd = _r.Random(77)
+    done = attempts = 0
+    while done < 5 and attempts < 400:
+        attempts += 1
+        nfix, nadv = rnd.randrange(1, 4), rnd.randrange(1, 4)
+        gates = [_random_expr(rnd, 0, nfix, nadv, rnd.randrange(2, 4)) for _ in range(rnd.choice([1, 2]))]
+        if any(g[0] == "const" for g in gates):
+            continue
+        ctx0 = OE.QueryIndexContext(0, nfix, nadv, 0, 0)
+        try:
+            degs = [OE.homogeneous(g, ctx0)[1] for g in gates]
+        except Exception:
+            continue
+        if not all(1 <= d <= 5 for d in degs) or any(_has_challenge(g) for g in gates):
+            continue
+        k = rnd.choice([2, 3])
+        rows = 1 << k
+        rng = np.random.default_rng(attempts)
+        fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
+        Ws = [rand_fe(rng, nadv * rows) for _ in range(2)]
+        St = S.PlonkStructure(0, k, [], fixed, nadv, gates)
+        ctx = PG.PolyContext(St, 1)
+        oS = OPG.Structure(O, list(gates), k, [], fixed, nadv, 0)
+        octx = oS.context(1)
+        betas = OPG.new_accumulator_betas(rnd.randrange(P.FR), ctx.betas_count)
+        delta, alpha = rnd.randrange(P.FR), rnd.randrange(P.FR)
+        m = lambda v: O.ints_to_mont(O.FR, list(v))
+        for compat in (True, False):
+            pF = PG.compute_F(ctx, m(betas), m([delta])[0], Ws[0], reference_compat=compat)
+            assert O.mont_to_ints(O.FR, pF) == OPG.compute_F(oS, octx, betas, delta, Ws[0], [], compat), ("F", gates)
+            bs = OPG.beta_stroke(betas, alpha, delta)
+            pG = PG.compute_G(ctx, m(bs), Ws, reference_compat=compat)
+            assert O.mont_to_ints(O.FR, pG) == OPG.compute_G(oS, octx, bs, Ws, [[] for _ in Ws], compat), ("G", gates)
+            pe = PG.evaluate_e_from_trace(ctx, m(betas), Ws[1], reference_compat=compat)
+            assert O.mont_to_ints(O.FR, pe) == [OPG.evaluate_e_from_trace(oS, octx, betas, Ws[1], [], compat)], ("e", gates)
+        St.close()
+        done += 1
+    assert done == 5
+
+
+def _has_challenge(e):
+    return e[0] == "chal" or any(isinstance(x, tuple) and _has_challenge(x) for x in e[1:])
