@@ -147,7 +147,7 @@ def test_emu_protogalaxy_random_circuits(emu_jit, oracle):
     O, S = oracle, emu_jit
     rnd = _r.Random(77)
     done = attempts = 0
-    while done < 5 and attempts < 400:
+    while done < 8 and attempts < 600:
         attempts += 1
         nfix, nadv = rnd.randrange(1, 4), rnd.randrange(1, 4)
         gates = [_random_expr(rnd, 0, nfix, nadv, rnd.randrange(2, 4)) for _ in range(rnd.choice([1, 2]))]
@@ -158,8 +158,9 @@ def test_emu_protogalaxy_random_circuits(emu_jit, oracle):
             degs = [OE.homogeneous(g, ctx0)[1] for g in gates]
         except Exception:
             continue
-        if not all(1 <= d <= 5 for d in degs) or any(_has_challenge(g) for g in gates):
+        if not all(1 <= d <= 5 for d in degs):
             continue
+        nch = 1 if any(_has_challenge(g) for g in gates) else 0
         k = rnd.choice([2, 3])
         rows = 1 << k
         rng = np.random.default_rng(attempts)
@@ -167,22 +168,24 @@ def test_emu_protogalaxy_random_circuits(emu_jit, oracle):
         Ws = [rand_fe(rng, nadv * rows) for _ in range(2)]
         St = S.PlonkStructure(0, k, [], fixed, nadv, gates)
         ctx = PG.PolyContext(St, 1)
-        oS = OPG.Structure(O, list(gates), k, [], fixed, nadv, 0)
+        oS = OPG.Structure(O, list(gates), k, [], fixed, nadv, nch)
         octx = oS.context(1)
         betas = OPG.new_accumulator_betas(rnd.randrange(P.FR), ctx.betas_count)
         delta, alpha = rnd.randrange(P.FR), rnd.randrange(P.FR)
         m = lambda v: O.ints_to_mont(O.FR, list(v))
+        chs_i = [[rnd.randrange(P.FR) for _ in range(nch)] for _ in range(2)]          # the traces' challenges (folded with L_j(X) in G)
+        chs = [m(c) if nch else np.zeros((0, 4), np.uint64) for c in chs_i]
         for compat in (True, False):
-            pF = PG.compute_F(ctx, m(betas), m([delta])[0], Ws[0], reference_compat=compat)
-            assert O.mont_to_ints(O.FR, pF) == OPG.compute_F(oS, octx, betas, delta, Ws[0], [], compat), ("F", gates)
+            pF = PG.compute_F(ctx, m(betas), m([delta])[0], Ws[0], challenges=chs[0], reference_compat=compat)
+            assert O.mont_to_ints(O.FR, pF) == OPG.compute_F(oS, octx, betas, delta, Ws[0], chs_i[0], compat), ("F", gates)
             bs = OPG.beta_stroke(betas, alpha, delta)
-            pG = PG.compute_G(ctx, m(bs), Ws, reference_compat=compat)
-            assert O.mont_to_ints(O.FR, pG) == OPG.compute_G(oS, octx, bs, Ws, [[] for _ in Ws], compat), ("G", gates)
-            pe = PG.evaluate_e_from_trace(ctx, m(betas), Ws[1], reference_compat=compat)
-            assert O.mont_to_ints(O.FR, pe) == [OPG.evaluate_e_from_trace(oS, octx, betas, Ws[1], [], compat)], ("e", gates)
+            pG = PG.compute_G(ctx, m(bs), Ws, challenges_list=chs, reference_compat=compat)
+            assert O.mont_to_ints(O.FR, pG) == OPG.compute_G(oS, octx, bs, Ws, chs_i, compat), ("G", gates)
+            pe = PG.evaluate_e_from_trace(ctx, m(betas), Ws[1], challenges=chs[1], reference_compat=compat)
+            assert O.mont_to_ints(O.FR, pe) == [OPG.evaluate_e_from_trace(oS, octx, betas, Ws[1], chs_i[1], compat)], ("e", gates)
         St.close()
         done += 1
-    assert done == 5
+    assert done == 8
 
 
 def _has_challenge(e):
