@@ -60,18 +60,43 @@ def parse():
     ap.add_argument("--config", default="cyclefold", choices=["cyclefold", "sangria"])
     ap.add_argument("--k", type=int, default=0, help="log2 rows (default: 20 for cyclefold, 17 for sangria)")
     ap.add_argument("--log-key", type=int, default=0, help="log2 commitment-key length (default: 24 / 21)")
-    ap.add_argument("--leaf-rows", default="true", choices=["true", "compat"],
-                    help="ProtoGalaxy leaf row: its own row (default) or row 0 like the reference (SURVEY.md Q1)")
+    ap.add_argument("--leaf-rows", default="compat", choices=["true", "compat"],
+                    help="ProtoGalaxy leaf row: row 0 like the reference (default: bit-exact with src/plonk/mod.rs:714, SURVEY.md Q1) "
+                         "or the leaf's own row (`true`: the intended computation, reported as secondary.true_leaf_rows by default)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (k=17 Sangria step, 2^24 MSM / NTT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ro-challenge", action="store_true",
-                    help="derive the challenges with the off-circuit Poseidon oracle (host code) instead of seeded constants")
+    ap.add_argument("--challenges", default="poseidon-ro", choices=["poseidon-ro", "seeded"],
+                    help="poseidon-ro (default): every challenge is squeezed from the off-circuit Poseidon oracle over the transcript, as the "
+                         "reference does (protogalaxy/mod.rs:80-133, sangria/mod.rs:162-179); seeded: constants (no oracle on the critical path)")
+    ap.add_argument("--ro-challenge", action="store_true", help="(r02 spelling of --challenges poseidon-ro; now the default)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--emu", action="store_true",
                     help="harness self-test without a GPU: loads the CPU logic emulator (tests/emu, test infrastructure) and keeps "
                          "'device' tensors in host memory; use a tiny --k.  The numbers it prints are meaningless")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU exchange; lets 2 ranks share one GPU in tests)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.ro_challenge = args.challenges == "poseidon-ro" or args.ro_challenge
+    return args
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: launch the N ranks ourselves (one process per GPU, `torch.distributed.run`
+    on 127.0.0.1) and hand the job over to them.  Fails loudly when the node has fewer than N devices."""
+    import socket
+    import subprocess
+    if not args.emu and args.dist_backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (one rank per GPU; no oversubscription)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def host_cpus():
@@ -109,7 +134,7 @@ class Dist:
             else:
                 dist.init_process_group(backend=args.dist_backend)
             self.dist = dist
-        assert self.world == args.gpus or self.world == 1, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
 
     def combine(self, curve, partial):
         if self.world == 1:
@@ -251,9 +276,10 @@ class PgPrimary:
         w = make_structure_inputs("primary", k, seed=0x5349524955530000 + 3)
         self.w, self.k, self.rows = w, k, w["rows"]
         self.S = S.PlonkStructure(0, k, [], w["fixed"], w["num_advice"], w["gates"])
-        # process-per-GPU: the leaves are sharded by the key's row stripes (true leaf rows only: the reference's row-0 quirk pins
-        # every leaf to rank 0's stripe), so F / G / e come out as partial polynomials and the witness upload is 1 / world each
-        self.sharded = D.world > 1 and not compat and ((1 << k) >> 10) % D.world == 0     # row stripes == key stripes of every column
+        # process-per-GPU: the leaves are sharded by the key's row stripes, so F / G / e come out as partial polynomials and the
+        # witness upload is 1 / world each (reference_compat pins every leaf to row 0: that row goes up to every rank as a halo)
+        self.sharded = D.world > 1 and k >= 10 and ((1 << k) >> 10) % D.world == 0        # row stripes == key stripes of every column
+        self.D = D
         if self.sharded:
             self.S.set_shard(D.rank, D.world)
         self.ctx = PG.PolyContext(self.S, 1)
@@ -303,19 +329,24 @@ class PgPrimary:
         """The same prove with the leaves sharded over the ranks: every rank evaluates the tiles of ITS stripes, the partial
         polynomials (33 / 8 coefficients) are all-gathered and added; K, e and the transcript are replicated host work."""
         PG, ctx, m = self.PG, self.ctx, self.m
-        pF = D.sum_field(0, PG.compute_F(ctx, self.betas, delta_m, self.accW, reference_compat=False))
+        pF = D.sum_field(0, PG.compute_F(ctx, self.betas, delta_m, self.accW, reference_compat=self.compat))
         if ro:
             ro.absorb_field(pF)
         alpha_m = ro.squeeze(255, 0) if ro else m([alpha])[0]
         bs = PG.beta_stroke(self.betas, alpha_m, delta_m)
-        pG = D.sum_field(0, PG.compute_G(ctx, bs, [self.accW, self.inW], reference_compat=False))
+        pG = D.sum_field(0, PG.compute_G(ctx, bs, [self.accW, self.inW], reference_compat=self.compat))
         pK = PG.compute_K_from_G(ctx, pG, PG.poly_eval(pF, alpha_m))
         if ro:
             ro.absorb_field(pK)
         gamma_m = ro.squeeze(255, 0) if ro else m([gamma])[0]
         self.e = PG.calculate_e(pF, pK, gamma_m, alpha_m, ctx.lagrange_domain)
         lag = PG.eval_lagrange_poly_for_cyclic_group(gamma_m, ctx.lagrange_domain)
-        self.accW = PG.fold_witness(0, [self.accW, self.inW], lag)     # all rows; the rank only ever reads its own stripes of the result
+        # in place, the rank's stripes only: nothing the rank runs reads another stripe of the accumulator -- except, with the
+        # reference's row-0 leaves, row 0 of every column (+ the first stripe), which every rank folds for itself
+        PG.fold_witness(0, [self.accW, self.inW], lag, out=self.accW, shard=(D.rank, D.world))
+        if self.compat and D.rank != 0:
+            a, b = self.accW.view(-1, self.rows, 4), self.inW.view(-1, self.rows, 4)
+            a[:, 0] = PG.fold_witness(0, [a[:, 0].contiguous(), b[:, 0].contiguous()], lag)
         self.betas = bs
         self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), lag[:2])       # fold_instance
 
@@ -323,7 +354,14 @@ class PgPrimary:
         """generate_plonk_trace -> run_sps_protocol_1: ck.commit(W1) of the NEW witness, host -> HBM inside the call."""
         hb = self.host_W[self.step_no & 1]
         self.step_no += 1
+        if D.world > 1 and not self.sharded:          # stripes of the columns are not key stripes: the whole vector goes up
+            import torch
+            self.inW.copy_(torch.from_numpy(hb.array.view(np.int64)))
+            self.inC = D.combine(S.CURVE_BN256, self.ck.commit(self.inW))
+            return
         self.inC = D.combine(S.CURVE_BN256, self.ck.commit_upload(hb.array, dev_copy=self.inW))
+        if self.sharded:                              # rows the rank's leaf tiles read beyond its stripes (row 0 under reference_compat)
+            self.S.upload_shard_halo(hb.array, self.inW, self.compat)
 
 
 def PGint(fe):
@@ -337,6 +375,27 @@ def cyclefold_step(S, D, pri, sup, ro=False, count=False):
     sup.witness_commit(S, D, True)            # B: support-circuit trace ...
     sup.prove(S, D, ro, count)                #    ... folded into the support accumulator
     pri.witness_commit(S, D)                  # C
+
+
+def build_cyclefold(S, D, k, log_key, compat, ks=15):
+    """The state of a CycleFold chain before its first step: primary ProtoGalaxy accumulator + incoming trace (committed), the
+    support circuit's Sangria accumulator + incoming trace (committed).  Shared by main() and tests/chain_cases.py."""
+    from workloads import make_support_inputs
+    pri = PgPrimary(S, D, k, log_key, compat)
+    sup = SangriaSide(S, D, make_support_inputs(ks, seed=0x5349524955530000 + 4), ks + 2, "support")
+    sup.witness_commit(S, D, False)
+    pri.inC = D.combine(S.CURVE_BN256, pri.ck.commit(pri.inW))
+    return pri, sup, ks
+
+
+def chain_digest(pri, sup):
+    """What the chain has folded so far (the primary's e and instance commitments, the support accumulator's commitments): the
+    same for every --gpus N, and -- with the reference's leaf rows and oracle-derived challenges -- what tests/chain_cases.py
+    recomputes on the CPU oracle."""
+    import hashlib
+    pri.settle(); sup.settle()
+    return hashlib.sha256(b"".join(np.ascontiguousarray(x, dtype=np.uint64).tobytes() for x in
+                                   (pri.e, pri.accC, pri.inC, sup.accCW, sup.accCE, sup.inC))).hexdigest()
 
 
 # ------------------------------------------------------------------------------------------ measurement helpers
@@ -468,13 +527,14 @@ def extras_sangria(S, D, args, k=17, log_key=21, steps=20, warmup=3):
     sec = SangriaSide(S, D, make_structure_inputs("secondary", k, seed=0x5349524955530000 + 3), log_key, "secondary")
     pri.witness_commit(S, D, False)
     sec.witness_commit(S, D, False)
-    sangria_step(S, D, pri, sec, False, count=True)
-    out = {}
+    ro = args.ro_challenge
+    sangria_step(S, D, pri, sec, False, ro, count=True)
+    out = {"challenges": "poseidon-ro" if ro else "seeded"}
     for name, from_host in (("device_resident", False), ("host_witness", True)):
         for _ in range(warmup):
-            sangria_step(S, D, pri, sec, from_host)
+            sangria_step(S, D, pri, sec, from_host, ro)
         S.profile_reset()
-        dt = timed(D, lambda: sangria_step(S, D, pri, sec, from_host), steps, after=lambda: (pri.settle(), sec.settle()))
+        dt = timed(D, lambda: sangria_step(S, D, pri, sec, from_host, ro), steps, after=lambda: (pri.settle(), sec.settle()))
         out[name] = {"fold_steps_per_s": round(steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4)}
         if not from_host:
             nz = sum(nonzero_rows(sd.inW) + sd.nz_terms for sd in (pri, sec))
@@ -554,6 +614,8 @@ def extras_msm_sharded(S, D, ck, log_n, reps=3):
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     import torch
     if args.emu:
         from sirius_amd import _lib
@@ -562,18 +624,13 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     D = Dist(args)
     import sirius_amd as S
-    from workloads import make_support_inputs
 
     out = None
     if args.config == "cyclefold":
         k = args.k or 20
         log_key = args.log_key or 24
         compat = args.leaf_rows == "compat"
-        pri = PgPrimary(S, D, k, log_key, compat)
-        ks = 15 if not args.emu else min(k, 5)
-        sup = SangriaSide(S, D, make_support_inputs(ks, seed=0x5349524955530000 + 4), ks + 2, "support")
-        sup.witness_commit(S, D, False)
-        pri.inC = D.combine(S.CURVE_BN256, pri.ck.commit(pri.inW))
+        pri, sup, ks = build_cyclefold(S, D, k, log_key, compat, 15 if not args.emu else min(k, 5))
         cyclefold_step(S, D, pri, sup, args.ro_challenge, count=True)           # untimed: also counts the non-zero cross-term rows
         for _ in range(args.warmup):
             cyclefold_step(S, D, pri, sup, args.ro_challenge)
@@ -591,12 +648,7 @@ def main():
                 st = S.profile_get(name)
                 if st and st["launches"]:
                     prof[name + "_ms"] = round(st["total_ms"] / st["launches"], 4)
-            import hashlib
-            pri.settle(); sup.settle()
-            # what the chain has folded so far (the primary's e and instance commitments, the support accumulator's commitments): the
-            # same for every --gpus N, which is how the tests compare the sharded step with the single-process one
-            digest = hashlib.sha256(b"".join(np.ascontiguousarray(x, dtype=np.uint64).tobytes() for x in
-                                             (pri.e, pri.accC, pri.inC, sup.accCW, sup.accCE, sup.inC))).hexdigest()
+            digest = chain_digest(pri, sup)
             out = {
                 "metric": "IVC fold-steps/s (CycleFold IVC::next hot path, Poseidon-shaped synthetic trace, 2^k rows)",
                 "value": round(args.steps / dt, 4), "unit": "fold-steps/s", "n_gpus": D.world, "steps": args.steps,
@@ -613,6 +665,17 @@ def main():
                 "witness_upload_bytes_per_step": int(pri.w["num_advice"] * pri.rows * 32 + 3 * sup.rows * 32),
                 "roofline": roof, "kernel_ms": prof, "state_digest": digest,
             }
+            if compat and D.world == 1 and not args.no_extras:
+                # beside the headline: the same step with every leaf at ITS OWN row (what the reference's `index & 2^k` was meant
+                # to be) -- more memory traffic in compute_F / compute_G, everything else identical
+                pri.compat = False
+                for _ in range(min(args.warmup, 2)):
+                    cyclefold_step(S, D, pri, sup, args.ro_challenge)
+                n_true = max(1, min(args.steps, 5))
+                dt_true = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), n_true, after=lambda: (pri.settle(), sup.settle()))
+                pri.compat = True
+                out["true_leaf_rows"] = {"fold_steps_per_s": round(n_true / dt_true, 4), "ms_per_step": round(dt_true / n_true * 1e3, 4),
+                                         "steps": n_true, "note": "--leaf-rows true: leaf i evaluated at row i mod 2^k instead of row 0"}
             if D.world == 1 and not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline_cyclefold(args, pri, sup, compat)
@@ -633,7 +696,7 @@ def main():
             micro = extras_microbench(S, D, ck24) if ck24 is not None else (extras_microbench(S, D, pri.ck, log_key, 1) if D.emu else None)
             S.profile_enable(False)
             if D.rank == 0:
-                out["secondary"] = {"sangria_k17": sec_obj, "microbench_2p24": micro}
+                out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "sangria_k17": sec_obj, "microbench_2p24": micro}
                 out["host_path_ms_per_step"] = sec_obj["host_path_ms_per_step"]
         if not args.no_extras and D.world > 1 and (log_key == 24 or D.emu):
             del pri.accW, pri.inW

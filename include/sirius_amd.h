@@ -238,15 +238,27 @@ void srs_structure_free(srs_structure *S);
 /* Multi-GPU (one process per GPU, keys from srs_ck_create_sharded): with a shard set, srs_cross_terms /
  * srs_commit_cross_terms evaluate the cross terms only on the rows of THIS rank's block-cyclic stripes (2^10 rows each, the
  * stripes of the sharded key) -- the only rows the rank's partial commitment and its part of the error fold read.  Rows of
- * T_out outside those stripes are left untouched (device buffers) / returned as zero (host buffers).  The deciders (srs_eval_gates, srs_is_sat_gates) always cover every row.
- * The ProtoGalaxy sums of a sharded structure (srs_pg_compute_F / _G / srs_pg_evaluate_e) cover the leaves of the rank's stripes only
- * (a 1024-leaf tile of the leaf kernels is a stripe; structures of fewer than 2^10 rows: rank 0 evaluates everything): every rank
- * gets a PARTIAL polynomial / value, the results of all ranks add up (coefficient-wise, e.g. srs_fold_lincomb on host vectors) to
- * the polynomial of the reference.  Row stripes coincide with the key's stripes of every witness column when 2^k / 2^10 is a
- * multiple of `world` (what the sharded srs_commit_upload relies on).  The witness rows of other ranks' stripes are never read (unless reference_compat pins every
- * leaf to row 0, which belongs to rank 0's stripe).  The whole-prove entries (srs_pg_prove, srs_sangria_prove) refuse sharded handles:
- * the challenges depend on the exchanged sums. */
+ * T_out outside those stripes read as ZERO afterwards: device buffers are cleared before the rank's rows are written (do not
+ * accumulate into a pre-filled T_out), host buffers are returned as zero.  The deciders (srs_eval_gates, srs_is_sat_gates)
+ * always cover every row.
+ * The ProtoGalaxy sums of a sharded structure (srs_pg_compute_F / _G / srs_pg_evaluate_e) cover the leaves of the rank's tiles
+ * only (a 1024-leaf tile of the leaf kernels is a stripe; structures of fewer than 2^10 rows: rank 0 evaluates everything):
+ * every rank gets a PARTIAL polynomial / value, the results of all ranks add up (coefficient-wise, e.g. srs_fold_lincomb on
+ * host vectors) to the polynomial of the reference.  The whole-prove entries (srs_pg_prove, srs_sangria_prove) refuse sharded
+ * handles: the challenges depend on the exchanged sums.
+ * WHICH WITNESS ROWS A RANK READS.  With the WHOLE witness resident the sharded calls are correct for any circuit.  After a
+ * sharded srs_commit_upload only the rank's key stripes are resident; that suffices only if ALL of these hold:
+ *   (1) 2^k / 2^10 is a multiple of `world` and k >= 10 (the row stripes of every column are key stripes of the rank);
+ *   (2) every column query of the gates has rotation 0 (a query at (row + rot) leaves the stripe);
+ *   (3) reference_compat = 0 (with reference_compat every ProtoGalaxy leaf reads row 0, rank 0's stripe -- src/plonk/mod.rs:714).
+ * When (2) or (3) fails call srs_structure_upload_shard_halo after the upload: it brings up exactly the missing rows (the
+ * rotation halo around the rank's stripes; row 0 + rotations of every column for reference_compat).  When (1) fails it returns
+ * SRS_ERR_INVALID: upload the whole vector instead (srs_upload). */
 int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world);
+/* witness_host: the n = srs_structure_num_witness_columns * 2^k elements handed to the sharded srs_commit_upload; dev_copy: its
+ * device copy.  No-op for world == 1 and for rotation-free circuits with reference_compat = 0. */
+int srs_structure_upload_shard_halo(const srs_structure *S, const srs_fe *witness_host, srs_fe *dev_copy, size_t n, int reference_compat,
+                                    void *stream);
 size_t srs_structure_num_witness_columns(const srs_structure *S);   /* num_advice + 5 * num_lookups */
 size_t srs_structure_num_cross_terms(const srs_structure *S);   /* d = grouped().len() - 1 */
 size_t srs_structure_num_challenges(const srs_structure *S);    /* PlonkStructure::num_challenges */
@@ -429,6 +441,11 @@ int srs_poly_eval(const srs_fe *coeffs, size_t n, const srs_fe *x, srs_fe *out);
 /* ProtoGalaxy::fold_witness (protogalaxy/mod.rs:176-210): out[i] = sum_{j<J} coefs[j] * W[j][i]  (J <= 4) */
 int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n,
                      int space, void *stream);
+/* The same fold on a process-per-GPU rank: DEVICE vectors; only the elements of the rank's block-cyclic stripes (2^10 elements
+ * each, stripe s belongs to rank s % world -- the key's stripes) of out[0 .. n) are computed and written, everything else is
+ * left as it is.  The rank's own kernels read nothing else of the folded accumulator (see srs_structure_set_shard). */
+int srs_fold_lincomb_sharded(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n, uint32_t rank,
+                             uint32_t world, void *stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,7 @@ def _prototypes():
         "srs_is_sat_permutation": (i32, [vp, vp, i32, vp, C.POINTER(sz)]),
         "srs_is_sat_witness_commit": (i32, [vp, C.POINTER(vp), C.POINTER(sz), sz, vp, vp, sz, vp, i32, vp, C.POINTER(sz), C.POINTER(i32)]),
         "srs_structure_set_shard": (i32, [vp, u32, u32]),
+        "srs_structure_upload_shard_halo": (i32, [vp, vp, vp, sz, i32, vp]),
         "srs_poseidon_new": (i32, [i32, sz, sz, sz, sz, C.POINTER(vp)]),
         "srs_poseidon_free": (None, [vp]),
         "srs_poseidon_reset": (None, [vp]),
@@ -111,6 +112,7 @@ def _prototypes():
         "srs_lagrange_eval": (i32, [vp, u32, vp]),
         "srs_poly_eval": (i32, [vp, sz, vp, vp]),
         "srs_fold_lincomb": (i32, [i32, vp, C.POINTER(vp), vp, sz, sz, i32, vp]),
+        "srs_fold_lincomb_sharded": (i32, [i32, vp, C.POINTER(vp), vp, sz, sz, u32, u32, vp]),
         "srs_ntt": (i32, [i32, vp, sz, i32, i32, i32, vp]),
         "srs_ntt_set_max_radix_bits": (i32, [i32]),
         "srs_ntt_batch": (i32, [i32, vp, sz, sz, sz, i32, i32, i32, vp]),

@@ -1355,6 +1355,55 @@ int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world) {
     rowprog::set_shard(S->s, rank, world);
     return SRS_OK;
 }
+int srs_structure_upload_shard_halo(const srs_structure *S, const srs_fe *witness_host, srs_fe *dev_copy, size_t n, int reference_compat,
+                                    void *stream) {
+    if (!S || !witness_host || !dev_copy) return fail(SRS_ERR_INVALID, "srs_structure_upload_shard_halo: bad argument");
+    const uint32_t world = rowprog::shard_world(S->s), rank = rowprog::shard_rank(S->s), k = rowprog::log_rows(S->s);
+    const size_t rows = rowprog::rows(S->s), cols = rowprog::num_witness_columns(S->s);
+    if (n != rows * cols) return fail(SRS_ERR_INVALID, "srs_structure_upload_shard_halo: n is not num_witness_columns * 2^k");
+    if (world <= 1) return SRS_OK;
+    const size_t SL = (size_t)1 << rowprog::ROW_STRIPE_LOG;
+    if (k < rowprog::ROW_STRIPE_LOG || (rows / SL) % world != 0)
+        return fail(SRS_ERR_INVALID, "srs_structure_upload_shard_halo: 2^k / 2^10 is not a multiple of the world size -- the row stripes of the "
+                                     "columns do not coincide with the key's stripes; upload the whole witness instead");
+    int rc = ensure_device();
+    if (rc) return rc;
+    int32_t lo = 0, hi = 0;
+    rowprog::rotation_range(S->s, &lo, &hi);
+    // rows of ONE column this rank reads beyond its own stripes, as a bitmap over the 2^k rows (k <= 28: at most 32 MiB of bits,
+    // built only when there is a rotation); row r of column c is element c * 2^k + r of the witness
+    std::vector<std::pair<size_t, size_t>> runs;        // [first, last) row intervals to upload, per column
+    auto own = [&](size_t row) { return (row >> rowprog::ROW_STRIPE_LOG) % world == rank; };
+    auto add_row = [&](std::vector<size_t> &v, int64_t r) {
+        const size_t row = (size_t)(((r % (int64_t)rows) + (int64_t)rows) % (int64_t)rows);
+        if (!own(row)) v.push_back(row);
+    };
+    std::vector<size_t> need;
+    if (lo < 0 || hi > 0) {
+        for (size_t s = rank; s < rows / SL; s += world) {
+            for (int64_t r = lo; r < 0; ++r) add_row(need, (int64_t)(s * SL) + r);
+            for (int64_t r = 0; r < hi; ++r) add_row(need, (int64_t)((s + 1) * SL) + r);
+        }
+    }
+    if (reference_compat)
+        for (int64_t r = lo; r <= hi; ++r) add_row(need, r);          // every leaf at row 0 (+ rotations), src/plonk/mod.rs:714
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    for (size_t i = 0; i < need.size();) {
+        size_t j = i + 1;
+        while (j < need.size() && need[j] == need[j - 1] + 1) ++j;
+        runs.emplace_back(need[i], need[j - 1] + 1);
+        i = j;
+    }
+    return guarded([&]() -> int {
+        const fe_t *src = reinterpret_cast<const fe_t *>(witness_host);
+        fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
+        for (auto &r : runs)
+            SRS_HIP_CHECK(hipMemcpy2DAsync(dst + r.first, rows * sizeof(fe_t), src + r.first, rows * sizeof(fe_t), (r.second - r.first) * sizeof(fe_t),
+                                           cols, hipMemcpyHostToDevice, (hipStream_t)stream));
+        return SRS_OK;
+    });
+}
 size_t srs_structure_num_cross_terms(const srs_structure *S) { return S ? rowprog::degree(S->s) : 0; }
 size_t srs_structure_num_challenges(const srs_structure *S) { return S ? rowprog::num_challenges(S->s) : 0; }
 size_t srs_structure_num_witness_columns(const srs_structure *S) { return S ? rowprog::num_witness_columns(S->s) : 0; }
@@ -2135,6 +2184,23 @@ int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_f
             } catch (...) { (void)hipFree(buf); throw; }
             (void)hipFree(buf);
         }
+        SRS_HIP_CHECK(hipGetLastError());
+        return SRS_OK;
+    });
+}
+
+int srs_fold_lincomb_sharded(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n, uint32_t rank,
+                             uint32_t world, void *stream) {
+    if (!valid_field(field) || !coefs || !W || (n && !out) || J == 0 || world == 0 || rank >= world)
+        return fail(SRS_ERR_INVALID, "srs_fold_lincomb_sharded: bad argument");
+    if (n == 0) return SRS_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        std::string err;
+        int erc = rowprog::lincomb(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *const *>(W),
+                                   reinterpret_cast<const fe_t *>(coefs), J, n, (hipStream_t)stream, err, rank, world);
+        if (erc) return fail(erc, "srs_fold_lincomb_sharded: " + err);
         SRS_HIP_CHECK(hipGetLastError());
         return SRS_OK;
     });

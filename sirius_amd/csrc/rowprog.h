@@ -22,6 +22,9 @@ void destroy(Structure *S);
 // multi-GPU: cross terms (mode 0 of evaluate) are computed only on the rows of this rank's block-cyclic stripes
 void set_shard(Structure *S, uint32_t rank, uint32_t world);
 uint32_t shard_world(const Structure *S);
+uint32_t shard_rank(const Structure *S);
+void rotation_range(const Structure *S, int32_t *lo, int32_t *hi);   // min / max rotation over every column query (0, 0: none)
+uint32_t log_rows(const Structure *S);
 size_t degree(const Structure *S);            // homogeneous degree d = number of cross terms
 size_t num_challenges(const Structure *S);    // PlonkStructure::num_challenges
 size_t num_advice(const Structure *S);
@@ -50,7 +53,9 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
            size_t *n_out, std::string &err, const fe_t *g_at_one = nullptr);
 int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t instances_to_fold, uint32_t log_domain_K,
                 hipStream_t st, fe_t *out_host, std::string &err);
-int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err);
+// world > 1: only the elements of rank's block-cyclic stripes (2^10 each) of out[0 .. n) are written
+int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err,
+            uint32_t rank = 0, uint32_t world = 1);
 
 // straight-line C++ of the structure's row program (tools/gen_rowprog_spec.py), its fingerprint and the
 // ahead-of-time kernel it maps to (-1: interpreter)

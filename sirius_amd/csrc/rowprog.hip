@@ -560,11 +560,13 @@ struct LincombArgs {
 };
 // AFFINE: the coefficients sum to one (Lagrange values, the only caller on the hot path: ProtoGalaxy::fold_witness), so
 // sum_j c_j w_j = w_0 + sum_{j>=1} c_j (w_j - w_0): one product less per element, the same field element.
+// world > 1 (process-per-GPU ranks): n counts the elements of THIS rank's block-cyclic stripes; only those are folded.
 template <class F, bool AFFINE>
-__global__ void k_lincomb(fe_t *__restrict__ out, LincombArgs a, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_lincomb(fe_t *__restrict__ out, LincombArgs a, size_t n, uint32_t rank, uint32_t world) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
+    for (; l < n; l += stride) {
+        const size_t i = world <= 1 ? l : ((((l >> ROW_STRIPE_LOG) * world + rank) << ROW_STRIPE_LOG) + (l & ((1u << ROW_STRIPE_LOG) - 1)));
         fe_t acc;
         if (AFFINE) {
             const fe_t w0 = a.w[0][i];
@@ -1703,6 +1705,7 @@ struct Structure {
     Arena arena;
     std::vector<uint8_t> host_stage;   // source of the per-call staging copy (must outlive the asynchronous copy)
     uint32_t shard_rank = 0, shard_world = 1;   // cross terms: evaluate only this rank's row stripes (set_shard)
+    int32_t min_rot = 0, max_rot = 0;           // range of the rotations of every column query in the gates / lookup expressions
 };
 
 static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx &ctx, bool fold_mode, Program &p,
@@ -1800,6 +1803,9 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     if (!parse_gates(gates, gates_words, num_gates, ast, roots, err)) return nullptr;
     if (num_lookups && !parse_gates(lookup_exprs, lookup_words, 2 * num_lookups, ast, lroots, err)) return nullptr;
     if (!num_lookups && has_vector_lookup) { err = "has_vector_lookup without lookups"; return nullptr; }
+    int32_t min_rot = 0, max_rot = 0;
+    for (const Node &nd : ast.n)
+        if (nd.kind == N_POLY) { min_rot = std::min(min_rot, nd.rot); max_rot = std::max(max_rot, nd.rot); }
     if (num_selectors + num_fixed == 0) { err = "Fixed & Selectors can't be empty in one time"; return nullptr; }   // eval.rs:47-54
     // destroy(), not delete: an exception half-way (e.g. hipMalloc of the fixed columns at a large k) must free the device
     // allocations and the run-time compiled module the structure already owns
@@ -1812,6 +1818,8 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     S->num_advice = num_advice;
     S->num_lookups = num_lookups;
     S->has_vector_lookup = has_vector_lookup;
+    S->min_rot = min_rot;
+    S->max_rot = max_rot;
     // ConstraintSystemMetainfo::build: the gate-compression challenge comes after the lookup challenges
     // (r1 [, r2]), i.e. ctx.num_challenges starts at 2 / 1 / 0
     // (src/table/constraint_system_metainfo.rs:81-97) -> CompressedGates::new (src/plonk/mod.rs:84-107)
@@ -1931,6 +1939,9 @@ void set_shard(Structure *S, uint32_t rank, uint32_t world) {
     S->shard_world = world ? world : 1;
 }
 uint32_t shard_world(const Structure *S) { return S->shard_world; }
+uint32_t shard_rank(const Structure *S) { return S->shard_rank; }
+void rotation_range(const Structure *S, int32_t *lo, int32_t *hi) { *lo = S->min_rot; *hi = S->max_rot; }
+uint32_t log_rows(const Structure *S) { return S->k; }
 size_t degree(const Structure *S) { return S->degree; }
 size_t num_challenges(const Structure *S) { return S->s_num_challenges; }
 size_t num_advice(const Structure *S) { return S->num_advice; }
@@ -2659,8 +2670,18 @@ size_t log_derivative_mismatches(Structure *S, const fe_t *W_dev, hipStream_t st
     return bad;
 }
 
-int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err) {
+int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err,
+            uint32_t rank, uint32_t world) {
     if (J == 0 || J > JMAX) { err = "unsupported number of witnesses"; return 4; }
+    if (world > 1) {                           // elements of this rank's stripes (block-cyclic, 2^ROW_STRIPE_LOG each)
+        const size_t SL = (size_t)1 << ROW_STRIPE_LOG, full = n / SL;
+        size_t mine = (full > rank ? (full - rank + world - 1) / world : 0) * SL;
+        if (n % SL && full % world == rank) mine += n % SL;
+        n = mine;
+    } else {
+        rank = 0;
+        world = 1;
+    }
     if (!n) return 0;
     LincombArgs a;
     a.J = (uint32_t)J;
@@ -2674,11 +2695,11 @@ int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, s
     for (size_t j = 0; j < J; ++j) sum = f.add(sum, coefs[j]);
     const bool affine = J >= 2 && f.is_zero(f.sub(sum, f.one()));
     if (field == 0) {
-        if (affine) SRS_LAUNCH((k_lincomb<Fr, true>), (blocks), (256), 0, st, out, a, n);
-        else SRS_LAUNCH((k_lincomb<Fr, false>), (blocks), (256), 0, st, out, a, n);
+        if (affine) SRS_LAUNCH((k_lincomb<Fr, true>), (blocks), (256), 0, st, out, a, n, rank, world);
+        else SRS_LAUNCH((k_lincomb<Fr, false>), (blocks), (256), 0, st, out, a, n, rank, world);
     } else {
-        if (affine) SRS_LAUNCH((k_lincomb<Fq, true>), (blocks), (256), 0, st, out, a, n);
-        else SRS_LAUNCH((k_lincomb<Fq, false>), (blocks), (256), 0, st, out, a, n);
+        if (affine) SRS_LAUNCH((k_lincomb<Fq, true>), (blocks), (256), 0, st, out, a, n, rank, world);
+        else SRS_LAUNCH((k_lincomb<Fq, false>), (blocks), (256), 0, st, out, a, n, rank, world);
     }
     return 0;
 }

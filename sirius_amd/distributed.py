@@ -13,9 +13,9 @@ def all_gather_commitments(curve, partial, group=None, device=None):
     """partial: (8,) or (m, 8) uint64 partial commitment(s) of this rank -> full commitment(s) on every rank."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return partial
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group)      # a group of ONE rank still goes through the collective (and the host sum normalises)
     p = np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1, 8)
     t = torch.from_numpy(p.view(np.int64).copy())
     if device is not None:
@@ -32,7 +32,7 @@ def all_gather_field_sum(field, partial, group=None, device=None):
     ranks, on every rank.  There is no modular-sum reduction op either: all-gather of the raw bytes, sum through the library."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return partial
     from .protogalaxy import fold_witness
     from .field import ints_to_mont

@@ -86,6 +86,13 @@ class PlonkStructure:
         """Multi-GPU: cross terms only on the rows of this rank's key stripes (srs_structure_set_shard)."""
         L.check(L.lib().srs_structure_set_shard(self._h, rank, world))
 
+    def upload_shard_halo(self, witness_host, dev_copy, reference_compat=False):
+        """After a sharded `commit_upload` only this rank's key stripes of the witness are resident: bring up the rows the rank's
+        sharded kernels read beyond them (rotation halo; row 0 of every column for reference_compat) -- srs_structure_upload_shard_halo."""
+        a = np.ascontiguousarray(witness_host, dtype=np.uint64).reshape(-1, 4)
+        dp = dev_copy.data_ptr() if _is_torch(dev_copy) else dev_copy.ctypes.data
+        L.check(L.lib().srs_structure_upload_shard_halo(self._h, a.ctypes.data, dp, a.shape[0], int(bool(reference_compat)), _stream()))
+
     def close(self):
         if getattr(self, "_h", None):
             L.lib().srs_structure_free(self._h)

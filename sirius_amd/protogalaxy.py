@@ -109,14 +109,20 @@ def poly_eval(coeffs, x):
     return out
 
 
-def fold_witness(field, Ws, lagrange_for_gamma):
-    """W' = sum_j L_j(gamma) * W_j   (ProtoGalaxy::fold_witness)."""
+def fold_witness(field, Ws, lagrange_for_gamma, out=None, shard=None):
+    """W' = sum_j L_j(gamma) * W_j   (ProtoGalaxy::fold_witness).  shard = (rank, world): device vectors, only the rank's
+    block-cyclic stripes of `out` are computed (srs_fold_lincomb_sharded; `out` may be one of the inputs)."""
     bufs = [_buf(w, 4) for w in Ws]
     spaces = {b[1] for b in bufs}
     assert len(spaces) == 1 and len({b[2] for b in bufs}) == 1
     coefs = _fe(lagrange_for_gamma)[: len(bufs)].copy()
     wp = (C.c_void_p * len(bufs))(*[b[0] for b in bufs])
-    out = _alloc_like(Ws[0], bufs[0][2])
+    if out is None:
+        out = _alloc_like(Ws[0], bufs[0][2])
+    if shard is not None and shard[1] > 1:
+        L.check(L.lib().srs_fold_lincomb_sharded(field, out.data_ptr() if _is_torch(out) else out.ctypes.data, wp, coefs.ctypes.data,
+                                                 len(bufs), bufs[0][2], shard[0], shard[1], _stream()))
+        return out
     L.check(L.lib().srs_fold_lincomb(field, out.data_ptr() if _is_torch(out) else out.ctypes.data, wp, coefs.ctypes.data,
                                      len(bufs), bufs[0][2], spaces.pop(), _stream()))
     return out

@@ -1,0 +1,85 @@
+"""GPU parity of the chain bench.py's headline times: `CyclefoldIVC::next` hot path with the reference's leaf rows
+(src/plonk/mod.rs:714) and Poseidon-derived challenges (src/nifs/protogalaxy/mod.rs:80-133,400-481;
+src/nifs/sangria/mod.rs:162-179,253-277), several steps, against the same chain recomputed on the CPU oracle
+(tests/chain_cases.py).  Bit-exact: the digest covers e, the folded instance commitments of both circuits and the last
+witness commitments, and every step's challenges depend on all of the previous step."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,log_key,ks,steps", [(10, 14, 8, 2), (12, 16, 9, 3)])
+def test_cyclefold_chain_digest_vs_oracle(srs, oracle, k, log_key, ks, steps):
+    import chain_cases as CC
+    assert CC.product_chain(srs, k, log_key, ks, steps) == CC.oracle_chain(oracle, srs, k, log_key, ks, steps)
+
+
+def test_cyclefold_chain_true_rows_differs(srs, oracle):
+    """the intended leaf rows (`--leaf-rows true`) fold a DIFFERENT chain: the switch is not a no-op"""
+    import chain_cases as CC
+    assert CC.product_chain(srs, 10, 14, 8, 1, compat=False) != CC.product_chain(srs, 10, 14, 8, 1, compat=True)
+
+
+NCCL_WORLD1 = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SRS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SRS_ROOT"], "tests"))
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+import sirius_amd as S
+import oracle as O
+from conftest import seeded_scalars
+from sirius_amd.distributed import all_gather_commitments, all_gather_field_sum
+dev = torch.device("cuda", 0)
+for cid in (0, 1):
+    ck = S.CommitmentKey.setup_synthetic(cid, 3000, seed=3, rank=0, world=1)
+    sc = seeded_scalars(O, cid, 2500, 9, "trace")
+    part = ck.commit(sc)
+    got = all_gather_commitments(cid, part, device=dev)              # RCCL all_gather of the 64 raw bytes, then the host sum
+    assert np.array_equal(got, O.msm(cid, sc, ck.bases()[:2500])), cid
+    batch = all_gather_commitments(cid, np.stack([part, np.zeros(8, np.uint64)]), device=dev)
+    assert np.array_equal(batch[0], part) and not batch[1].any()
+poly = seeded_scalars(O, 0, 33, 5)
+assert np.array_equal(all_gather_field_sum(0, poly, device=dev), poly)    # RCCL all_gather of 33 field elements, summed through the library
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t.item()) == 1.5
+dist.barrier()
+dist.destroy_process_group()
+print("nccl-ok")
+'''
+
+
+def test_rccl_world1_collectives(srs, oracle, tmp_path):
+    """The process-per-GPU exchange on the REAL backend: torch.distributed `nccl` (= RCCL on ROCm) initialised with one rank on
+    the MI355X, partial commitments and partial polynomials sent through the actual all_gather (sirius_amd/distributed.py no
+    longer short-circuits a one-rank group), the max-over-ranks all_reduce and the barrier bench.py uses.  Proves the RCCL
+    load, the int64-view dtype path and the device placement on hardware; world > 1 is covered by the gloo tests."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = str(so.getsockname()[1])
+    script = tmp_path / "nccl_world1.py"
+    script.write_text(NCCL_WORLD1)
+    env = dict(os.environ, SRS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nccl-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_bench_gpus_flag_fails_loudly_without_devices():
+    """`python bench.py --gpus 8` on a one-GPU box must refuse (one rank per GPU), not silently run one process."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    want = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)

@@ -251,6 +251,64 @@ def test_commit_full_size_properties(srs, oracle, cid, n):
     ck.close()
 
 
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def test_commit_config_sizes_vs_oracle(srs, oracle):
+    """BASELINE configs[4] (2^24-point MSM) and configs[2] (12 * 2^20 witness commit, bn256) at FULL size, compared DIRECTLY
+    with the oracle's best_multiexp restatement (src/commitment.rs:81-90) on the key's own bases: the production pipelines --
+    20-bit wide windows from 2^23 scalars, the two-pass scatter, the streamed 6-chunk upload with chunk-folded buckets, a
+    3-shard multi-device key -- at the sizes BASELINE names, not only forced onto small inputs."""
+    O = oracle
+    cid = 0
+    n24 = 1 << 24
+    ck = srs.CommitmentKey.setup_synthetic(cid, n24, seed=11)
+    bases = ck.bases()
+    for kind, seed in (("uniform", 1), ("trace", 2)):                       # configs[4]: wide-window pipeline
+        v = seeded_scalars(O, cid, n24, seed, kind)
+        assert np.array_equal(ck.commit(_dev(v)), O.msm(cid, v, bases)), ("2^24", kind)
+    n = 12 << 20                                                            # configs[2]: the primary witness commit
+    v = seeded_scalars(O, cid, n, 3, "trace")
+    v[1::7] = seeded_scalars(O, cid, (n + 5) // 7, 4, "uniform")[: v[1::7].shape[0]]      # denser than the mixture: every chunk has full-width scalars
+    want = O.msm(cid, v, bases[:n])
+    d = _dev(v)
+    assert np.array_equal(ck.commit(d), want), "12*2^20 commit (device resident)"
+    hb = srs.HostBuffer(n)
+    hb.array[:] = v
+    d.zero_()
+    assert np.array_equal(ck.commit_upload(hb.array, dev_copy=d), want), "12*2^20 commit_upload (page-locked, default chunks)"
+    import torch
+    assert torch.equal(d, _dev(v))
+    assert np.array_equal(ck.commit_upload(v), want), "12*2^20 commit_upload (pageable)"
+    hb.close()
+    ck.close()
+    del d
+    torch.cuda.empty_cache()
+    mk = srs.CommitmentKey.create_multi(cid, bases[:n], 3)                  # scalars partitioned over 3 shards
+    assert np.array_equal(mk.commit(v), want), "12*2^20 commit on a 3-shard key"
+    assert np.array_equal(mk.commit_upload(v), want), "12*2^20 commit_upload on a 3-shard key"
+    mk.close()
+
+
+def test_commit_config_k22_vs_oracle(srs, oracle):
+    """BASELINE configs[3]: the 12 * 2^22 = 50 M-scalar witness commit on a 2^26 key (64 + 52 GiB of window tables), device
+    resident (wide windows) and streamed from host memory (chunks of both pipelines), against the oracle."""
+    import torch
+    O = oracle
+    cid, n = 0, 12 << 22
+    ck = srs.CommitmentKey.setup_synthetic(cid, 1 << 26, seed=12)
+    bases = ck.bases()[:n]
+    v = seeded_scalars(O, cid, n, 5, "trace")
+    want = O.msm(cid, v, bases)
+    del bases
+    d = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    assert np.array_equal(ck.commit_upload(v, dev_copy=d), want), "12*2^22 commit_upload"
+    assert np.array_equal(ck.commit(d), want), "12*2^22 commit (device resident)"
+    ck.close()
+
+
 def test_two_pass_scatter_matches_single_pass(srs, oracle):
     """The MSD two-pass scatter (k_group + k_scatter2, used from 2^24-point MSMs on) against the single-pass one and the
     oracle on sizes the oracle can do: forced through SRS_MSM_SORT (read once per process -> subprocesses)."""

@@ -214,12 +214,23 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
                         timeout=900, cwd=ROOT, env=env)
     assert r1.returncode == 0, r1.stderr[-3000:]
     one = json.loads(r1.stdout.strip().splitlines()[-1])
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                         "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo"] +
+    # no torchrun around it: `bench.py --gpus 2` launches its two ranks itself (spawn_ranks)
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo"] +
                         [a for a in common if a != "--no-extras"],          # N > 1 secondary object: the sharded MSM microbenchmark
-                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env2)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     two = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "msm+leaf-shard2"
     assert one["state_digest"] == two["state_digest"]
+    assert one["config"]["leaf_rows"] == "compat" and one["config"]["challenges"] == "poseidon-ro"      # the headline configuration
     assert two["secondary"]["microbench_msm_sharded"]["msm_uniform"]["n_gpus"] == 2
+    # the intended leaf rows shard the same way
+    r1t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--leaf-rows", "true"] + common, capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    r2t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--leaf-rows", "true"] + common,
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env2)
+    assert r1t.returncode == 0 and r2t.returncode == 0, r2t.stdout[-2000:] + r2t.stderr[-4000:]
+    d1 = json.loads(r1t.stdout.strip().splitlines()[-1])["state_digest"]
+    d2 = json.loads([l for l in r2t.stdout.strip().splitlines() if l.startswith("{")][-1])["state_digest"]
+    assert d1 == d2 and d1 != one["state_digest"]

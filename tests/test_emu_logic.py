@@ -211,6 +211,23 @@ def test_emu_bench_harness():
     assert line["config"]["workload"].startswith("cyclefold_poseidon") and line["cpu_baseline"]["kind"] == "port"
 
 
+def test_emu_chain_digest_vs_oracle():
+    """bench.py's headline chain (reference leaf rows + Poseidon-derived challenges, 2 CycleFold steps) through the emulator's
+    kernel logic == the same chain recomputed on the oracle (tests/chain_cases.py); the GPU version is tests/test_chain_gpu.py."""
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from sirius_amd import _lib\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "import sirius_amd as S, oracle as O, chain_cases as CC\n"
+        "a = CC.product_chain(S, 4, 8, 3, 2, emu=True); b = CC.oracle_chain(O, S, 4, 8, 3, 2)\n"
+        "assert a == b, (a, b)\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_long_level0_parts():
     """msm.hip l0_log_for: 64 gathered additions per level-0 thread (the setting of large MSMs), forced on a small one."""
     import sys

@@ -242,6 +242,7 @@ def test_cyclefold_config_k20_vs_oracle(srs, oracle):
     _config_size_case(srs, oracle, 20, compare_oracle=True)
 
 
-def test_protogalaxy_config_k22_properties(srs, oracle):
-    """BASELINE configs[3] (ProtoGalaxy at k = 22, n = 2^23 leaves) on one GPU: the identities at full size."""
-    _config_size_case(srs, oracle, 22, compare_oracle=False)
+def test_protogalaxy_config_k22_vs_oracle(srs, oracle):
+    """BASELINE configs[3] (ProtoGalaxy at k = 22, n = 2^23 leaves) on one GPU: F / G / e at full size against the CPU oracle
+    (both leaf modes) and the size-independent identities."""
+    _config_size_case(srs, oracle, 22, compare_oracle=True)
