@@ -19,7 +19,8 @@
  *
  * Calls are synchronous from the caller's point of view (the two streaming folds on device-resident
  * operands are stream-ordered instead, see srs_fold_witness) and thread-compatible (distinct handles
- * may be used from distinct threads; the library rebinds the calling thread to the process's GPU).  Errors: int return code + srs_last_error() (thread-local).
+ * may be used from distinct threads; the library rebinds the calling thread to the process's GPU; commits on ONE key handle from several threads are
+ * serialised inside the library -- the key's scratch memory is per handle).  Errors: int return code + srs_last_error() (thread-local).
  * There is NO CPU fallback: without a gfx950 device every compute entry returns SRS_ERR_DEVICE.
  */
 #ifndef SIRIUS_AMD_H
@@ -48,7 +49,8 @@ enum {
     SRS_ERR_LAYOUT = 6,           /* srs_layout_selftest mismatch                                  */
     SRS_ERR_EVAL_INDEX = 7,       /* plonk::eval::Error::*OutOfBoundary (src/plonk/eval.rs:3-25)   */
     SRS_ERR_IO = 8,               /* io::Error from File::open / read_exact / write_all (src/commitment.rs:99-127) */
-    SRS_ERR_INVALID_DATA = 9      /* io::ErrorKind::InvalidData "Wrong file in cache, some ptr out of curve" (:152-158) */
+    SRS_ERR_INVALID_DATA = 9,     /* io::ErrorKind::InvalidData "Wrong file in cache, some ptr out of curve" (:152-158) */
+    SRS_ERR_UNSUPPORTED = 10      /* part of the reference that lives in an un-vendored third-party crate (srs_ck_setup) */
 };
 
 enum { SRS_CURVE_BN256 = 0, SRS_CURVE_GRUMPKIN = 1 };   /* src/lib.rs:29-48 (C1 / C2 of the cycle) */
@@ -97,6 +99,16 @@ int srs_ck_create_sharded(int curve, const srs_affine *bases, size_t len, int sp
  * CommitmentKey::setup (src/commitment.rs:55-79: SHAKE256 + hash_to_curve, the latter inside the
  * un-vendored halo2curves); real keys enter through srs_ck_create (e.g. from the reference's cache file). */
 int srs_ck_setup_synthetic(int curve, size_t len, uint64_t seed, uint32_t rank, uint32_t world, srs_ck **out);
+/* CommitmentKey::setup(k, label) (src/commitment.rs:55-79), the restatable half: chunk i of its uniform byte stream is bytes
+ * [32 i, 32 i + 32) of SHAKE256(label) (`Shake256::default().chain(label).finalize_xof()`, read 32 bytes at a time, :61-67).
+ * Writes chunks first .. first + count - 1 (count * 32 bytes) to `out`.  Host code (FIPS 202 restated in csrc/keygen.hip). */
+int srs_ck_setup_uniform_bytes(const uint8_t *label, size_t label_len, size_t first, size_t count, uint8_t *out);
+/* The other half maps each chunk to a point with halo2curves' `hash_to_curve("from_uniform_bytes")` (:69-71) -- third-party code
+ * outside the reference tree, pulled by an unpinned branch: NOT restated.  Always returns SRS_ERR_UNSUPPORTED (after the
+ * reference's own argument check, k < 32) with a message naming the alternatives: srs_ck_load_file on the reference's cache
+ * file, or srs_ck_create on bases the Rust side generated.  (`par_bridge()` at :69 does not preserve order, so the reference
+ * itself does not reproduce a key's order from the label; the cache file is what pins a key.) */
+int srs_ck_setup(int curve, uint32_t k, const uint8_t *label, size_t label_len, srs_ck **out);
 /* Copies this rank's bases (`srs_ck_local_len` points, window 0 of the table) to host memory. */
 int srs_ck_get_bases(const srs_ck *ck, srs_affine *out);
 size_t srs_ck_local_len(const srs_ck *ck);
@@ -379,7 +391,10 @@ int srs_fold_error(int field, srs_fe *out, const srs_fe *e, const srs_fe *const 
  * ro = NULL *r_io is used as given --, RelaxedPlonkWitness::fold IN PLACE (W1 <- W1 + r W2, E <- E + sum r^k T_k,
  * accumulator.rs:364-404) and the group half of RelaxedPlonkInstance::fold on the library's host workers:
  * folded_commitments[0] = W_commitments[0] + r W_commitments[1], folded_commitments[1] = E_commitment + sum r^k commits[k]
- * (accumulator.rs:201-264), valid after srs_job_wait(jobs[0]) / srs_job_wait(jobs[1]).  `challenges` as in srs_commit_cross_terms. */
+ * (accumulator.rs:201-264), valid after srs_job_wait(jobs[0]) / srs_job_wait(jobs[1]).  `challenges` as in srs_commit_cross_terms.
+ * Failure: every argument check happens before anything is written; a failure after that point is a device failure
+ * (SRS_ERR_DEVICE), after which W1 / E may be partly folded and must be considered lost.  No job is left running on an error
+ * return (a job already queued is waited for). */
 int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, const srs_fe *W2,
                       srs_fe *E, void *stream, srs_fe *r_io, srs_fe *const *T_dev, srs_affine *cross_term_commits,
                       const srs_affine *W_commitments, const srs_affine *E_commitment, srs_affine *folded_commitments, uint64_t *jobs);

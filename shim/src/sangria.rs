@@ -1,0 +1,66 @@
+//! Sangria: `VanillaFS::commit_cross_terms` (sirius src/nifs/sangria/mod.rs:102-158), `RelaxedPlonkWitness::fold`
+//! (src/nifs/sangria/accumulator.rs:364-404), the group half of `RelaxedPlonkInstance::fold` (:201-264).
+use std::ptr;
+
+use crate::commit::GpuKey;
+use crate::sys::*;
+use crate::{check, GpuCurve, ShimError};
+
+/// Device mirror of a `PlonkStructure` (src/plonk/mod.rs:127-157): gates compiled to row programs, fixed columns and selectors in
+/// HBM.  Built once (`PlonkStructure.gpu: OnceCell<GpuStructure>`) from the gates serialised into the header's postfix word stream
+/// (`SRS_EX_*`: a 20-line recursive walk over `Expression<F>`).
+pub struct GpuStructure { pub(crate) raw: *mut srs_structure }
+unsafe impl Send for GpuStructure {}
+
+impl GpuStructure {
+    #[allow(clippy::too_many_arguments)]
+    pub fn create(field: i32, k: u32, selectors: &[Vec<u8>], fixed: &[*const srs_fe], num_advice: usize, gate_words: &[u64], num_gates: usize)
+        -> Result<Self, ShimError> {
+        let sel: Vec<*const u8> = selectors.iter().map(|s| s.as_ptr()).collect();
+        let mut raw: *mut srs_structure = ptr::null_mut();
+        check(unsafe { srs_structure_create(field, k, sel.len(), fixed.len(), num_advice, sel.as_ptr(), fixed.as_ptr(), SRS_SPACE_HOST,
+                                            gate_words.as_ptr(), gate_words.len(), num_gates, &mut raw) })?;
+        Ok(Self { raw })
+    }
+    pub fn num_cross_terms(&self) -> usize { unsafe { srs_structure_num_cross_terms(self.raw) } }
+}
+impl Drop for GpuStructure { fn drop(&mut self) { unsafe { srs_structure_free(self.raw) } } }
+
+/// `commit_cross_terms`: `challenges` = concat_vec!(U1.challenges, [U1.u], U2.challenges, [DEFAULT_u]) (:113-118); W1 / W2 the
+/// round vectors concatenated.  Returns (cross_terms, cross_term_commits); rc 1 / 7 map to the reference's two error variants.
+pub fn commit_cross_terms<C: GpuCurve>(s: &GpuStructure, ck: &GpuKey<C>, w1: &[C::ScalarExt], w2: &[C::ScalarExt], challenges: &[C::ScalarExt],
+                                        row_size: usize) -> Result<(Vec<Box<[C::ScalarExt]>>, Vec<C>), ShimError> {
+    use halo2_proofs::halo2curves::ff::Field;
+    let d = s.num_cross_terms();
+    let mut terms: Vec<Box<[C::ScalarExt]>> = (0..d).map(|_| vec![C::ScalarExt::ZERO; row_size].into_boxed_slice()).collect();
+    let t_ptrs: Vec<*mut srs_fe> = terms.iter_mut().map(|t| t.as_mut_ptr() as *mut srs_fe).collect();
+    let mut commits = vec![C::identity(); d];
+    check(unsafe { srs_commit_cross_terms(s.raw, ck.raw, w1.as_ptr() as *const srs_fe, w2.as_ptr() as *const srs_fe,
+                                          challenges.as_ptr() as *const srs_fe, challenges.len(), SRS_SPACE_HOST, ptr::null_mut(),
+                                          t_ptrs.as_ptr(), commits.as_mut_ptr() as *mut srs_affine) })?;
+    Ok((terms, commits))
+}
+
+/// `RelaxedPlonkWitness::fold`, one round vector: out = w1 + r * w2
+pub fn fold_witness<F: Copy>(field: i32, out: &mut [F], w1: &[F], w2: &[F], r: &F) -> Result<(), ShimError> {
+    assert!(out.len() == w1.len() && w1.len() == w2.len());
+    check(unsafe { srs_fold_witness(field, out.as_mut_ptr() as *mut srs_fe, w1.as_ptr() as *const srs_fe, w2.as_ptr() as *const srs_fe,
+                                    r as *const F as *const srs_fe, out.len(), SRS_SPACE_HOST, ptr::null_mut()) })
+}
+
+/// `RelaxedPlonkWitness::fold`, the error vector: out = e + sum_k r^(k+1) * t[k]
+pub fn fold_error<F: Copy>(field: i32, out: &mut [F], e: &[F], cross_terms: &[Box<[F]>], r: &F) -> Result<(), ShimError> {
+    let tp: Vec<*const srs_fe> = cross_terms.iter().map(|t| t.as_ptr() as *const srs_fe).collect();
+    check(unsafe { srs_fold_error(field, out.as_mut_ptr() as *mut srs_fe, e.as_ptr() as *const srs_fe, tp.as_ptr(), tp.len(),
+                                  r as *const F as *const srs_fe, out.len(), SRS_SPACE_HOST, ptr::null_mut()) })
+}
+
+/// group half of `RelaxedPlonkInstance::fold`: acc + sum_i scalars[i] * points[i]  (host code in the library)
+pub fn point_lincomb<C: GpuCurve>(acc: Option<&C>, points: &[C], scalars: &[C::ScalarExt]) -> Result<C, ShimError> {
+    assert_eq!(points.len(), scalars.len());
+    let mut out = C::identity();
+    check(unsafe { srs_point_lincomb(C::CURVE, acc.map(|a| a as *const C as *const srs_affine).unwrap_or(ptr::null()),
+                                     points.as_ptr() as *const srs_affine, scalars.as_ptr() as *const srs_fe, points.len(), SRS_REPR_MONT,
+                                     &mut out as *mut C as *mut srs_affine) })?;
+    Ok(out)
+}

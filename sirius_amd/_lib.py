@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsirius_amd.so")
 
-OK, ERR_TOO_LONG_INPUT, ERR_NOT_POW2, ERR_K_TOO_LARGE, ERR_INVALID, ERR_DEVICE, ERR_LAYOUT, ERR_EVAL_INDEX, ERR_IO, ERR_INVALID_DATA = range(10)
+OK, ERR_TOO_LONG_INPUT, ERR_NOT_POW2, ERR_K_TOO_LARGE, ERR_INVALID, ERR_DEVICE, ERR_LAYOUT, ERR_EVAL_INDEX, ERR_IO, ERR_INVALID_DATA, ERR_UNSUPPORTED = range(11)
 CURVE_BN256, CURVE_GRUMPKIN = 0, 1
 FIELD_FR, FIELD_FQ = 0, 1
 SPACE_HOST, SPACE_DEVICE = 0, 1
@@ -50,6 +50,8 @@ def _prototypes():
         "srs_ck_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "srs_ck_create_sharded": (i32, [i32, vp, sz, i32, u32, u32, C.POINTER(vp)]),
         "srs_ck_setup_synthetic": (i32, [i32, sz, C.c_uint64, u32, u32, C.POINTER(vp)]),
+        "srs_ck_setup_uniform_bytes": (i32, [C.c_char_p, sz, sz, sz, vp]),
+        "srs_ck_setup": (i32, [i32, u32, C.c_char_p, sz, C.POINTER(vp)]),
         "srs_ck_get_bases": (i32, [vp, vp]),
         "srs_ck_local_len": (sz, [vp]),
         "srs_point_lincomb": (i32, [i32, vp, vp, vp, sz, i32, vp]),

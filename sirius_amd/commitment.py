@@ -68,6 +68,23 @@ class CommitmentKey:
         self._h = h
         return self
 
+    @staticmethod
+    def setup_uniform_bytes(label, first, count):
+        """The 32-byte chunks `first .. first + count` of CommitmentKey::setup's SHAKE256(label) stream (src/commitment.rs:61-67)
+        as a (count, 32) uint8 array."""
+        out = np.zeros((count, 32), dtype=np.uint8)
+        L.check(L.lib().srs_ck_setup_uniform_bytes(bytes(label), len(label), first, count, out.ctypes.data))
+        return out
+
+    @classmethod
+    def setup(cls, curve, k, label):
+        """`CommitmentKey::setup` (src/commitment.rs:55-79): NOT available -- the chunk -> point map is halo2curves'
+        hash_to_curve (third party, unpinned); raises SiriusAmdError(rc = ERR_UNSUPPORTED).  Use load_from_file / __init__."""
+        assert k < 32
+        h = C.c_void_p()
+        L.check(L.lib().srs_ck_setup(curve, k, bytes(label), len(label), C.byref(h)))
+        raise AssertionError("srs_ck_setup returned OK")
+
     @classmethod
     def create_multi(cls, curve, bases, n_devices=0):
         """One process, several GPUs (srs_ck_create_multi): the library spreads the key over `n_devices` shards (0 = all

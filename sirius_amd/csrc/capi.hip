@@ -109,6 +109,10 @@ struct CkShard {
 };
 
 struct srs_ck {
+    // One commit at a time per key handle: the scratch arena, the landing slots, the running buckets of a chunked commit, the copy
+    // stream and the shard workers' job slots are per-handle state.  Calls from several host threads on ONE handle serialise here
+    // (recursive: srs_commit_upload* end in srs_commit); distinct handles run concurrently.
+    std::recursive_mutex mu;
     msm::Key key;       // the key of a single-device handle; for a multi-device handle only curve / global_len are meaningful
     Arena staging;      // H2D staging of host scalars
     hipStream_t copy_stream = nullptr;       // srs_commit_upload: uploads run here, the MSMs on the caller's stream
@@ -394,7 +398,10 @@ int create_multi(int curve, size_t len, int n_devices, Fill fill, srs_ck **out) 
     ck->key.len = 0;
     try {
         for (uint32_t d = 0; d < world; ++d) {
-            std::unique_ptr<CkShard> sh(new CkShard());
+            // the shard joins ck->shards BEFORE anything is allocated for it: a failure below (hipMalloc of a large table, the
+            // fill, build_table) then reaches free_shards through srs_ck_free and releases its table, stream and arena
+            ck->shards.emplace_back(new CkShard());
+            CkShard *sh = ck->shards.back().get();
             sh->device = (home + (int)d) % phys;               // shard 0 on the process's device
             sh->key.curve = curve;
             sh->key.global_len = len;
@@ -410,7 +417,6 @@ int create_multi(int curve, size_t len, int n_devices, Fill fill, srs_ck **out) 
                 fill(*sh);
                 msm::build_table(sh->key, sh->stream);
             }
-            ck->shards.push_back(std::move(sh));
         }
         SRS_HIP_CHECK(hipSetDevice(home));
 #if !defined(SRS_EMU)
@@ -780,6 +786,7 @@ int srs_commit_batch(srs_ck *ck, const srs_fe *const *scalars, const size_t *n, 
                      int repr, void *stream, srs_affine *out) {
     if (!ck || !out || (batch && (!scalars || !n))) return fail(SRS_ERR_INVALID, "srs_commit: bad argument");
     if (batch == 0) return SRS_OK;
+    std::lock_guard<std::recursive_mutex> key_lock(ck->mu);
     for (size_t m = 0; m < batch; ++m) {
         if (n[m] > ck->key.global_len)
             return fail(SRS_ERR_TOO_LONG_INPUT, "Can't commit too long input: input len: " + std::to_string(n[m]) +
@@ -963,6 +970,7 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
                                                 std::to_string(ck->key.global_len));
     int rc = ensure_device();
     if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> key_lock(ck->mu);
     hipStream_t st = (hipStream_t)stream;
     if (ck->shards.empty() && ck->key.world > 1 && n && dev_copy) {
         // sharded (process-per-GPU) key: the rank's kernels -- its partial MSM, its rows of the cross terms, its tiles of the
@@ -1045,6 +1053,7 @@ int srs_commit_upload_columns(srs_ck *ck, const srs_fe *const *columns_host, con
         if (lens[c] && !columns_host[c]) return fail(SRS_ERR_INVALID, "srs_commit_upload_columns: null column");
     int rc = ensure_device();
     if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> key_lock(ck->mu);
     hipStream_t st = (hipStream_t)stream;
     return guarded([&]() -> int {
         std::vector<Seg> segs;
@@ -2153,7 +2162,9 @@ int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_
     rc = srs_point_lincomb_async(curve, &W_commitments[0], &W_commitments[1], reinterpret_cast<const srs_fe *>(&r), 1, SRS_REPR_MONT,
                                  &folded_commitments[0], &jobs[0]);
     if (rc) return rc;
-    return srs_point_lincomb_async(curve, E_commitment, cross_term_commits, rp.data(), d, SRS_REPR_MONT, &folded_commitments[1], &jobs[1]);
+    rc = srs_point_lincomb_async(curve, E_commitment, cross_term_commits, rp.data(), d, SRS_REPR_MONT, &folded_commitments[1], &jobs[1]);
+    if (rc) (void)srs_job_wait(jobs[0]);     // never leave job 0 writing into folded_commitments[0] after an error return
+    return rc;
 }
 
 int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n, int space, void *stream) {

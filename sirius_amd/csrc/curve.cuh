@@ -9,9 +9,7 @@
 // identity is ZZ = 0.  Formulas: EFD shortw/xyzz  madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1.
 #pragma once
 #include "field.cuh"
-#if defined(SRS_EMU)
-#include "hipemu.h"   // CPU logic emulator (tests/emu): quad exchange primitive
-#endif
+#include "lanes.cuh"
 
 namespace srs {
 
@@ -39,27 +37,10 @@ struct Grumpkin {
 // additions on a nearly idle chip; one addition is 14 dependent-or-not modmuls that a single lane issues back to back
 // (~12 us).  Spread over a quad, the 14 products form 4 levels of <= 4 independent products, exchanged with DPP
 // quad_perm moves (register crossbar, no LDS): ~3.5 us per addition for ~20 % more lane-cycles.
-#if defined(SRS_EMU)
 template <int K>
-SRS_D uint32_t quad_bcast_u32(uint32_t v) { return __emu_quad_bcast(v, K); }
-#elif defined(__HIP_DEVICE_COMPILE__)
-template <int K>
-SRS_D uint32_t quad_bcast_u32(uint32_t v) {   // quad_perm:[K,K,K,K]
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xF, 0xF, true);
-}
-#else
-template <int K>
-SRS_D uint32_t quad_bcast_u32(uint32_t v) { return v; }   // host pass of hipcc: never executed
-#endif
-template <int K>
-SRS_D fe_t quad_bcast(const fe_t &x) {
+SRS_D fe_t quad_bcast(const fe_t &x) {        // quad_bcast_words: lanes.cuh
     fe_t o;
-#if defined(SRS_EMU)
-    __emu_quad_bcast8(x.v, K, o.v);
-#else
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o.v[i] = quad_bcast_u32<K>(x.v[i]);
-#endif
+    quad_bcast_words<K, 8>(x.v, o.v);
     return o;
 }
 // operand of the lane's role: value selects limb by limb on by-value arguments.  (A nested ?: over references, or

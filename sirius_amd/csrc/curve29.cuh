@@ -23,12 +23,7 @@ struct xyzz29_t {
 template <int K>
 SRS_D f29_t quad_bcast29(const f29_t &x) {
     f29_t o;
-#if defined(SRS_EMU)
-    __emu_quad_bcast_n(x.v, K, o.v, 9);
-#else
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o.v[i] = quad_bcast_u32<K>(x.v[i]);
-#endif
+    quad_bcast_words<K, 9>(x.v, o.v);
     return o;
 }
 SRS_D f29_t quad_select29(uint32_t q, f29_t a0, f29_t a1, f29_t a2, f29_t a3) {   // BY VALUE (see quad_select)

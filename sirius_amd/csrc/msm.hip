@@ -924,28 +924,14 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
 // 64-lane exchange of an XYZZ point
 __device__ __forceinline__ xyzz_t shfl_down_point(const xyzz_t &p, unsigned delta) {
     xyzz_t o;
-#if defined(SRS_EMU)
-    __emu_shfl_down_bulk128(&p, &o, delta, 64);
-    return o;
-#endif
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
-    uint32_t *d = reinterpret_cast<uint32_t *>(&o);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) d[i] = __shfl_down(s[i], delta, 64);
+    shfl_down_words<32>(reinterpret_cast<const uint32_t *>(&p), reinterpret_cast<uint32_t *>(&o), delta, 64);
     return o;
 }
 
 // 64-lane exchange of a point in 9-limb coordinates (36 words), inside groups of `width` lanes
 __device__ __forceinline__ xyzz29_t shfl_down_point29(const xyzz29_t &p, unsigned delta, int width) {
     xyzz29_t o;
-#if defined(SRS_EMU)
-    __emu_shfl_down_bulk(&p, &o, delta, width, 36);
-    return o;
-#endif
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
-    uint32_t *d = reinterpret_cast<uint32_t *>(&o);
-#pragma unroll
-    for (int i = 0; i < 36; ++i) d[i] = __shfl_down(s[i], delta, width);
+    shfl_down_words<36>(reinterpret_cast<const uint32_t *>(&p), reinterpret_cast<uint32_t *>(&o), delta, width);
     return o;
 }
 
@@ -1014,14 +1000,7 @@ __device__ __forceinline__ void lds_tree_sum(xyzz_t *v, uint32_t n_pow2) {
 // 64-lane exchange of an XYZZ point inside groups of `width` lanes
 __device__ __forceinline__ xyzz_t shfl_down_point_w(const xyzz_t &p, unsigned delta, int width) {
     xyzz_t o;
-#if defined(SRS_EMU)
-    __emu_shfl_down_bulk128(&p, &o, delta, width);
-    return o;
-#endif
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(&p);
-    uint32_t *d = reinterpret_cast<uint32_t *>(&o);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) d[i] = __shfl_down(s[i], delta, width);
+    shfl_down_words<32>(reinterpret_cast<const uint32_t *>(&p), reinterpret_cast<uint32_t *>(&o), delta, width);
     return o;
 }
 

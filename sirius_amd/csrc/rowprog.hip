@@ -1634,11 +1634,7 @@ static std::string jit_translation_unit(const std::string &fn_source, int field,
                "bool accumulate) { jit_fn_sweep<" + fname + ">(C, row, npts, U, nu, acc, accumulate); });\n        return;\n    }\n";
     return "#include \"rowprog_dev.cuh\"\nnamespace srs {\nnamespace rowprog {\n" + fn_source +
            "extern \"C\" __global__ void __launch_bounds__(128, 2) srs_jit_rowprog(DevArgs A) {\n" + body + "    spec_kernel_body<" + fname +
-           ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname + ">(C, row, pt, U); });\n}\n}\n}\n"
-           // the CPU logic emulator (tests/emu/jit_emu.cpp: g++ + dlopen instead of hiprtc) enters through this launcher, which
-           // runs the kernel on the emulator state of the loaded object
-           "#if defined(SRS_EMU)\nextern \"C\" void srs_jit_launch_emu(unsigned blocks, unsigned threads, unsigned smem, const void *a) {\n"
-           "    hipemu::launch(srs::rowprog::srs_jit_rowprog, dim3(blocks), dim3(threads), (size_t)smem, *static_cast<const srs::rowprog::DevArgs *>(a));\n}\n#endif\n";
+           ">(A, [](const RowCtx &C, uint32_t row, uint32_t pt, const fe_t *U) { return jit_fn<" + fname + ">(C, row, pt, U); });\n}\n}\n}\n";
 }
 
 // Host-only check of the run-time compilation path (no device): a small program in the emitted form -- column loads,

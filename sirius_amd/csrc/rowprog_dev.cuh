@@ -3,9 +3,7 @@
 #pragma once
 #include "field.cuh"
 #include "field29.cuh"
-#if defined(SRS_EMU)
-#include "hipemu.h"   // CPU logic emulator (tests/emu)
-#endif
+#include "lanes.cuh"      // SRS_SWEEP_ACC
 
 namespace srs {
 namespace rowprog {
@@ -173,11 +171,6 @@ constexpr uint32_t SW_WORDS = 9;
 // The accumulators are DYNAMIC shared memory, sized by the launch for the points actually evaluated (sweep_smem_bytes): at
 // 9 points they are 41.5 KB and only three workgroups fit a CU; the cross terms of the benchmark circuits have 6 - 7.
 SRS_HD constexpr uint32_t sweep_smem_bytes(uint32_t npts) { return npts * SW_WORDS * RP_THREADS * 4u; }
-#if defined(SRS_EMU)
-#define SRS_SWEEP_ACC(name) static thread_local uint32_t name[(DMAX + 1) * SW_WORDS * RP_THREADS]
-#else
-#define SRS_SWEEP_ACC(name) extern __shared__ uint32_t name[]
-#endif
 __device__ __forceinline__ f29_t sw_load(const uint32_t *acc, uint32_t pt) {
     f29_t o;
 #pragma unroll

@@ -23,7 +23,12 @@ static bool build(const std::string &source, const std::string &out_so, bool syn
     static std::atomic<int> seq{0};
     const std::string base = "/tmp/srs_emu_jit_" + std::to_string((long)getpid()) + "_" + std::to_string(seq++);
     const std::string src = base + ".cpp", errf = base + ".err";
-    if (FILE *f = std::fopen(src.c_str(), "wb")) { std::fwrite(source.data(), 1, source.size(), f); std::fclose(f); }
+    // the emitted unit defines the kernel srs_jit_rowprog; the emulator enters it through this launcher (the product never sees it)
+    static const char kLauncher[] =
+        "\nextern \"C\" void srs_jit_launch_emu(unsigned blocks, unsigned threads, unsigned smem, const void *a) {\n"
+        "    hipemu::launch(srs::rowprog::srs_jit_rowprog, dim3(blocks), dim3(threads), (size_t)smem, *static_cast<const srs::rowprog::DevArgs *>(a));\n}\n";
+    const std::string unit = source + kLauncher;
+    if (FILE *f = std::fopen(src.c_str(), "wb")) { std::fwrite(unit.data(), 1, unit.size(), f); std::fclose(f); }
     else { log = "cannot write " + src; return false; }
     const std::string cmd = std::string("g++ -std=c++20 -O1 -fPIC -DSRS_EMU -I" SRS_EMU_INC1 " -I" SRS_EMU_INC2
                                         " -pthread -Wno-unknown-pragmas -Wno-attributes ") +

@@ -163,3 +163,12 @@ def test_no_device_fails_loudly():
     with pytest.raises(S.SiriusAmdError) as e:
         S.CommitmentKey(0, O.make_bases(0, 1, 4))
     assert e.value.rc == 5
+
+
+def test_host_group_entries_vs_eip196(oracle):
+    """The library's HOST group arithmetic (srs_point_sum / srs_point_mul / srs_point_lincomb: the instance folds of
+    RelaxedPlonkInstance::fold, accumulator.rs:201-264) against the EIP-196 known answers.  No device needed."""
+    import eip196_cases as E
+    import sirius_amd as S
+    E.check_adder(oracle, lambda a, b: S.point_sum(0, np.stack([a, b])), lambda k, p: S.point_mul(0, k, p),
+                  lambda s, b: S.point_lincomb(0, None, b, s))

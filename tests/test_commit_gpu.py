@@ -570,3 +570,18 @@ def _concat_cases(S, O, cid, make_dev, k=11):
 def test_concatenate_with_padding_and_column_commit(srs, oracle, cid):
     import torch
     _concat_cases(srs, oracle, cid, lambda n: torch.full((n, 4), 7, dtype=torch.int64, device="cuda"))
+
+
+def test_commit_vs_eip196_known_answers(srs, oracle):
+    """CommitmentKey::commit on the device (n = 1, 2: ecMul / ecAdd as MSMs over keys made of the vectors' points) and the
+    host group entries against the EIP-196 known answers -- an authority outside this repository for the bn256 arithmetic
+    every MSM kernel is built from (9 x 29-bit mixed / full additions, doublings through equal points, the identity)."""
+    import eip196_cases as E
+
+    def msm(scalars, bases):
+        ck = srs.CommitmentKey(0, bases)
+        try:
+            return ck.commit(np.ascontiguousarray(scalars))
+        finally:
+            ck.close()
+    E.check_adder(oracle, lambda a, b: srs.point_sum(0, np.stack([a, b])), lambda k, p: srs.point_mul(0, k, p), msm)

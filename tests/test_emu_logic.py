@@ -211,6 +211,39 @@ def test_emu_bench_harness():
     assert line["config"]["workload"].startswith("cyclefold_poseidon") and line["cpu_baseline"]["kind"] == "port"
 
 
+def test_emu_commit_vs_eip196():
+    """the MSM kernel logic (emulator) on the EIP-196 known answers: ecAdd / ecMul as 1- and 2-term commitments"""
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from sirius_amd import _lib\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "import sirius_amd as S, oracle as O, eip196_cases as E\n"
+        "def msm(s, b):\n"
+        "    ck = S.CommitmentKey(0, b); out = ck.commit(np.ascontiguousarray(s)); ck.close(); return out\n"
+        "E.check_adder(O, lambda a, b: S.point_sum(0, np.stack([a, b])), lambda k, p: S.point_mul(0, k, p), msm)\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_emu_non_contiguous_and_int64_inputs():
+    """strided views / int64 arrays through RelaxedPlonkWitness.fold, lookup_coeff_2, batch_invert_assigned (tests/input_forms_cases.py)"""
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from sirius_amd import _lib\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "import sirius_amd as S, oracle as O\n"
+        "from input_forms_cases import run_input_forms_case\n"
+        "run_input_forms_case(S, O, 0, 700, 4); run_input_forms_case(S, O, 1, 300, 2)\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_chain_digest_vs_oracle():
     """bench.py's headline chain (reference leaf rows + Poseidon-derived challenges, 2 CycleFold steps) through the emulator's
     kernel logic == the same chain recomputed on the oracle (tests/chain_cases.py); the GPU version is tests/test_chain_gpu.py."""

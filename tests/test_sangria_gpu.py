@@ -399,3 +399,11 @@ def test_row_sharded_cross_terms(srs, oracle):
     _row_shard_case(srs, oracle, 0, 0, 13, (5, 3), 2)       # ahead-of-time kernel
     _row_shard_case(srs, oracle, 1, 1, 12, (3, 2), 3)       # interpreter, world not a power of two
     _row_shard_case(srs, oracle, 1, 1, 14, (2, 2), 4)       # run-time compiled kernel
+
+
+def test_non_contiguous_and_int64_inputs(srs, oracle):
+    """ADVICE r01 / r02 regression: strided views and int64-typed host arrays through RelaxedPlonkWitness.fold, lookup_coeff_2 and
+    batch_invert_assigned -- the converted temporaries must outlive the C call (tests/input_forms_cases.py)."""
+    from input_forms_cases import run_input_forms_case
+    run_input_forms_case(srs, oracle, 0, 3000, 12)
+    run_input_forms_case(srs, oracle, 1, 1000, 4)
