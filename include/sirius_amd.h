@@ -331,6 +331,11 @@ void srs_poseidon_reset(srs_poseidon *H);   /* forget everything absorbed (a fre
 int srs_poseidon_absorb_field(srs_poseidon *H, const srs_fe *v, size_t n);
 int srs_poseidon_absorb_point(srs_poseidon *H, int curve, const srs_affine *p);
 int srs_poseidon_squeeze(srs_poseidon *H, size_t num_bits, int out_field, srs_fe *out);
+/* The same squeeze with the sponge run ON THE DEVICE (one wavefront: lanes = state elements / MDS products, the 9 x 29-bit
+ * multiplier).  Same value as srs_poseidon_squeeze; T <= 8.  A permutation is a chain of dependent products, so this is SLOWER
+ * than the host code (measured: DESIGN.md 4.8, profiles/r03_poseidon_device_vs_host.txt) -- it exists so that the comparison is
+ * a measurement; the proves use the host sponge.  *kernel_ms (optional) receives the kernel's HIP-event time. */
+int srs_poseidon_squeeze_device(srs_poseidon *H, size_t num_bits, int out_field, srs_fe *out, double *kernel_ms);
 
 /* ---- deciders: permutation (copy-constraint) check and witness-commitment check ----
  * srs_sparse = the reference's SparseMatrix<F> = Vec<(row, col, value)> (src/polynomial/sparse.rs:5) of an n x n matrix,

@@ -92,6 +92,7 @@ def _prototypes():
         "srs_poseidon_absorb_field": (i32, [vp, vp, sz]),
         "srs_poseidon_absorb_point": (i32, [vp, i32, vp]),
         "srs_poseidon_squeeze": (i32, [vp, sz, i32, vp]),
+        "srs_poseidon_squeeze_device": (i32, [vp, sz, i32, vp, C.POINTER(C.c_double)]),
         "srs_batch_invert_assigned": (i32, [i32, vp, vp, vp, sz, i32, vp, vp]),
         "srs_structure_free": (None, [vp]),
         "srs_structure_num_cross_terms": (sz, [vp]),

@@ -1631,6 +1631,19 @@ int srs_poseidon_squeeze(srs_poseidon *H, size_t num_bits, int out_field, srs_fe
         return SRS_OK;
     });
 }
+int srs_poseidon_squeeze_device(srs_poseidon *H, size_t num_bits, int out_field, srs_fe *out, double *kernel_ms) {
+    if (!H || !out || !valid_field(out_field)) return fail(SRS_ERR_INVALID, "srs_poseidon_squeeze_device: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        std::string err;
+        fe_t o;
+        if (!poseidon::squeeze_device(*H->h, num_bits, out_field, o, kernel_ms, err))
+            return fail(SRS_ERR_INVALID, "srs_poseidon_squeeze_device: " + err);
+        std::memcpy(out, &o, 32);
+        return SRS_OK;
+    });
+}
 
 // ------------------------------------------------------------------ deciders
 int srs_sparse_create(int field, size_t n, const uint64_t *rows, const uint64_t *cols, const srs_fe *values, size_t nnz, srs_sparse **out) {

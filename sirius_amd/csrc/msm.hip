@@ -875,7 +875,7 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum1(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
              size_t plan_stride, int level, xyzz_t *__restrict__ out, size_t out_stride, uint32_t l1,
-             const Link *__restrict__ link) {
+             const Link *__restrict__ link, uint32_t quad_max) {
     uint32_t m = blockIdx.y;
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t t;
@@ -883,7 +883,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     size_t in_off, out_off;
     if (link) {                                // wide windows: flat thread space of this level over the segments
         const uint32_t n_all = link->base[level][NSEG_W];
-        quad = n_all <= ACC1_QUAD_MAX;
+        quad = n_all <= quad_max;
         t = quad ? (lin >> 2) : lin;
         if (t >= n_all) return;
         m = link_segment(link->base[level], t);
@@ -899,7 +899,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     const uint32_t *tp = tp_prev + (NBUCKET + 1);
     const uint32_t n_out = tp[NBUCKET];
     if (!link) {
-        quad = (uint64_t)n_out * gridDim.y <= ACC1_QUAD_MAX;   // whole batch: latency-bound only while the chip is not full
+        quad = (uint64_t)n_out * gridDim.y <= quad_max;   // whole batch: latency-bound only while the chip is not full
         t = quad ? (lin >> 2) : lin;
     }
     if (t >= n_out) return;                    // in quad mode the 4 lanes of a quad leave together
@@ -1230,6 +1230,18 @@ static uint32_t l0_log_for(uint64_t M) {
     return lg;
 }
 
+// k_accum1 gives every output to a quad of lanes while a level has at most this many outputs (x batch): a level that cannot
+// fill the chip's 2^17.6 resident lanes is a chain of dependent additions, and a quad shortens each by 3.3x for 1.3x the
+// lane-cycles.  SRS_MSM_QUAD_MAX=<log2> overrides (A/B).
+static uint32_t acc1_quad_max() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("SRS_MSM_QUAD_MAX");
+        const int lg = e ? std::atoi(e) : 0;
+        return (lg >= 1 && lg <= 24) ? (1u << lg) : ACC1_QUAD_MAX;
+    }();
+    return v;
+}
+
 static int levels_for(uint64_t max_entries) {
     const uint64_t ACC_L0 = 1ull << l0_log_for(max_entries);
     uint64_t parts = (max_entries + ACC_L0 - 1) / ACC_L0;
@@ -1355,9 +1367,9 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     uint64_t cap = parts0_cap;
     for (int level = 1; level < levels; ++level) {
         cap = cap / ACC_L1 + NBUCKET + 1;
-        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, ACC1_QUAD_MAX)), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                    (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, level, nxt, nxt_stride,
-                   (uint32_t)ACC_L1, no_link);
+                   (uint32_t)ACC_L1, no_link, acc1_quad_max());
         std::swap(cur, nxt);
         std::swap(cur_stride, nxt_stride);
         // both buffers can hold any later level: parts shrink monotonically and pong >= level-1 cap
@@ -1488,8 +1500,9 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     uint64_t cap = w.parts0_cap;
     for (int level = 1; level < w.levels; ++level) {
         cap = cap / ACC_L1 + (uint64_t)NSEG_W * (NBUCKET + 1);
-        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, ACC1_QUAD_MAX)), ACC_THREADS)), (ACC_THREADS), 0,
-                   stream, (const xyzz_t *)cur, (size_t)0, (const uint32_t *)plan, w.plan_stride, level, nxt, (size_t)0, (uint32_t)ACC_L1, lk);
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS)), (ACC_THREADS), 0,
+                   stream, (const xyzz_t *)cur, (size_t)0, (const uint32_t *)plan, w.plan_stride, level, nxt, (size_t)0, (uint32_t)ACC_L1, lk,
+                   acc1_quad_max());
         std::swap(cur, nxt);
     }
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), NSEG_W), (FINAL_THREADS), 0, stream, (const xyzz_t *)ping, (size_t)0,

@@ -17,8 +17,10 @@
 //     reversal so the result lands in natural order; ifft's n^-1 is folded into the first table.
 //     Physical traffic = P x 64 B/element (+32 B for the first-pass table), P = number of passes.
 #include "ntt.h"
+#include "field29.cuh"
 #include "prof.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -32,6 +34,16 @@ constexpr uint32_t COLS = 1u << COLS_LOG;   // neighbouring columns per tile: 25
 constexpr uint32_t SMALL_LOG = 10; // single-workgroup path up to 2^10 points
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// The butterfly multiplier.  M29 = false: field.cuh's 8 x 32-bit CIOS (405 instructions).  M29 = true: the 9 x 29-bit carry-free
+// multiplier of field29.cuh (225 instructions) between an unpack of both operands and a pack + canonicalisation of the product
+// (26 + 26 + 75): the data stay canonical 8 x 32 in LDS and HBM, the TWIDDLE tables are then stored times 2^5 (the radix of that
+// multiplier is 2^261: x 2^256 * w 2^261 / 2^261 = x w 2^256, the ABI form, bit for bit).  A/B switch SRS_NTT_MUL29 (r03).
+template <bool M29>
+__device__ __forceinline__ fe_t tw_mul(const fe_t &x, const fe_t &w) {
+    if constexpr (M29) return Fr29::to_canonical_fe(Fr29::mul(Fr29::unpack(x), Fr29::unpack(w)));
+    else return Fr::mul(x, w);
+}
 
 // T[i] = scale * base^(e(i)),  e(i) = (i >> lo_bits) * (i & (2^lo_bits - 1)) mod 2^m   (m = log2 of table)
 // lo_bits == 0 : plain powers base^i.
@@ -67,7 +79,7 @@ __device__ __forceinline__ fe_t apply_scale3(const Scale3 &s, fe_t v, size_t idx
 }
 
 // one DIT butterfly stage over an LDS tile laid out [row][col], rows = 2^rbits
-template <uint32_t NCOLS>
+template <uint32_t NCOLS, bool M29>
 __device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rbits, uint32_t s) {
     const uint32_t half = 1u << s;
     const uint32_t pairs = (1u << (rbits - 1)) * NCOLS;
@@ -78,7 +90,7 @@ __device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rb
         uint32_t hi = lo + half;
         fe_t a = tile[lo * NCOLS + c];
         fe_t b = tile[hi * NCOLS + c];
-        if (j) b = Fr::mul(b, W[j << (rbits - 1 - s)]);
+        if (j) b = tw_mul<M29>(b, W[j << (rbits - 1 - s)]);
         tile[lo * NCOLS + c] = Fr::add(a, b);
         tile[hi * NCOLS + c] = Fr::sub(a, b);
     }
@@ -86,7 +98,7 @@ __device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rb
 
 // two DIT stages (s, s + 1) in one LDS round trip: a thread owns the 4 elements base + {0, 1, 2, 3} * 2^s of a radix-4
 // group -- the same 4 twiddle multiplications as two radix-2 stages, half the LDS traffic and half the barriers
-template <uint32_t NCOLS>
+template <uint32_t NCOLS, bool M29>
 __device__ __forceinline__ void lds_stage2(fe_t *tile, const fe_t *W, uint32_t rbits, uint32_t s) {
     const uint32_t h = 1u << s;
     const uint32_t groups = (1u << (rbits - 2)) * NCOLS;
@@ -98,12 +110,12 @@ __device__ __forceinline__ void lds_stage2(fe_t *tile, const fe_t *W, uint32_t r
         fe_t e2 = tile[(base + 2 * h) * NCOLS + c], e3 = tile[(base + 3 * h) * NCOLS + c];
         if (j) {                                                   // stage s: pairs (0,1) and (2,3), twiddle w^(j 2^(r-1-s))
             const fe_t t1 = W[j << (rbits - 1 - s)];
-            e1 = Fr::mul(e1, t1);
-            e3 = Fr::mul(e3, t1);
+            e1 = tw_mul<M29>(e1, t1);
+            e3 = tw_mul<M29>(e3, t1);
         }
         fe_t a0 = Fr::add(e0, e1), a1 = Fr::sub(e0, e1), a2 = Fr::add(e2, e3), a3 = Fr::sub(e2, e3);
-        if (j) a2 = Fr::mul(a2, W[j << (rbits - 2 - s)]);          // stage s + 1: pairs (0,2) and (1,3)
-        a3 = Fr::mul(a3, W[(j + h) << (rbits - 2 - s)]);
+        if (j) a2 = tw_mul<M29>(a2, W[j << (rbits - 2 - s)]);      // stage s + 1: pairs (0,2) and (1,3)
+        a3 = tw_mul<M29>(a3, W[(j + h) << (rbits - 2 - s)]);
         tile[base * NCOLS + c] = Fr::add(a0, a2);
         tile[(base + 2 * h) * NCOLS + c] = Fr::sub(a0, a2);
         tile[(base + h) * NCOLS + c] = Fr::add(a1, a3);
@@ -112,15 +124,15 @@ __device__ __forceinline__ void lds_stage2(fe_t *tile, const fe_t *W, uint32_t r
 }
 
 // all `rbits` stages of a tile
-template <uint32_t NCOLS>
+template <uint32_t NCOLS, bool M29 = false>
 __device__ __forceinline__ void lds_stages(fe_t *tile, const fe_t *W, uint32_t rbits) {
     uint32_t s = 0;
     for (; s + 1 < rbits; s += 2) {
-        lds_stage2<NCOLS>(tile, W, rbits, s);
+        lds_stage2<NCOLS, M29>(tile, W, rbits, s);
         __syncthreads();
     }
     if (s < rbits) {
-        lds_stage<NCOLS>(tile, W, rbits, s);
+        lds_stage<NCOLS, M29>(tile, W, rbits, s);
         __syncthreads();
     }
 }
@@ -159,7 +171,7 @@ struct PassArgs {
 };
 
 // non-final pass: tile = (hi, 16 consecutive `rest`), in place, times inter-digit twiddle T
-template <uint32_t RBITS>
+template <uint32_t RBITS, bool M29>
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_ntt_pass(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg,
                const fe_t *__restrict__ T, Scale3 pre) {
@@ -179,18 +191,18 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     }
     for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
     __syncthreads();
-    lds_stages<COLS>(tile, W, RBITS);
+    lds_stages<COLS, M29>(tile, W, RBITS);
     for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
         uint32_t kd = e / COLS, c = e % COLS;
         size_t tidx = ((size_t)kd << pa.lbits) + rest0 + c;      // T[k_j][rest]
-        fe_t x = Fr::mul(tile[e], T[tidx]);
+        fe_t x = tw_mul<M29>(tile[e], T[tidx]);
         dst[base + ((size_t)kd << pa.lbits) + c] = x;
     }
 }
 
 // final pass: tile = 16 consecutive k1 (most significant memory digit) x one contiguous run;
 // output index = digit reversal  k1 + N1*(k2 + N2*(...)) + (N1..N_{p-1}) * k_p
-template <uint32_t RBITS>
+template <uint32_t RBITS, bool M29>
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_ntt_last(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg, Scale3 fin) {
     __shared__ fe_t tile[(1u << RBITS) * COLS];
@@ -228,7 +240,7 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     }
     for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
     __syncthreads();
-    lds_stages<COLS>(tile, W, RBITS);
+    lds_stages<COLS, M29>(tile, W, RBITS);
     for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
         uint32_t kp = e / COLS, c = e % COLS;
         size_t oidx = (size_t)(k1_0 + c) + ((size_t)out_mid << r1) + ((size_t)kp << (pa.log_n - RBITS));
@@ -283,6 +295,7 @@ struct Plan {
     uint32_t radix_bits[4] = {0, 0, 0, 0};
     fe_t *W[4] = {nullptr, nullptr, nullptr, nullptr};   // w_(2^r)^e tables per pass (small path: W[0] = w_n^e)
     fe_t *T[4] = {nullptr, nullptr, nullptr, nullptr};   // inter-digit twiddles after pass j (j < npass-1)
+    bool mul29 = false;                                  // multi-pass plans: butterflies on the 9 x 29-bit multiplier, tables times 2^5
     fe_t scale;                                          // n^-1 for ifft (small path only)
     fe_t *scratch = nullptr;                             // n elements (multi-pass ping buffer)
 };
@@ -290,6 +303,10 @@ struct Plan {
 static std::mutex g_mu;
 static uint32_t g_max_radix = 8;   // tuning knob (4..8): digits per pass; never changes results
 static std::map<std::pair<uint32_t, bool>, Plan> g_plans;
+static bool use_mul29() {
+    static const bool on = [] { const char *e = std::getenv("SRS_NTT_MUL29"); return e && e[0] == '1'; }();
+    return on;
+}
 
 static void fill(fe_t *T, uint32_t log_entries, uint32_t lo_bits, const fe_t &base, const fe_t &scale, hipStream_t st) {
     size_t n = (size_t)1 << log_entries;
@@ -325,16 +342,20 @@ static Plan &get_plan(uint32_t log_n, bool inverse, hipStream_t st) {
             left -= r;
             if (r < 4) { set_error("ntt: digit narrower than 4 bits (raise max radix)"); throw DeviceError{4}; }
         }
+        p.mul29 = use_mul29();
+        fe_t unit = Fr::one();              // the tables' common factor: 1, or 2^5 for the 2^261-radix multiplier (tw_mul)
+        if (p.mul29)
+            for (int d = 0; d < 5; ++d) unit = Fr::add(unit, unit);
         uint32_t below = log_n;
         for (uint32_t j = 0; j < p.npass; ++j) {
             uint32_t r = p.radix_bits[j];
             below -= r;
             SRS_HIP_CHECK(hipMalloc((void **)&p.W[j], sizeof(fe_t) << (r - 1)));
-            fill(p.W[j], r - 1, 0, omega_for(r, inverse), Fr::one(), st);
+            fill(p.W[j], r - 1, 0, omega_for(r, inverse), unit, st);
             if (j + 1 < p.npass) {
                 uint32_t m = r + below;     // M_j = 2^m entries: T[k][rest] = w_M^(k*rest), k < 2^r, rest < 2^below
                 SRS_HIP_CHECK(hipMalloc((void **)&p.T[j], sizeof(fe_t) << m));
-                fill(p.T[j], m, below, omega_for(m, inverse), j == 0 ? ninv : Fr::one(), st);
+                fill(p.T[j], m, below, omega_for(m, inverse), j == 0 ? Fr::mul(ninv, unit) : unit, st);
             }
         }
         SRS_HIP_CHECK(hipMalloc((void **)&p.scratch, sizeof(fe_t) << log_n));
@@ -366,14 +387,16 @@ static void launch_pass(const fe_t *src, fe_t *dst, const PassArgs &pa, const Pl
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
-    SRS_LAUNCH((k_ntt_pass<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
+    if (p.mul29) SRS_LAUNCH((k_ntt_pass<R, true>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
+    else SRS_LAUNCH((k_ntt_pass<R, false>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
 }
 template <uint32_t R>
 static void launch_last(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &fin,
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
-    SRS_LAUNCH((k_ntt_last<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
+    if (p.mul29) SRS_LAUNCH((k_ntt_last<R, true>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
+    else SRS_LAUNCH((k_ntt_last<R, false>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
 }
 #define DISPATCH_R(fn, r, ...)                          \
     switch (r) {                                        \

@@ -256,10 +256,17 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     uint32_t *acc = acc_all + tid;
     const fe_t *U0 = A.utab + G.utab_off;
     const fe_t one261 = U0[PgSpecCall<F, ID>::one(gate)];
-    for (uint32_t l = 0; l < LPT; ++l) {
-        PgSpecCall<F, ID>::sweep(gate, A.ctx, A.compat ? 0u : row0 + (l << TL), A.P, U0 + (size_t)l * A.P * G.n_uniform, G.n_uniform, acc, l != 0);
-        if (l + 1 < LPT)
-            for (uint32_t p = 0; p < A.P; ++p) sw_fold<F>(acc, p, one261);
+    if (A.compat) {
+        // the reference's leaf rows (`index & 2^k`, src/plonk/mod.rs:714): the LPT leaves of a thread all sit at row 0 of this gate,
+        // so they share ONE gate evaluation f(X_p); sum_l w_l f = (sum_l w_l) f exactly -- table LPT holds the term coefficients
+        // times the sum of the thread's leaf weights (pg_sum)
+        PgSpecCall<F, ID>::sweep(gate, A.ctx, 0u, A.P, U0 + (size_t)LPT * A.P * G.n_uniform, G.n_uniform, acc, false);
+    } else {
+        for (uint32_t l = 0; l < LPT; ++l) {
+            PgSpecCall<F, ID>::sweep(gate, A.ctx, row0 + (l << TL), A.P, U0 + (size_t)l * A.P * G.n_uniform, G.n_uniform, acc, l != 0);
+            if (l + 1 < LPT)
+                for (uint32_t p = 0; p < A.P; ++p) sw_fold<F>(acc, p, one261);
+        }
     }
     for (uint32_t p = 0; p < A.P; ++p) {
         weighted_tree<F>(red, sw_finish<F>(acc, p, one261), A.weights, A.wpts, TL);
@@ -294,6 +301,10 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
     fe_t v[LPT];
 #pragma unroll
     for (uint32_t l = 0; l < LPT; ++l) {
+        if (A.compat && l) {                               // reference leaf rows (src/plonk/mod.rs:714): all LPT leaves are the gate at row 0
+            v[l] = v[0];
+            continue;
+        }
         const uint32_t row = A.compat ? 0u : row0 + (l << TL);
         if constexpr (ID >= 0) {                           // sweep form with one point: the 9 x 29-bit multiplier
             using PC = PgSpecCall<F, (ID >= 0 ? ID : 0)>;
@@ -2279,16 +2290,19 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         gp[g].result = p.result;
         gp[g].n_uniform = (uint32_t)nu;
         gp[g].utab_off = (uint32_t)utab.size();
-        utab.resize(utab.size() + nu * leaf_pts * (sweep_leaves ? lpt : 1u));
+        utab.resize(utab.size() + nu * leaf_pts * (sweep_leaves ? lpt + 1 : 1u));
         for (uint32_t lp = 0; lp < leaf_pts; ++lp)
             if (!eval_uniform(p, f, ch_pt[lp].data(), n_ch, 0, false, 0, utab.data() + gp[g].utab_off + (size_t)lp * nu, err)) return 7;
         if (sweep_leaves) {
             // k_pg_leaves_sweep: one table per leaf slot l of a thread, the term coefficients times w_l = prod_{b in bits(l)} c_(TL + b)
+            // table lpt: the SUM of the w_l (reference_compat: the lpt leaves of a thread share one evaluation at row 0)
             const uint32_t TL = tile_log - 3;
-            for (uint32_t l = 1; l < lpt; ++l) {
+            fe_t wsum = Fr::one();
+            for (uint32_t l = 1; l <= lpt; ++l) {
                 fe_t wl = Fr::one();
                 for (uint32_t b = 0; b < 3; ++b)
                     if ((l >> b) & 1u) wl = Fr::mul(wl, weights[(size_t)(TL + b) * wpts]);
+                if (l == lpt) wl = wsum; else wsum = Fr::add(wsum, wl);
                 fe_t *dst = utab.data() + gp[g].utab_off + (size_t)l * leaf_pts * nu;
                 std::memcpy(dst, utab.data() + gp[g].utab_off, (size_t)leaf_pts * nu * sizeof(fe_t));
                 for (uint32_t lp = 0; lp < leaf_pts; ++lp)

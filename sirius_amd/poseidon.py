@@ -46,3 +46,11 @@ class PoseidonHash:
         out = np.zeros(4, dtype=np.uint64)
         L.check(L.lib().srs_poseidon_squeeze(self._h, num_bits, out_field, out.ctypes.data))
         return out
+
+    def squeeze_device(self, num_bits, out_field):
+        """the same squeeze with the sponge run on the device (one wavefront) -> (value, kernel milliseconds); slower than the
+        host code by construction (a permutation is a chain) -- kept for the measured comparison"""
+        out = np.zeros(4, dtype=np.uint64)
+        ms = C.c_double()
+        L.check(L.lib().srs_poseidon_squeeze_device(self._h, num_bits, out_field, out.ctypes.data, C.byref(ms)))
+        return out, ms.value

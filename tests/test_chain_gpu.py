@@ -83,3 +83,10 @@ def test_bench_gpus_flag_fails_loudly_without_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_device_sponge_equals_host_sponge(srs):
+    """srs_poseidon_squeeze_device (one wavefront on the MI355X) == srs_poseidon_squeeze (host), which tests/test_poseidon.py pins
+    to the reference's known answer through the oracle"""
+    from test_emu_logic import POSEIDON_DEVICE_CODE
+    exec(compile(POSEIDON_DEVICE_CODE.replace("import sirius_amd as S\n", ""), "<device sponge>", "exec"), {"S": srs})

@@ -244,6 +244,32 @@ def test_emu_non_contiguous_and_int64_inputs():
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+POSEIDON_DEVICE_CODE = (
+    "import random, numpy as np\n"
+    "import sirius_amd as S\n"
+    "from sirius_amd.field import MODULUS, ints_to_mont\n"
+    "for field in (0, 1):\n"
+    "    for (t, rf, rp) in ((5, 10, 10), (3, 4, 3), (7, 8, 5)):\n"
+    "        for n in (0, 1, 3, 4, 5, 8, 29):\n"
+    "            h = S.PoseidonHash(field, t, t - 1, rf, rp)\n"
+    "            vals = [random.Random(n * 7 + i).randrange(MODULUS[field]) for i in range(n)]\n"
+    "            if n: h.absorb_field(ints_to_mont(field, vals))\n"
+    "            for bits, of in ((128, field), (253, 1 - field)):\n"
+    "                assert np.array_equal(h.squeeze(bits, of), h.squeeze_device(bits, of)[0]), (field, t, n, bits)\n"
+    "print('ok')\n")
+
+
+def test_emu_device_sponge_equals_host_sponge():
+    """k_poseidon_sponge (the device version of the random oracle, kept for the measured host-vs-device comparison) returns the host
+    sponge's value: both fields, T = 3 / 5 / 7, buffers around the rate (padding in the same / an extra chunk)"""
+    import sys
+    code = ("import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\nfrom sirius_amd import _lib\n"
+            f"_lib.load({EMU_LIB!r})\n" + POSEIDON_DEVICE_CODE)
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_chain_digest_vs_oracle():
     """bench.py's headline chain (reference leaf rows + Poseidon-derived challenges, 2 CycleFold steps) through the emulator's
     kernel logic == the same chain recomputed on the oracle (tests/chain_cases.py); the GPU version is tests/test_chain_gpu.py."""

@@ -49,3 +49,31 @@ def test_library_matches_oracle_on_both_fields():
     hh = S.PoseidonHash(0)
     with pytest.raises(S.SiriusAmdError):
         hh.absorb_point(0, np.zeros(8, np.uint64))           # bn256 coordinates are Fq elements, this oracle is over Fr
+
+
+def test_scalar_and_ifma_permutations_agree_with_the_oracle():
+    """The host permutation has two implementations (csrc/poseidon.hip: 4 x 64-bit scalar code; csrc/poseidon_x86.hip: AVX-512 IFMA,
+    chosen by cpuid).  Both are run against the oracle (one subprocess each; SRS_POSEIDON_SCALAR=1 forces the scalar one) on the
+    transcript sizes of a ProtoGalaxy prove and on edge values (0, 1, p - 1) -- whatever CPU the suite runs on, the path it does
+    not take by default is still covered when the CPU has IFMA, and the scalar path always is."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import random, sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O, sirius_amd as S\n"
+        "from oracle import poseidon as OP, pyref as P\n"
+        "rnd = random.Random(11)\n"
+        "for field, p in ((0, P.FR), (1, P.FQ)):\n"
+        "    for t, r_f, r_p in ((5, 10, 10), (3, 4, 3), (8, 8, 9)):\n"
+        "        h, o = S.PoseidonHash(field, t, t - 1, r_f, r_p), OP.PoseidonHash(p, t, t - 1, r_f, r_p)\n"
+        "        for n in (25, 32, 256):\n"
+        "            vals = [rnd.randrange(p) for _ in range(n - 3)] + [0, 1, p - 1]\n"
+        "            h.absorb_field(O.ints_to_mont(field, vals)); o.absorb_field_iter(vals)\n"
+        "            assert O.mont_to_ints(field, h.squeeze(253, field)) == [o.squeeze(253)], (field, t, n)\n"
+        "print('ok')\n")
+    for scalar in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_POSEIDON_SCALAR=scalar), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (scalar, r.stdout[-300:], r.stderr[-1500:])
