@@ -116,6 +116,7 @@ struct srs_ck {
     msm::Key key;       // the key of a single-device handle; for a multi-device handle only curve / global_len are meaningful
     Arena staging;      // H2D staging of host scalars
     hipStream_t copy_stream = nullptr;       // srs_commit_upload: uploads run here, the MSMs on the caller's stream
+    hipStream_t sort_stream = nullptr;       // chunked commits: the sort kernels of chunk j + 1 slip into the drain of k_accum0 of chunk j
     std::vector<hipEvent_t> events;
     std::vector<std::unique_ptr<CkShard>> shards;      // non-empty: multi-device key
 };
@@ -774,6 +775,7 @@ void srs_ck_free(srs_ck *ck) {
     }
     for (hipEvent_t e : ck->events) (void)hipEventDestroy(e);
     if (ck->copy_stream) (void)hipStreamDestroy(ck->copy_stream);
+    if (ck->sort_stream) (void)hipStreamDestroy(ck->sort_stream);
     if (ck->key.table) (void)hipFree(ck->key.table);
     msm::release(ck->key);
     ck->staging.release();
@@ -877,12 +879,11 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
     size_t per = 0;
     for (size_t j = 0; j < chunks; ++j) per = std::max(per, cut[j + 1] - cut[j]);
     if (!ck->copy_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->copy_stream, hipStreamNonBlocking));
-    while (ck->events.size() < chunks + 1) {
+    while (ck->events.size() < 2 * chunks + 2) {
         hipEvent_t e;
         SRS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ck->events.push_back(e);
     }
-    msm::reserve(ck->key, (uint32_t)per, 1);
     // the copy stream must not overwrite dst while earlier work on the caller's stream still reads it
     SRS_HIP_CHECK(hipEventRecord(ck->events[chunks], st));
     SRS_HIP_CHECK(hipStreamWaitEvent(ck->copy_stream, ck->events[chunks], 0));
@@ -890,14 +891,37 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
     // every chunk on the 16-bit windows: the chunks fold their buckets into one running set and only the last one is reduced
     bool fold = chunks > 1 && !std::getenv("SRS_COMMIT_NO_FOLD");
     for (size_t j = 0; j < chunks; ++j) fold = fold && msm::may_fold(ck->key, (uint32_t)(cut[j + 1] - cut[j]));
+    // ... and with a DEFERRED TAIL (msm::chunked_*): a chunk runs only its sort and k_accum0, the accumulation levels run once for all
+    // chunks as a batch; the sort kernels go to a second stream so that they start in the drain of the previous chunk's k_accum0
+    const bool deferred = fold && msm::chunked_supported(ck->key, (uint32_t)per, (uint32_t)chunks);
+    static const bool two_streams = [] { const char *e = std::getenv("SRS_COMMIT_SORT_STREAM"); return !(e && e[0] == '0'); }();
+    hipStream_t s_sort = st;
+    if (deferred) {
+        msm::chunked_begin(ck->key, (uint32_t)per, (uint32_t)chunks, st);
+        if (two_streams) {
+            if (!ck->sort_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->sort_stream, hipStreamNonBlocking));
+            s_sort = ck->sort_stream;
+            SRS_HIP_CHECK(hipEventRecord(ck->events[2 * chunks + 1], st));          // the workspace is free / its counters are cleared
+            SRS_HIP_CHECK(hipStreamWaitEvent(s_sort, ck->events[2 * chunks + 1], 0));
+        }
+    } else {
+        msm::reserve(ck->key, (uint32_t)per, 1);
+    }
     auto upload = [&](size_t j) {
         upload_range(dst, segs, cut[j], cut[j + 1], ck->copy_stream);
         SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
     };
     auto launch = [&](size_t j) {
-        SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
         const fe_t *ptr = dst + cut[j];
         const uint32_t nn = (uint32_t)(cut[j + 1] - cut[j]), base = (uint32_t)cut[j];
+        if (deferred) {
+            SRS_HIP_CHECK(hipStreamWaitEvent(s_sort, ck->events[j], 0));
+            msm::chunked_front(ck->key, (uint32_t)j, ptr, nn, base, repr == SRS_REPR_MONT, s_sort, st, ck->events[chunks + 1 + j]);
+            launched[j] = true;
+            if (j + 1 == chunks) msm::chunked_tail(ck->key, st, (uint32_t)j);
+            return;
+        }
+        SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
         const msm::Fold f = !fold ? msm::FOLD_NONE : (j == 0 ? msm::FOLD_FIRST : (j + 1 == chunks ? msm::FOLD_LAST : msm::FOLD_MIDDLE));
         launched[j] = msm::enqueue(ck->key, &ptr, &nn, &base, 1, repr == SRS_REPR_MONT, st, (uint32_t)j, f);
     };
@@ -942,7 +966,9 @@ std::vector<size_t> commit_cuts(size_t n, size_t align) {
     } else {                             // a SHORT first chunk (its upload is the only one nothing overlaps), growing ones after it
         // (measured on the 12 * 2^20 witness, profiles/r02_commit_cuts.txt: six chunks growing ~1.5x beat four -- the MSM left to do
         // after the last byte has arrived is what counts once the per-chunk fixed cost is down to ~0.4 ms)
-        std::vector<double> frac = {0.045, 0.15, 0.32, 0.53, 0.77};
+        // r03: re-tuned once the per-chunk costs had changed (a chunk may grow ~1.3x + 0.4 M scalars over its predecessor before the
+        // chip waits for its upload: profiles/r03_ab_accum0_variants.txt) -- was {0.045, 0.15, 0.32, 0.53, 0.77}
+        std::vector<double> frac = {0.024, 0.089, 0.208, 0.399, 0.677};
         if (const char *e = std::getenv("SRS_COMMIT_CUTS")) {      // tuning: cumulative fractions, e.g. "0.1,0.4"
             frac.clear();
             for (const char *q = e; *q;) {

@@ -18,7 +18,7 @@ constexpr uint32_t SEG = 128, SEG_BUCKETS = NBUCKET / SEG;   // two-pass scatter
 constexpr uint32_t SORT_TILE2 = 65536;          // entries per workgroup of the second pass
 constexpr uint64_t TWO_PASS_MIN_SLOTS = 1ull << 28;   // digit slots (16 n x batch) from which the two-pass scatter wins (measured: 2^24-point MSMs)
 constexpr uint32_t PLAN_THREADS = 1024;
-constexpr uint32_t ACC_THREADS = 128;
+constexpr uint32_t ACC_THREADS = 256;        // r03 A/B (profiles/r03_ab_accum0_variants.txt): 256 beats 128 and 64 by 2-3 % of a k = 20 step
 constexpr uint32_t ACC_L0_LOG = 4, ACC_L0 = 1u << ACC_L0_LOG;   // gathered mixed adds per level-0 thread
 constexpr uint32_t ACC_L1_LOG = 3, ACC_L1 = 1u << ACC_L1_LOG;   // full adds per thread on later levels
 constexpr uint32_t FINAL_THREADS = 256;   // 4 wavefronts = 4 buckets per workgroup
@@ -46,6 +46,18 @@ constexpr uint32_t WIDE_MIN_N_LOG = 23;   // MSMs from 2^23 scalars take the wid
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
 static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
 
+// workspace of a chunked commit with a deferred tail (msm.hip: chunked_*): set j of the commit lives in batch slot j
+struct Chunked {
+    uint32_t sets = 0, l0_log = 0;
+    int levels = 0;
+    bool defer_tail = false;      // the accumulation levels of all sets run once, batched, in chunked_tail (else per set, after its k_accum0)
+    uint64_t M = 0, parts0_cap = 0, parts1_cap = 0;      // per slot: digit slots, level-0 / level-1 part capacity
+    size_t plan_stride = 0;
+    uint16_t *dig = nullptr, *tb = nullptr;
+    uint32_t *sorted = nullptr, *count = nullptr, *cursor = nullptr, *plan = nullptr;
+    xyzz_t *ping = nullptr, *pong = nullptr, *buckets = nullptr, *rc = nullptr, *d_out = nullptr;
+};
+
 // Device-resident commitment key: window-expanded table T[w * len + i] = 2^(16 w) P_i, coordinates in the
 // R' = 2^261 Montgomery form of the 9 x 29-bit multiplier (field29.cuh) once build_table has run.
 struct Key {
@@ -58,6 +70,7 @@ struct Key {
     affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (keys of >= 2^WIDE_MIN_KEY_LOG bases; owned by the key: release())
     xyzz_t *fold_buckets = nullptr;   // running bucket sums of a chunked commit (enqueue(.., fold)); owned by the key
     bool slot_wide[LANDING_SLOTS] = {};       // landing slot -> which pipeline produced it (finish() combines 3 or 4 partial sums)
+    Chunked chunked;          // layout of the running chunked commit (pointers into `arena`)
     Arena arena;              // per-key scratch (grow-only)
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
 };
@@ -98,6 +111,17 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
              hipStream_t stream, uint32_t slot, Fold fold = FOLD_NONE);
 void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host);
 void reserve(Key &k, uint32_t n_max, uint32_t batch);
+
+// Chunked commit with a DEFERRED TAIL (one 16-bit-window MSM cut into `sets` <= BATCH_ARGS chunks of <= n_max scalars, all over one
+// bucket set): chunked_begin lays the sets out as the batch slots of one workspace; chunked_front(j) runs only the sort and k_accum0
+// of set j (sort kernels on s_sort, k_accum0 on s_acc after `sorted_ev`; both may be the same stream); chunked_tail runs the
+// accumulation levels ONCE for all sets as a batch, adds the sets' buckets, reduces, and lands the 3 partial sums in `slot`
+// (finish(k, 1, slot, true, ..) after the stream has been synchronised).  Every set must be non-empty.
+bool chunked_supported(const Key &k, uint32_t n_max, uint32_t sets);
+void chunked_begin(Key &k, uint32_t n_max, uint32_t sets, hipStream_t stream);
+void chunked_front(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t s_sort, hipStream_t s_acc,
+                   hipEvent_t sorted_ev);
+void chunked_tail(Key &k, hipStream_t stream, uint32_t slot);
 
 }  // namespace msm
 }  // namespace srs

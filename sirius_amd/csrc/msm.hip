@@ -984,6 +984,24 @@ __global__ void SRS_KERNEL_BOUNDS(64, 1)
     }
 }
 
+// chunked commits with a deferred tail (chunked_* below): the finished buckets of ALL chunk sets (batch slot m: where k_rowcol would
+// read them) are added up into the key's running buckets.  One QUAD per bucket.   grid = NBUCKET * 4 / 256
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(256, 1)
+    k_bucket_sum(const xyzz_t *__restrict__ buckets, const xyzz_t *__restrict__ ping, size_t ping_stride, const xyzz_t *__restrict__ pong,
+                 size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t sets, xyzz_t *__restrict__ total) {
+    using E29 = Ec29<C>;
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x, b = lin >> 2, q = lin & 3u;
+    xyzz29_t acc = E29::identity();
+    for (uint32_t m = 0; m < sets; ++m) {
+        const uint32_t *hdr = plan + (size_t)m * plan_stride + plan_stride - 4;      // [0] levels run, [1] all buckets single
+        const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + (size_t)m * ping_stride : pong + (size_t)m * pong_stride) : buckets + (size_t)m * NBUCKET;
+        const xyzz29_t x = E29::unpack(B[b]);
+        acc = m == 0 ? x : E29::add_quad(acc, x, q);
+    }
+    if (q == 0) total[b] = E29::pack(acc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 5. bucket reduction  S = sum_b (b+1) B_b,  b = hi * RED_COLS + lo
 //    S = RED_COLS * sum_hi hi * R_hi  +  sum_lo (lo+1) * C_lo
@@ -1516,6 +1534,174 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     SRS_HIP_CHECK(hipMemcpyAsync(land, d_out, 4 * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     k.slot_wide[slot] = true;
     return true;
+}
+
+// ---- chunked commit with a deferred tail --------------------------------------------------------------------------------------
+// The chunks of a streamed commit (capi.hip: commit_streamed) used to run the whole pipeline each: sort, k_accum0, then the
+// latency-bound tail -- k_accum1 levels, k_accum_final, k_bucket_fold -- ~0.25 ms per chunk on a chip that is 60 % empty.  Here the
+// chunk sets occupy the BATCH SLOTS of one workspace (set j = slot j: own digits / sorted list / plan / parts), a chunk runs only its
+// front (sort + k_accum0), and the tail runs ONCE for all sets as a batch (grid.y = sets): the same additions in launches that fill
+// the chip, then k_bucket_sum adds the sets' buckets and the usual single reduction follows.  The sort kernels of set j + 1 may be
+// issued on a second stream: they then slip into the drain of k_accum0 of set j instead of waiting behind it.
+// MEASURED SLOWER than the plain flow (one workspace reused by every chunk, everything on the caller's stream) on the k = 20 step --
+// 14.7-15.3 against 14.3 ms, profiles/r03_ab_commit_pipeline.txt: the step is bound by the sum of the kernels' work, the overlap only
+// moves it around, and six workspaces instead of one cost more than the overlap gains.  OFF by default; SRS_COMMIT_SLOTS=1 turns it on.
+// SRS_COMMIT_DEFER=1   : the accumulation levels of all chunks run once, batched, after the last chunk (measured slower: the per-chunk
+//                        levels fill gaps in which the chip waits for the next upload anyway, profiles/r03_ab_commit_pipeline.txt).
+// SRS_COMMIT_SORT_WG=n : workgroup size of the histogram / scatter kernels on the side stream (default 256).
+static uint32_t chunked_sort_threads() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("SRS_COMMIT_SORT_WG");
+        const int t = e ? std::atoi(e) : 256;
+        return (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) ? (uint32_t)t : 256u;
+    }();
+    return v;
+}
+template <class C>
+static void chunked_front_t(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t s_sort,
+                            hipStream_t s_acc, hipEvent_t sorted_ev) {
+    Chunked &S = k.chunked;
+    const uint64_t M = S.M;
+    uint16_t *dig = S.dig + (size_t)j * M;
+    uint32_t *sorted = S.sorted + (size_t)j * M;
+    uint32_t *count = S.count + (size_t)j * NBUCKET, *cursor = S.cursor + (size_t)j * NBUCKET;
+    uint32_t *plan = S.plan + (size_t)j * S.plan_stride;
+    xyzz_t *ping = S.ping + (size_t)j * S.parts0_cap;
+    uint16_t *tb = S.tb + (size_t)j * S.parts0_cap;
+    BatchDesc bd;
+    for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
+        bd.ptr[m] = m == 0 ? scalars_dev : nullptr;
+        bd.n[m] = m == 0 ? n : 0;
+        bd.base[m] = m == 0 ? base : 0;
+    }
+    SRS_LAUNCH((k_digits<C>), (ceil_div(n, 256), 1), (256), 0, s_sort, bd, dig, (size_t)M, is_mont, k.compact_scalars ? 0u : k.rank,
+               k.compact_scalars ? 1u : k.world);
+    uint32_t tile = (uint32_t)(((uint64_t)n * NWIN + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
+    tile = (tile + 1023u) & ~1023u;
+    if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
+    const uint32_t tiles = ceil_div(n, tile);
+    // On a side stream the sort workgroups are SMALL (one wavefront per SIMD, < 56 VGPRs, the LDS k_accum0 does not use): they fit next to
+    // the three 150-VGPR waves k_accum0 keeps on every SIMD and run under the previous chunk's accumulation instead of after it.
+    const uint32_t sort_threads = s_sort != s_acc ? chunked_sort_threads() : SORT_THREADS;
+    SRS_LAUNCH(k_hist, (tiles, NWIN, 1), (sort_threads), 0, s_sort, (const uint16_t *)dig, (size_t)M, bd, count, tile, (uint32_t *)nullptr);
+    SRS_LAUNCH(k_plan, (1), (PLAN_THREADS), 0, s_sort, (const uint32_t *)count, cursor, plan, S.plan_stride, S.levels, S.l0_log,
+               (uint32_t)ACC_L1_LOG, (const uint32_t *)nullptr);
+    SRS_LAUNCH(k_scatter, (tiles, NWIN, 1), (sort_threads), 0, s_sort, (const uint16_t *)dig, (size_t)M, bd, cursor, sorted, (size_t)M,
+               (uint32_t)k.len, tile);
+    const Link *no_link = nullptr;
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, 1), (256), 0, s_sort, (const uint32_t *)plan, S.plan_stride, tb, (size_t)S.parts0_cap, no_link);
+    if (s_sort != s_acc) {
+        SRS_HIP_CHECK(hipEventRecord(sorted_ev, s_sort));
+        SRS_HIP_CHECK(hipStreamWaitEvent(s_acc, sorted_ev, 0));
+    }
+    {
+        prof::Scope ps("msm_accum0", s_acc, n);
+        const uint64_t cap = ((uint64_t)n * NWIN >> S.l0_log) + NBUCKET + 1;          // this set's parts, not the slot's capacity
+        SRS_LAUNCH((k_accum0<C>), (ceil_div(cap, ACC_THREADS), 1), (ACC_THREADS), 0, s_acc, (const uint32_t *)sorted, (size_t)M,
+                   (const uint32_t *)plan, S.plan_stride, (const uint16_t *)tb, (size_t)S.parts0_cap, (const affine_t *)k.table, ping,
+                   (size_t)S.parts0_cap, 1u << S.l0_log, no_link);
+    }
+    if (!S.defer_tail) {             // this set's accumulation levels now (they fill the gaps in which the chip waits for the next upload)
+        xyzz_t *pong = S.pong + (size_t)j * S.parts1_cap, *buckets = S.buckets + (size_t)j * NBUCKET;
+        xyzz_t *cur = ping, *nxt = pong;
+        size_t cur_stride = S.parts0_cap, nxt_stride = S.parts1_cap;
+        uint64_t cap = ((uint64_t)n * NWIN >> S.l0_log) + NBUCKET + 1;
+        for (int level = 1; level < S.levels; ++level) {
+            cap = cap / ACC_L1 + NBUCKET + 1;
+            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), 1), (ACC_THREADS), 0,
+                       s_acc, (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, S.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
+                       acc1_quad_max());
+            std::swap(cur, nxt);
+            std::swap(cur_stride, nxt_stride);
+        }
+        SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), 1), (FINAL_THREADS), 0, s_acc, (const xyzz_t *)ping, (size_t)S.parts0_cap,
+                   (const xyzz_t *)pong, (size_t)S.parts1_cap, (const uint32_t *)plan, S.plan_stride, buckets, no_link);
+        if (!k.fold_buckets) SRS_HIP_CHECK(hipMalloc((void **)&k.fold_buckets, (size_t)NBUCKET * sizeof(xyzz_t)));
+        SRS_LAUNCH((k_bucket_fold<C>), (NBUCKET / 64), (64), 0, s_acc, (const xyzz_t *)buckets, (const xyzz_t *)ping, (const xyzz_t *)pong,
+                   (const uint32_t *)plan, S.plan_stride, k.fold_buckets, j == 0 ? 1 : 0);
+    }
+}
+
+template <class C>
+static void chunked_tail_t(Key &k, hipStream_t stream, uint32_t slot) {
+    Chunked &S = k.chunked;
+    const uint32_t sets = S.sets;
+    const Link *no_link = nullptr;
+    if (S.defer_tail) {
+        xyzz_t *cur = S.ping, *nxt = S.pong;
+        size_t cur_stride = S.parts0_cap, nxt_stride = S.parts1_cap;
+        uint64_t cap = S.parts0_cap;
+        for (int level = 1; level < S.levels; ++level) {
+            cap = cap / ACC_L1 + NBUCKET + 1;
+            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), sets), (ACC_THREADS), 0,
+                       stream, (const xyzz_t *)cur, cur_stride, (const uint32_t *)S.plan, S.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
+                       acc1_quad_max());
+            std::swap(cur, nxt);
+            std::swap(cur_stride, nxt_stride);
+        }
+        SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), sets), (FINAL_THREADS), 0, stream, (const xyzz_t *)S.ping, (size_t)S.parts0_cap,
+                   (const xyzz_t *)S.pong, (size_t)S.parts1_cap, (const uint32_t *)S.plan, S.plan_stride, S.buckets, no_link);
+        if (!k.fold_buckets) SRS_HIP_CHECK(hipMalloc((void **)&k.fold_buckets, (size_t)NBUCKET * sizeof(xyzz_t)));
+        SRS_LAUNCH((k_bucket_sum<C>), (NBUCKET * 4 / 256), (256), 0, stream, (const xyzz_t *)S.buckets, (const xyzz_t *)S.ping, (size_t)S.parts0_cap,
+                   (const xyzz_t *)S.pong, (size_t)S.parts1_cap, (const uint32_t *)S.plan, S.plan_stride, sets, k.fold_buckets);
+    }
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, 1), (128), 0, stream, (const xyzz_t *)k.fold_buckets, (const xyzz_t *)S.ping,
+               (size_t)S.parts0_cap, (const xyzz_t *)S.pong, (size_t)S.parts1_cap, (const uint32_t *)S.plan, S.plan_stride, S.rc, no_link, 1);
+    SRS_LAUNCH((k_reduce_final<C>), (3, 1), (RED_THREADS), 0, stream, (const xyzz_t *)S.rc, S.d_out);
+    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
+    xyzz_t *land = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
+    SRS_HIP_CHECK(hipMemcpyAsync(land, S.d_out, 3 * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
+    k.slot_wide[slot] = false;
+}
+
+bool chunked_supported(const Key &k, uint32_t n_max, uint32_t sets) {
+    static const bool on = [] { const char *e = std::getenv("SRS_COMMIT_SLOTS"); return e && e[0] == '1'; }();
+    return on && sets >= 2 && sets <= BATCH_ARGS && !use_wide(k, n_max, 1) && !use_two_pass((uint64_t)n_max * NWIN, 1);
+}
+
+void chunked_begin(Key &k, uint32_t n_max, uint32_t sets, hipStream_t stream) {
+    Chunked &S = k.chunked;
+    static const bool defer = [] { const char *e = std::getenv("SRS_COMMIT_DEFER"); return e && e[0] == '1'; }();
+    S.defer_tail = defer;
+    S.sets = sets;
+    S.M = (uint64_t)n_max * NWIN;
+    S.levels = levels_for(S.M);
+    S.l0_log = l0_log_for(S.M);
+    S.plan_stride = (size_t)(S.levels + 1) * (NBUCKET + 1) + 4;
+    S.parts0_cap = (S.M >> S.l0_log) + NBUCKET + 1;
+    S.parts1_cap = S.parts0_cap / ACC_L1 + NBUCKET + 1;
+    Arena &A = k.arena;
+    size_t per = 0;
+    per += Arena::pad(S.M * sizeof(uint16_t)) + Arena::pad(S.M * sizeof(uint32_t));
+    per += 2 * Arena::pad(NBUCKET * sizeof(uint32_t)) + Arena::pad(S.plan_stride * sizeof(uint32_t));
+    per += Arena::pad(S.parts0_cap * sizeof(xyzz_t)) + Arena::pad(S.parts0_cap * sizeof(uint16_t)) + Arena::pad(S.parts1_cap * sizeof(xyzz_t));
+    per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));
+    A.reserve(per * sets + Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t)) + Arena::pad(3 * sizeof(xyzz_t)) + 16 * 4096);
+    A.reset();
+    S.d_out = A.take<xyzz_t>(3);
+    S.dig = A.take<uint16_t>(S.M * sets);
+    S.sorted = A.take<uint32_t>(S.M * sets);
+    S.count = A.take<uint32_t>((size_t)NBUCKET * sets);
+    S.cursor = A.take<uint32_t>((size_t)NBUCKET * sets);
+    S.plan = A.take<uint32_t>(S.plan_stride * sets);
+    S.ping = A.take<xyzz_t>(S.parts0_cap * sets);
+    S.tb = A.take<uint16_t>(S.parts0_cap * sets);
+    S.pong = A.take<xyzz_t>(S.parts1_cap * sets);
+    S.buckets = A.take<xyzz_t>((size_t)NBUCKET * sets);
+    S.rc = A.take<xyzz_t>(RED_ROWS + RED_COLS);
+    SRS_HIP_CHECK(hipMemsetAsync(S.count, 0, (size_t)NBUCKET * sets * sizeof(uint32_t), stream));
+}
+void chunked_front(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t s_sort, hipStream_t s_acc,
+                   hipEvent_t sorted_ev) {
+    if (j >= k.chunked.sets || (uint64_t)n * NWIN > k.chunked.M || n == 0) {
+        set_error("internal: msm::chunked_front out of range");
+        throw DeviceError{5};
+    }
+    if (k.curve == 0) chunked_front_t<Bn256>(k, j, scalars_dev, n, base, is_mont, s_sort, s_acc, sorted_ev);
+    else chunked_front_t<Grumpkin>(k, j, scalars_dev, n, base, is_mont, s_sort, s_acc, sorted_ev);
+}
+void chunked_tail(Key &k, hipStream_t stream, uint32_t slot) {
+    if (k.curve == 0) chunked_tail_t<Bn256>(k, stream, slot); else chunked_tail_t<Grumpkin>(k, stream, slot);
 }
 
 // host end of enqueue_t, after `stream` has been synchronised:  S = RED_COLS * (2 A' + Z) + B  (10 group operations per MSM)

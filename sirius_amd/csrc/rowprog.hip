@@ -336,28 +336,59 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
 }
 
 // one level of the polynomial tree: out[i] = in[2i] + in[2i+1] * (beta + X delta); nodes >= m_valid are zero.
-// coefficient-major arrays: in[m * n_in + node] (degree deg_in), out[m * n_out + node] (degree deg_in + 1)
+// coefficient-major arrays: in[m * n_in + node] (degree deg_in), out[m * n_out + node] (degree deg_in + 1).
+// One thread per (coefficient m, node i) -- consecutive threads = consecutive nodes of one coefficient (coalesced): the upper levels
+// have few nodes, and a thread per NODE walking its deg + 2 coefficients in turn left them at 16-48 us of pure latency each (r02:
+// 18 launches = 0.5 ms of a step); r03.
 template <class F>
 __global__ void k_pg_F_level(const fe_t *__restrict__ in, uint32_t n_in, uint32_t m_valid, uint32_t deg_in, fe_t beta, fe_t delta,
                              fe_t *__restrict__ out, uint32_t n_out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= n_out * (deg_in + 2)) return;
+    const uint32_t m = lin / n_out, i = lin - m * n_out;
     const bool hasL = 2 * i < m_valid, hasR = 2 * i + 1 < m_valid;
-    fe_t prevR = F::zero();
-    for (uint32_t m = 0; m <= deg_in + 1; ++m) {
-        fe_t acc = F::zero();
-        fe_t r = F::zero();
-        if (m <= deg_in) {
-            if (hasL) acc = in[(size_t)m * n_in + 2 * i];
-            if (hasR) {
-                r = in[(size_t)m * n_in + 2 * i + 1];
-                acc = F::add(acc, F::mul(r, beta));
-            }
-        }
-        if (m >= 1 && hasR) acc = F::add(acc, F::mul(prevR, delta));
-        out[(size_t)m * n_out + i] = acc;
-        prevR = r;
+    fe_t acc = F::zero();
+    if (m <= deg_in) {
+        if (hasL) acc = in[(size_t)m * n_in + 2 * i];
+        if (hasR) acc = F::add(acc, F::mul(in[(size_t)m * n_in + 2 * i + 1], beta));
     }
+    if (m >= 1 && hasR) acc = F::add(acc, F::mul(in[(size_t)(m - 1) * n_in + 2 * i + 1], delta));
+    out[(size_t)m * n_out + i] = acc;
+}
+
+// the top of the tree in ONE workgroup: the last `nlev` <= PG_F_TAIL_LEVELS levels (n_in = 2^nlev <= 32 nodes) through LDS, the same
+// (coefficient, node) threads; writes the final polynomial (degree deg_in + nlev) to out[0 .. deg_in + nlev]
+constexpr uint32_t PG_F_TAIL_LEVELS = 5, PG_F_TAIL_MAXDEG = 40;
+struct PgFTail {
+    fe_t beta[PG_F_TAIL_LEVELS], delta[PG_F_TAIL_LEVELS];
+};
+template <class F>
+__global__ void SRS_KERNEL_BOUNDS(512, 1)
+    k_pg_F_tail(const fe_t *__restrict__ in, uint32_t n_in, uint32_t m_valid, uint32_t deg_in, uint32_t nlev, PgFTail T, fe_t *__restrict__ out) {
+    __shared__ fe_t buf[2][(PG_F_TAIL_MAXDEG + 1) * 16];        // level outputs: <= 16 nodes x <= 41 coefficients
+    const uint32_t t = threadIdx.x;
+    uint32_t cur_n = n_in, deg = deg_in, valid = m_valid;
+    for (uint32_t lv = 0; lv < nlev; ++lv) {
+        const uint32_t n_out = cur_n >> 1;
+        const fe_t *src = lv == 0 ? in : buf[(lv - 1) & 1];
+        fe_t *dst = buf[lv & 1];
+        for (uint32_t lin = t; lin < n_out * (deg + 2); lin += blockDim.x) {
+            const uint32_t m = lin / n_out, i = lin - m * n_out;
+            const bool hasL = 2 * i < valid, hasR = 2 * i + 1 < valid;
+            fe_t acc = F::zero();
+            if (m <= deg) {
+                if (hasL) acc = src[(size_t)m * cur_n + 2 * i];
+                if (hasR) acc = F::add(acc, F::mul(src[(size_t)m * cur_n + 2 * i + 1], T.beta[lv]));
+            }
+            if (m >= 1 && hasR) acc = F::add(acc, F::mul(src[(size_t)(m - 1) * cur_n + 2 * i + 1], T.delta[lv]));
+            dst[(size_t)m * n_out + i] = acc;
+        }
+        __syncthreads();
+        cur_n = n_out;
+        ++deg;
+        valid = (valid + 1) >> 1;
+    }
+    for (uint32_t m = t; m <= deg; m += blockDim.x) out[m] = buf[(nlev - 1) & 1][m];
 }
 
 #define SRS_SPEC_PART 2
@@ -2373,13 +2404,29 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         for (uint32_t b = TL + 3; b < levels; ++b) order.push_back(b);
         size_t n_in = n0, m_valid = n_tiles_valid * T;
         uint32_t deg = 3;
-        for (uint32_t b : order) {
+        size_t at = 0;
+        for (; at < order.size(); ++at) {
+            // the last levels (<= 32 nodes left) run in one workgroup (k_pg_F_tail)
+            const size_t left = order.size() - at;
+            if (n_in <= 32 && left <= PG_F_TAIL_LEVELS && deg + left <= PG_F_TAIL_MAXDEG && !std::getenv("SRS_PG_F_NO_TAIL")) break;
+            const uint32_t b = order[at];
             const size_t n_out = n_in / 2;
-            SRS_LAUNCH((k_pg_F_level<Fr>), ((uint32_t)((n_out + 127) / 128)), (128), 0, st, (const fe_t *)cur, (uint32_t)n_in,
+            SRS_LAUNCH((k_pg_F_level<Fr>), ((uint32_t)((n_out * (deg + 2) + 127) / 128)), (128), 0, st, (const fe_t *)cur, (uint32_t)n_in,
                        (uint32_t)m_valid, deg, weights_in[b], deltas[b], nxt, (uint32_t)n_out);
             n_in = n_out;
             m_valid = (m_valid + 1) / 2;
             ++deg;
+            std::swap(cur, nxt);
+        }
+        if (at < order.size()) {
+            const uint32_t nlev = (uint32_t)(order.size() - at);
+            PgFTail tl;
+            for (uint32_t l = 0; l < PG_F_TAIL_LEVELS; ++l) {
+                tl.beta[l] = l < nlev ? weights_in[order[at + l]] : Fr::zero();
+                tl.delta[l] = l < nlev ? deltas[order[at + l]] : Fr::zero();
+            }
+            SRS_LAUNCH((k_pg_F_tail<Fr>), (1), (512), 0, st, (const fe_t *)cur, (uint32_t)n_in, (uint32_t)m_valid, deg, nlev, tl, nxt);
+            deg += nlev;
             std::swap(cur, nxt);
         }
         // n_in == 1: cur[m] = coefficient m, m <= deg = levels; the reference's vector has fft_points_count_F entries
