@@ -418,7 +418,7 @@ def msm_roofline(S, units_note, nz_madds=None, world=1):
     sec = acc0["total_ms"] * 1e-3
     achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / sec / 1e9
     traffic, src = None, None
-    for name in ("r02_pmc_accum0.json", "r01_pmc_accum0.json"):
+    for name in ("r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if world == 1:

@@ -1243,6 +1243,12 @@ void build_table(Key &k, hipStream_t stream) {
 static uint32_t l0_log_for(uint64_t M) {
     static const int forced = [] { const char *e = std::getenv("SRS_MSM_L0"); return e ? std::atoi(e) : 0; }();
     if (forced >= 1 && forced <= 7) return (uint32_t)forced;
+    // small MSMs (the support circuit's 3 * 2^15 and 2^15-row commits) cannot fill the chip with 16-entry parts: 2^21 digit slots give
+    // < 2^17 level-0 threads, each a chain of 16 dependent additions on a chip that holds 2^17.6 -- shorter parts, more threads
+    // (r03; SRS_MSM_L0_SMALL=0 restores 16 everywhere)
+    static const bool small_on = [] { const char *e = std::getenv("SRS_MSM_L0_SMALL"); return !(e && e[0] == '0'); }();
+    if (small_on && M < (1ull << 21)) return 2;
+    if (small_on && M < (1ull << 22)) return 3;
     uint32_t lg = ACC_L0_LOG;
     while (lg < 7 && (M >> (lg + 1)) >= (5ull << 20)) ++lg;
     return lg;

@@ -243,7 +243,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_spec(PgArgs A) {
 // w_l = prod_{b in bits(l)} c_(TL + b) of the leaf-index bits it owns: the host multiplies the term coefficients of the
 // uniform table by w_l (one table per l, A.utab = [gate][l][P][nu]), so leaf l simply ACCUMULATES onto the same lazy 9 x 29-bit
 // sums in LDS; between leaves the sums are folded below 2p.  Needs wpts == 1, P <= DMAX + 1 and affine advice leaves.
-template <class F, int ID, uint32_t LPT>
+template <class F, int ID, uint32_t LPT, bool COMPAT>
 __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     __shared__ fe_t red[RP_THREADS];
     SRS_SWEEP_ACC(acc_all);                                 // sweep_smem_bytes(P) of dynamic LDS
@@ -256,7 +256,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     uint32_t *acc = acc_all + tid;
     const fe_t *U0 = A.utab + G.utab_off;
     const fe_t one261 = U0[PgSpecCall<F, ID>::one(gate)];
-    if (A.compat) {
+    if constexpr (COMPAT) {
         // the reference's leaf rows (`index & 2^k`, src/plonk/mod.rs:714): the LPT leaves of a thread all sit at row 0 of this gate,
         // so they share ONE gate evaluation f(X_p); sum_l w_l f = (sum_l w_l) f exactly -- table LPT holds the term coefficients
         // times the sum of the thread's leaf weights (pg_sum)
