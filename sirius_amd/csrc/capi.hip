@@ -873,11 +873,16 @@ void upload_range(fe_t *dst, const std::vector<Seg> &segs, size_t a, size_t b, h
 
 // the streamed commit of srs_commit_upload / srs_commit_upload_columns (single-device key): chunk j goes up on the key's copy
 // stream while the MSM of chunk j - 1 runs on the caller's stream; `cuts` = chunk boundaries (element offsets, first 0, last n)
+// A key sharded over processes (world > 1; one contiguous source, chunk boundaries multiples of world * 2^10): every chunk brings up and
+// accumulates only THIS rank's block-cyclic stripes of its range -- the same overlap of upload and MSM, 1 / world of both per rank.
 int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const std::vector<size_t> &cut, fe_t *dst, int repr,
                     hipStream_t st, srs_affine *out) {
     const size_t chunks = cut.size() - 1;
+    const uint32_t W = ck->key.world, R = ck->key.rank;
+    const size_t SL = (size_t)1 << msm::STRIPE_LOG;
+    auto local = [&](size_t a, size_t b) { return shard_count(b, R, W) - shard_count(a, R, W); };     // this rank's elements of [a, b)
     size_t per = 0;
-    for (size_t j = 0; j < chunks; ++j) per = std::max(per, cut[j + 1] - cut[j]);
+    for (size_t j = 0; j < chunks; ++j) per = std::max(per, local(cut[j], cut[j + 1]));
     if (!ck->copy_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->copy_stream, hipStreamNonBlocking));
     while (ck->events.size() < 2 * chunks + 2) {
         hipEvent_t e;
@@ -890,7 +895,7 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
     std::vector<bool> launched(chunks, false);
     // every chunk on the 16-bit windows: the chunks fold their buckets into one running set and only the last one is reduced
     bool fold = chunks > 1 && !std::getenv("SRS_COMMIT_NO_FOLD");
-    for (size_t j = 0; j < chunks; ++j) fold = fold && msm::may_fold(ck->key, (uint32_t)(cut[j + 1] - cut[j]));
+    for (size_t j = 0; j < chunks; ++j) fold = fold && local(cut[j], cut[j + 1]) > 0 && msm::may_fold(ck->key, (uint32_t)local(cut[j], cut[j + 1]));
     // ... and with a DEFERRED TAIL (msm::chunked_*): a chunk runs only its sort and k_accum0, the accumulation levels run once for all
     // chunks as a batch; the sort kernels go to a second stream so that they start in the drain of the previous chunk's k_accum0
     const bool deferred = fold && msm::chunked_supported(ck->key, (uint32_t)per, (uint32_t)chunks);
@@ -908,12 +913,30 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
         msm::reserve(ck->key, (uint32_t)per, 1);
     }
     auto upload = [&](size_t j) {
-        upload_range(dst, segs, cut[j], cut[j + 1], ck->copy_stream);
+        if (W == 1) {
+            upload_range(dst, segs, cut[j], cut[j + 1], ck->copy_stream);
+        } else {                             // one strided copy of the rank's stripes of [cut_j, cut_j+1) + the ragged last stripe
+            const fe_t *src = segs[0].src + cut[j];
+            fe_t *d = dst + cut[j];
+            const size_t len = cut[j + 1] - cut[j], full = len / SL;
+            const size_t mine = full > R ? (full - R + W - 1) / W : 0;
+            if (mine)
+                SRS_HIP_CHECK(hipMemcpy2DAsync(d + R * SL, W * SL * sizeof(fe_t), src + R * SL, W * SL * sizeof(fe_t), SL * sizeof(fe_t), mine,
+                                               hipMemcpyHostToDevice, ck->copy_stream));
+            if (len % SL && full % W == R)
+                SRS_HIP_CHECK(hipMemcpyAsync(d + full * SL, src + full * SL, (len % SL) * sizeof(fe_t), hipMemcpyHostToDevice, ck->copy_stream));
+        }
         SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
     };
     auto launch = [&](size_t j) {
         const fe_t *ptr = dst + cut[j];
-        const uint32_t nn = (uint32_t)(cut[j + 1] - cut[j]), base = (uint32_t)cut[j];
+        // sharded: nn local scalars of the chunk, read through the stripe map relative to ptr (cut_j is a multiple of world * 2^10);
+        // their bases start at local index cut_j / world
+        const uint32_t nn = (uint32_t)local(cut[j], cut[j + 1]), base = (uint32_t)(W == 1 ? cut[j] : cut[j] / W);
+        if (nn == 0) {                       // a rank without a stripe in this chunk (ragged end)
+            SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
+            return;
+        }
         if (deferred) {
             SRS_HIP_CHECK(hipStreamWaitEvent(s_sort, ck->events[j], 0));
             msm::chunked_front(ck->key, (uint32_t)j, ptr, nn, base, repr == SRS_REPR_MONT, s_sort, st, ck->events[chunks + 1 + j]);
@@ -949,15 +972,17 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
 }
 
 // chunk boundaries of a streamed commit of n elements; `align`: boundaries are multiples of it (columns are never split)
-std::vector<size_t> commit_cuts(size_t n, size_t align) {
+// `n_eff`: the scalars one device accumulates (n / world on a sharded key): what the number of chunks is chosen from
+std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
     static const size_t want = [] { const char *e = std::getenv("SRS_COMMIT_CHUNKS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
-    size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n >> 20));
+    if (!n_eff) n_eff = n;
+    size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n_eff >> 20));
     chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
     auto up = [&](size_t x) { return std::min(n, (x + align - 1) / align * align); };
     std::vector<size_t> cut(1, 0);
     static const bool tuned_env = std::getenv("SRS_COMMIT_CUTS") != nullptr;
-    const bool tuned = tuned_env && n >= ((size_t)1 << 20);     // the tuning switch leaves small commits (support circuit) alone
-    if (!want && !tuned && chunks < 4 && n >= ((size_t)1 << 19)) {       // 0.5 - 4 M scalars: a quarter first, so that 3/4 of the upload hides behind its MSM
+    const bool tuned = tuned_env && n_eff >= ((size_t)1 << 20);     // the tuning switch leaves small commits (support circuit) alone
+    if (!want && !tuned && chunks < 4 && n_eff >= ((size_t)1 << 19)) {       // 0.5 - 4 M scalars: a quarter first, so that 3/4 of the upload hides behind its MSM
         const size_t c = up(n / 4);
         if (c > 0 && c < n) cut.push_back(c);
     } else if (want || (chunks < 4 && !tuned)) {     // equal pieces
@@ -1001,22 +1026,13 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
     if (ck->shards.empty() && ck->key.world > 1 && n && dev_copy) {
         // sharded (process-per-GPU) key: the rank's kernels -- its partial MSM, its rows of the cross terms, its tiles of the
         // ProtoGalaxy leaves -- read only the rank's block-cyclic stripes of any vector, so only those go up: n * 32 / world
-        // bytes over this GPU's link (one strided copy + the ragged tail); the other stripes of dev_copy are left as they are
-        rc = guarded([&]() -> int {
-            const size_t S = (size_t)1 << msm::STRIPE_LOG, W = ck->key.world, R = ck->key.rank;
-            const fe_t *src = reinterpret_cast<const fe_t *>(scalars_host);
-            fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
-            const size_t full = n / S;                                   // complete stripes
-            const size_t mine = full > R ? (full - R + W - 1) / W : 0;   // complete stripes of this rank
-            if (mine)
-                SRS_HIP_CHECK(hipMemcpy2DAsync(dst + R * S, W * S * sizeof(fe_t), src + R * S, W * S * sizeof(fe_t), S * sizeof(fe_t), mine,
-                                               hipMemcpyHostToDevice, st));
-            if (n % S && full % W == R)                                  // the ragged last stripe is this rank's
-                SRS_HIP_CHECK(hipMemcpyAsync(dst + full * S, src + full * S, (n % S) * sizeof(fe_t), hipMemcpyHostToDevice, st));
-            return SRS_OK;
+        // bytes over this GPU's link, in chunks whose upload overlaps the MSM of the previous chunk (commit_streamed); the other
+        // stripes of dev_copy are left as they are
+        return guarded([&]() -> int {
+            const size_t align = (size_t)ck->key.world << msm::STRIPE_LOG;
+            std::vector<Seg> segs(1, Seg{reinterpret_cast<const fe_t *>(scalars_host), 0, n});
+            return commit_streamed(ck, segs, n, commit_cuts(n, align, n / ck->key.world), reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
         });
-        if (rc) return rc;
-        return srs_commit(ck, dev_copy, n, SRS_SPACE_DEVICE, repr, stream, out);
     }
     if (!ck->shards.empty() || ck->key.world != 1 || n == 0) {
         // multi-device key: every shard pulls its stripes from the host buffer over its own link; sharded (process-per-GPU)

@@ -585,3 +585,18 @@ def test_commit_vs_eip196_known_answers(srs, oracle):
         finally:
             ck.close()
     E.check_adder(oracle, lambda a, b: srs.point_sum(0, np.stack([a, b])), lambda k, p: srs.point_mul(0, k, p), msm)
+
+
+def test_sharded_commit_upload_chunked(srs, oracle):
+    """srs_commit_upload on a process-sharded key streams the rank's stripes in chunks (upload of chunk j + 1 under the MSM of chunk j);
+    the ranks' partial commitments sum to the oracle's, foreign stripes of the device copy stay untouched (tests/test_emu_logic.py)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from test_emu_logic import SHARDED_UPLOAD_CODE
+    code = "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\nimport sirius_amd as S\n" + SHARDED_UPLOAD_CODE
+    for chunks in ("1", "3"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS=chunks), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])

@@ -270,6 +270,41 @@ def test_emu_device_sponge_equals_host_sponge():
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+SHARDED_UPLOAD_CODE = (
+    "import numpy as np, torch\n"
+    "import oracle as O\n"
+    "from conftest import seeded_scalars\n"
+    "dev = 'cuda' if torch.cuda.is_available() else 'cpu'\n"
+    "for cid, n, world in ((0, 9000, 2), (1, 7 * 1024 + 5, 3), (0, 1024, 4), (1, 3000, 2)):\n"
+    "    bases = O.make_bases(cid, 4, n + 3)\n"
+    "    v = seeded_scalars(O, cid, n, 19, 'trace'); want = O.msm(cid, v, bases[:n]); parts = []\n"
+    "    for r in range(world):\n"
+    "        ck = S.CommitmentKey(cid, bases, rank=r, world=world)\n"
+    "        d = torch.full((n, 4), 7, dtype=torch.int64, device=dev)\n"
+    "        parts.append(ck.commit_upload(v, dev_copy=d))\n"
+    "        got = d.cpu().numpy().view(np.uint64)\n"
+    "        for s0 in range(0, n, 1024):                     # the rank's stripes are up, every other stripe is untouched\n"
+    "            blk = got[s0:s0 + 1024]\n"
+    "            assert np.array_equal(blk, v[s0:s0 + 1024]) if (s0 // 1024) % world == r else (blk == 7).all(), (cid, n, world, r, s0)\n"
+    "        ck.close()\n"
+    "    assert np.array_equal(S.point_sum(cid, np.stack(parts)), want), (cid, n, world)\n"
+    "print('ok')\n")
+
+
+def test_emu_sharded_commit_upload_chunked():
+    """srs_commit_upload on a key sharded over processes: the rank's stripes go up in chunks overlapped with their MSM
+    (commit_streamed with world > 1) -- partial commitments of all ranks sum to the oracle's, for 1 / 2 / 3 / 5 chunks, ragged ends,
+    ranks without a stripe in the last chunk; foreign stripes of the device copy stay untouched"""
+    import sys
+    code = ("import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\nfrom sirius_amd import _lib\n"
+            f"_lib.load({EMU_LIB!r})\nimport sirius_amd as S\n" + SHARDED_UPLOAD_CODE)
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    for chunks in ("1", "2", "3", "5"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS=chunks), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_chain_digest_vs_oracle():
     """bench.py's headline chain (reference leaf rows + Poseidon-derived challenges, 2 CycleFold steps) through the emulator's
     kernel logic == the same chain recomputed on the oracle (tests/chain_cases.py); the GPU version is tests/test_chain_gpu.py."""
