@@ -293,13 +293,13 @@ SHARDED_UPLOAD_CODE = (
 
 def test_emu_sharded_commit_upload_chunked():
     """srs_commit_upload on a key sharded over processes: the rank's stripes go up in chunks overlapped with their MSM
-    (commit_streamed with world > 1) -- partial commitments of all ranks sum to the oracle's, for 1 / 2 / 3 / 5 chunks, ragged ends,
+    (commit_streamed with world > 1) -- partial commitments of all ranks sum to the oracle's, for 1 / 3 chunks, ragged ends,
     ranks without a stripe in the last chunk; foreign stripes of the device copy stay untouched"""
     import sys
     code = ("import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\nfrom sirius_amd import _lib\n"
             f"_lib.load({EMU_LIB!r})\nimport sirius_amd as S\n" + SHARDED_UPLOAD_CODE)
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    for chunks in ("1", "2", "3", "5"):
+    for chunks in ("1", "3"):
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS=chunks), capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])
