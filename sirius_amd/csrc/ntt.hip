@@ -20,6 +20,7 @@
 #include "field29.cuh"
 #include "prof.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -382,11 +383,23 @@ void release_plans() {
     g_plans.clear();
 }
 
+// Threads per workgroup of a pass.  The kernels hold ~124 VGPRs, i.e. 4 waves per SIMD: a 1024-thread workgroup is then ALONE on its CU
+// and its load, butterfly and store phases run one after the other with nothing to overlap them.  512 threads (each thread two
+// butterfly groups per stage) let two workgroups share a CU (2 x 68 KiB of LDS) and one computes while the other moves data.
+// SRS_NTT_THREADS=<n> overrides (A/B, profiles/r03_ab_ntt_threads.txt).
+static uint32_t pass_threads(uint32_t tile_elems) {
+    static const uint32_t forced = [] { const char *e = std::getenv("SRS_NTT_THREADS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    uint32_t t = tile_elems >= 4096 ? 1024 : (tile_elems >= 1024 ? 512 : 256);
+    if (tile_elems >= 2048) t = 512;
+    if (forced == 128 || forced == 256 || forced == 512 || forced == 1024) t = std::min(forced, tile_elems >= 1024 ? 1024u : 256u);
+    return t;
+}
+
 template <uint32_t R>
 static void launch_pass(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &pre,
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
-    uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
+    uint32_t threads = pass_threads((1u << R) * COLS);
     if (p.mul29) SRS_LAUNCH((k_ntt_pass<R, true>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
     else SRS_LAUNCH((k_ntt_pass<R, false>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
 }
@@ -394,7 +407,7 @@ template <uint32_t R>
 static void launch_last(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &fin,
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
-    uint32_t threads = ((1u << R) * COLS) >= 4096 ? 1024 : (((1u << R) * COLS) >= 1024 ? 512 : 256);
+    uint32_t threads = pass_threads((1u << R) * COLS);
     if (p.mul29) SRS_LAUNCH((k_ntt_last<R, true>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
     else SRS_LAUNCH((k_ntt_last<R, false>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
 }
