@@ -305,6 +305,28 @@ def test_emu_sharded_commit_upload_chunked():
         assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_emu_commit_pipeline_variants():
+    """The measured-and-shelved pipelines of the streamed commit stay correct (msm::chunked_*, DESIGN.md 4.1): one workspace slot per
+    chunk with per-chunk accumulation levels (SRS_COMMIT_SLOTS=1), and the levels of all chunks once, batched (+ SRS_COMMIT_DEFER=1)."""
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from sirius_amd import _lib\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "import sirius_amd as S, oracle as O\n"
+        "from conftest import seeded_scalars\n"
+        "for cid, n, kind in ((0, 4096, 'trace'), (1, 3000, 'uniform'), (0, 2049, 'uniform')):\n"
+        "    bases = O.make_bases(cid, 4, n + 5); ck = S.CommitmentKey(cid, bases)\n"
+        "    v = seeded_scalars(O, cid, n, 19, kind)\n"
+        "    assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases[:n])), (cid, n)\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    for extra in ({"SRS_COMMIT_SLOTS": "1"}, {"SRS_COMMIT_SLOTS": "1", "SRS_COMMIT_DEFER": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS="3", **extra), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_chain_digest_vs_oracle():
     """bench.py's headline chain (reference leaf rows + Poseidon-derived challenges, 2 CycleFold steps) through the emulator's
     kernel logic == the same chain recomputed on the oracle (tests/chain_cases.py); the GPU version is tests/test_chain_gpu.py."""
