@@ -46,10 +46,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 MSM_BYTES_PER_SCALAR = 96.0    # 64 B base + 32 B scalar, each read once
 NTT_BYTES_PER_ELEMENT = 64.0   # read once + write once
 # ALU side note: the bucket accumulation is integer-multiplier bound.  One mixed addition = 8 products + 2 squares on the
-# 9 x 29-bit limb form = 8 * 171 + 2 * 135 multiplier instructions (v_mad_u64_u32 / v_mul_lo_u32); the chip issues
-# 31.2 T v_mad_u64_u32 per second (profiles/r02_ubench29_gfx950.txt: 50.7 lane-ops/clk/CU x 256 CUs x 2.4 GHz).
+# 9 x 29-bit limb form = 8 * 171 + 2 * 135 multiplier instructions (v_mad_u64_u32 / v_mul_lo_u32), minus the 81 + 9 of the one
+# Montgomery reduction that Y3 = t r - Y1 ppp shares since r03 (Fp29::mul2); the chip issues 31.2 T v_mad_u64_u32 per second
+# (profiles/r02_ubench29_gfx950.txt: 50.7 lane-ops/clk/CU x 256 CUs x 2.4 GHz).
 MAD_ISSUE_PER_S = 31.16e12
-MADD_MULT_INSNS = 8 * 171 + 2 * 135
+MADD_MULT_INSNS = 8 * 171 + 2 * 135 - 90
 
 
 def parse():
@@ -437,8 +438,8 @@ def msm_roofline(S, units_note, nz_madds=None, world=1):
         peak = MAD_ISSUE_PER_S / MADD_MULT_INSNS
         roof["alu"] = {"unit": "G mixed-add/s", "achieved": round(rate / 1e9, 3), "peak": round(peak / 1e9, 3),
                        "frac": round(rate / peak, 4),
-                       "peak_source": "instruction issue: 31.2 T v_mad_u64_u32/s (profiles/r02_ubench29_gfx950.txt) / 1638 multiplier "
-                                      "instructions per mixed addition (8 products x 171 + 2 squares x 135)"}
+                       "peak_source": "instruction issue: 31.2 T v_mad_u64_u32/s (profiles/r02_ubench29_gfx950.txt) / 1548 multiplier "
+                                      "instructions per mixed addition (8 products x 171 + 2 squares x 135 - 90: one shared reduction)"}
     return roof
 
 

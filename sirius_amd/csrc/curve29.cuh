@@ -160,6 +160,59 @@ struct Ec29 {
         return o;
     }
 
+    // The same addition for the bucket accumulation (k_accum0), r03: acc + Q or acc - Q straight from the RAW table entry.
+    //   * the sign is folded into the formula -- r = +-s2 - Y1 -- instead of negating y when the entry is loaded (a negation,
+    //     a carry normalisation, a zero test and a select per gathered point);
+    //   * Y3 = t r - Y1 ppp is ONE double-width sum with ONE Montgomery reduction (Fp29::mul2): 9 reductions per addition, not 10.
+    // Invariant of the accumulator along a chain of these: y NORMALISED (limbs < 2^29), value < 5P; x, zz, zzz as before.
+    SRS_HD static xyzz29_t madd_signed(const xyzz29_t &a, const aff29_t &q, bool neg) {
+        if (is_identity(q)) return a;
+        if (is_identity(a)) {
+            xyzz29_t o;
+            o.x = q.x;
+            o.y = neg ? F::normalize(F::template neg_lazy<1, 0>(q.y)) : q.y;     // P - y: y != 0 on a curve of odd order
+            o.zz = one();
+            o.zzz = o.zz;
+            return o;
+        }
+        f29_t u2 = F::mul(a.zz, q.x);                                           // < 2P norm
+        f29_t s2 = F::mul(a.zzz, q.y);                                          // < 2P norm
+        f29_t p = F::normalize(F::template sub_lazy<10, 0>(u2, a.x));           // u2 - X1 + 10P in (P, 12P) norm
+        f29_t rpos = F::template sub_lazy<6, 0>(s2, a.y);                       //  s2 - Y1 + 6P in (P, 8P), limbs < 3 * 2^29
+        f29_t rneg = F::template neg_lazy<8, 1>(F::add_lazy(s2, a.y));          // -s2 - Y1 + 8P in (P, 8P], limbs < 3 * 2^29
+        f29_t r = F::normalize(F::select(neg, rneg, rpos));
+        f29_t pp = F::sqr(p);                                                   // 144 P^2: < 2P norm
+        f29_t rr = F::sqr(r);                                                   // 64 P^2
+        if (F::is_zero_mod(pp)) {                                               // same x: acc = +-(+-Q)
+            if (F::is_zero_mod(rr)) {
+                aff29_t qq = q;
+                if (neg) qq.y = F::normalize(F::template neg_lazy<1, 0>(q.y));
+                xyzz29_t d = dbl_affine(qq);
+                d.y = F::normalize(d.y);                                        // keep the chain's invariant
+                return d;
+            }
+            return identity();
+        }
+        f29_t ppp = F::mul(p, pp);                                              // 24 P^2
+        f29_t qv = F::mul(a.x, pp);                                             // 18 P^2
+        xyzz29_t o;
+        f29_t sub = F::add_lazy(ppp, F::add_lazy(qv, qv));                      // ppp + 2 qv < 6P, limbs < 3 * 2^29
+        o.x = F::normalize(F::template sub_lazy<7, 2>(rr, sub));                // (P, 9P) norm
+        f29_t t = F::normalize(F::template sub_lazy<10, 0>(qv, o.x));           // qv - X3 + 10P in (P, 12P) norm
+        f29_t yn = F::template neg_lazy<6, 0>(a.y);                             // 6P - Y1 in (P, 6P], limbs < 2^30
+        o.y = F::mul2(t, r, yn, ppp);                                           // 96 P^2 + 12 P^2: < 2P norm
+        o.zz = F::mul(a.zz, pp);
+        o.zzz = F::mul(a.zzz, ppp);
+        return o;
+    }
+    // RAW table entry (8 x u32, R'-form, canonical) -> registers, no sign handling (madd_signed)
+    SRS_HD static aff29_t load_raw(const affine_t &q) {
+        aff29_t o;
+        o.x = F::unpack(q.x);
+        o.y = F::unpack(q.y);
+        return o;
+    }
+
     // ---- the partial sums after level 0 stay in R'-form end to end (msm.hip): in memory a point is the usual 4 x 8 x u32 record
     // holding CANONICAL R'-form coordinates; in registers it is lazy as above
     SRS_HD static xyzz29_t unpack(const xyzz_t &p) {

@@ -149,6 +149,40 @@ struct Fp29 {
         o.v[8] = (uint32_t)acc;
         return o;
     }
+    // (a * b + c * d) / 2^261 mod p with ONE Montgomery reduction: the two products are accumulated column by column into the same
+    // 64-bit sums (27 terms per column instead of 18), which needs the tighter limb bounds  a_i, c_i < 2^30,  b_j, d_j < 2^29
+    // (18 * 2^59 + 9 * 2^58 < 2^64) and  A * B + C * D < 2^261 * P;  returns a value < 2P with limbs < 2^29.
+    // Saves the 81 + 9 multiplier instructions of the second reduction (r03: the Y coordinate of a mixed addition is t r - y ppp).
+    SRS_HD static f29_t mul2(const f29_t &a, const f29_t &b, const f29_t &c, const f29_t &d) {
+        uint64_t acc = 0;
+        uint32_t m[9];
+        f29_t o;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * p(k - i);
+            m[k] = ((uint32_t)acc * INV) & MASK;
+            acc += (uint64_t)m[k] * p(0);
+            acc >>= B;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; ++k) {
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * p(k - i);
+            o.v[k - 9] = (uint32_t)acc & MASK;
+            acc >>= B;
+        }
+        o.v[8] = (uint32_t)acc;
+        return o;
+    }
     SRS_HD static f29_t sqr(const f29_t &a) {
         // the doubled cross products a_i a_j (i < j) are formed once: 45 + 81 multiply-accumulates instead of 81 + 81
         uint64_t acc = 0;

@@ -858,7 +858,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
                 vn = src[j + 1];
                 pn = table[vn & 0x7FFFFFFFu];
             }
-            acc = E29::madd(acc, E29::load(p, (v >> 31) != 0));
+            acc = E29::madd_signed(acc, E29::load_raw(p), (v >> 31) != 0);
             v = vn;
             p = pn;
         }

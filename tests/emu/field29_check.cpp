@@ -3,7 +3,9 @@
 // arithmetic and checks every result with Python integers.
 //   mul F a[9] b[9] | sqr F a[9] | norm F a[9] | add F a[9] b[9] | sub F CP E a[9] b[9] | neg F CP E b[9] | canon F a[9]
 //   unpack F w[8] | pack F a[9]
+//   mul2 F a[9] b[9] c[9] d[9]   : (a b + c d) / 2^261 with one reduction
 //   chain C n (w[16] neg){n}     : identity + n mixed additions of table-form points, lazy in between -> packed XYZZ (32 words)
+//   chains C n (w[16] neg){n}    : the same through madd_signed / load_raw (what k_accum0 runs)
 //   addp C a[32] b[32]           : Ec29::add of two packed partial sums -> packed
 //   dblp C a[32]                 : Ec29::dbl -> packed
 //   tform C w[16]                : table_form of an ABI affine point -> 16 words
@@ -46,6 +48,7 @@ template <class P>
 static void field_op(const std::string &op, std::istringstream &in) {
     using G = Fp29<P>;
     if (op == "mul") { f29_t a = rd9<P>(in), b = rd9<P>(in); pr(G::mul(a, b).v, 9); }
+    else if (op == "mul2") { f29_t a = rd9<P>(in), b = rd9<P>(in), c = rd9<P>(in), d = rd9<P>(in); pr(G::mul2(a, b, c, d).v, 9); }
     else if (op == "sqr") { f29_t a = rd9<P>(in); pr(G::sqr(a).v, 9); }
     else if (op == "norm") { f29_t a = rd9<P>(in); pr(G::normalize(a).v, 9); }
     else if (op == "add") { f29_t a = rd9<P>(in), b = rd9<P>(in); pr(G::add_lazy(a, b).v, 9); }
@@ -60,7 +63,8 @@ static void field_op(const std::string &op, std::istringstream &in) {
         bool ok = try_sub<P, 1, 0>(cp, e, neg, a, b) || try_sub<P, 2, 0>(cp, e, neg, a, b) || try_sub<P, 3, 0>(cp, e, neg, a, b) ||
                   try_sub<P, 5, 1>(cp, e, neg, a, b) || try_sub<P, 6, 2>(cp, e, neg, a, b) || try_sub<P, 7, 2>(cp, e, neg, a, b) ||
                   try_sub<P, 8, 0>(cp, e, neg, a, b) || try_sub<P, 10, 0>(cp, e, neg, a, b) || try_sub<P, 13, 0>(cp, e, neg, a, b) ||
-                  try_sub<P, 31, 0>(cp, e, neg, a, b) || try_sub<P, 3, 2>(cp, e, neg, a, b) || try_sub<P, 12, 2>(cp, e, neg, a, b);
+                  try_sub<P, 31, 0>(cp, e, neg, a, b) || try_sub<P, 3, 2>(cp, e, neg, a, b) || try_sub<P, 12, 2>(cp, e, neg, a, b) ||
+                  try_sub<P, 6, 0>(cp, e, neg, a, b) || try_sub<P, 8, 1>(cp, e, neg, a, b);
         if (!ok) std::printf("unsupported\n");
     } else std::printf("unsupported\n");
 }
@@ -70,7 +74,7 @@ static void curve_op(const std::string &op, std::istringstream &in) {
     using E = Ec29<C>;
     auto rdp = [&](xyzz_t &p) { p.x = rd8(in); p.y = rd8(in); p.zz = rd8(in); p.zzz = rd8(in); };
     auto prp = [&](const xyzz_t &p) { uint32_t w[32]; std::memcpy(w, &p, sizeof p); pr(w, 32); };
-    if (op == "chain") {
+    if (op == "chain" || op == "chains") {
         unsigned n;
         in >> std::dec >> n;
         xyzz29_t acc = E::identity();
@@ -80,7 +84,7 @@ static void curve_op(const std::string &op, std::istringstream &in) {
             q.y = rd8(in);
             unsigned neg;
             in >> std::dec >> neg;
-            acc = E::madd(acc, E::load(q, neg != 0));
+            acc = op == "chain" ? E::madd(acc, E::load(q, neg != 0)) : E::madd_signed(acc, E::load_raw(q), neg != 0);
         }
         prp(E::pack(acc));
     } else if (op == "addp") {

@@ -92,6 +92,18 @@ def test_products_at_the_bounds(calc, name, p):
         a, b = rnd.randrange(12 * p), rnd.randrange(12 * p)
         r = calc(f"mul {name} {hx(limbs29(a, 1, rnd))} {hx(limbs29(b, 1, rnd))}")
         assert val(r) < 2 * p and val(r) % p == a * b * inv % p
+    # mul2: (a b + c d) / 2^261 with ONE reduction -- a, c with limbs < 2^30, b, d normalised, at the bounds madd_signed uses
+    # (t < 12P, r < 8P; 6P - y <= 6P, ppp < 2P) and at the extreme all-ones limb patterns
+    quads = [(12 * p - 1, 8 * p - 1, 6 * p, 2 * p - 1), (0, 0, 0, 0), (p - 1, p - 1, p - 1, p - 1), (12 * p - 1, 8 * p - 1, 0, 0)]
+    quads += [(rnd.randrange(12 * p), rnd.randrange(8 * p), rnd.randrange(6 * p + 1), rnd.randrange(2 * p)) for _ in range(300)]
+    for a, b, c, d in quads:
+        assert a * b + c * d < R261 * p
+        for wa, wc in ((0, 0), (1, 1), (0, 1), (1, 0)):
+            r = calc(f"mul2 {name} {hx(limbs29(a, wa, rnd))} {hx(limbs29(b))} {hx(limbs29(c, wc, rnd))} {hx(limbs29(d))}")
+            assert all(v < (1 << 29) for v in r[:8]) and val(r) < 2 * p and val(r) % p == (a * b + c * d) * inv % p, (a, b, c, d, wa, wc)
+    ones30, ones29 = [(1 << 30) - 1] * 8 + [(1 << 22) - 1], [(1 << 29) - 1] * 8 + [(1 << 21) - 1]      # every limb at its bound
+    r = calc(f"mul2 {name} {hx(ones30)} {hx(ones29)} {hx(ones30)} {hx(ones29)}")
+    assert val(r) % p == 2 * val(ones30) * val(ones29) * inv % p
 
 
 @pytest.mark.parametrize("name,p", FIELDS)
@@ -106,7 +118,7 @@ def test_lazy_sums_differences_and_reductions(calc, name, p):
         r = calc(f"add {name} {hx(limbs29(a, 1, rnd))} {hx(limbs29(b, 1, rnd))}")
         assert val(r) == a + b
     # a - b + CP p with the (CP, E) pairs of curve29.cuh and the sweep emitter; b below CP p with limbs < 2^(29 + E)
-    for cp, e in ((1, 0), (2, 0), (3, 0), (5, 1), (6, 2), (7, 2), (8, 0), (10, 0), (13, 0), (31, 0), (3, 2), (12, 2)):
+    for cp, e in ((1, 0), (2, 0), (3, 0), (5, 1), (6, 2), (7, 2), (8, 0), (10, 0), (13, 0), (31, 0), (3, 2), (12, 2), (6, 0), (8, 1)):
         for _ in range(40):
             b = rnd.choice([0, 1, p - 1, cp * p - 1, rnd.randrange(cp * p), max(0, cp * p - (1 << e) * (1 << 232))])
             lb = limbs29(b, e, rnd)
@@ -159,9 +171,12 @@ def test_group_law_on_the_lazy_form(calc, cname, cid):
     G = cv.g
     pts = [cv.mul(rnd.randrange(1, cv.q), G) for _ in range(12)]
 
-    def chain(seq):                                         # seq of (point, negate)
-        line = f"chain {cname} {len(seq)} " + " ".join(hx(tform(Q)) + f" {int(n)}" for Q, n in seq)
-        return calc(line)
+    def chain(seq):                                         # seq of (point, negate): Ec29::madd(load(..)) AND madd_signed(load_raw(..))
+        body = f"{cname} {len(seq)} " + " ".join(hx(tform(Q)) + f" {int(n)}" for Q, n in seq)
+        a, b = calc("chain " + body), calc("chains " + body)
+        if a != b:                                          # packed records are canonical except for the scale of (zz, zzz): compare points
+            assert point_of(a) == point_of(b), seq
+        return b
     # plain sums, long enough for the lazy bounds to reach their steady state
     seq = [(rnd.choice(pts), rnd.random() < 0.5) for _ in range(40)]
     want = (0, 0)
