@@ -642,7 +642,7 @@ def main():
         scalars_per_step = pri.w["num_advice"] * pri.rows + (3 + 2) * sup.rows
         if D.rank == 0:
             nz = sum(nonzero_rows(torch.from_numpy(hb.array.view(np.int64))) for hb in pri.host_W) / 2.0 + nonzero_rows(sup.inW) + sup.nz_terms
-            roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 6 chunks + the support circuit's 5*2^15 per step",
+            roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 7 chunks + the support circuit's 5*2^15 per step",
                                 16.0 * nz * args.steps / D.world, D.world)
             prof = {}
             for name in ("pg_F_leaves", "pg_G_leaves", "rowprog_cross_terms"):

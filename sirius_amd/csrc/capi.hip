@@ -991,9 +991,10 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
     } else {                             // a SHORT first chunk (its upload is the only one nothing overlaps), growing ones after it
         // (measured on the 12 * 2^20 witness, profiles/r02_commit_cuts.txt: six chunks growing ~1.5x beat four -- the MSM left to do
         // after the last byte has arrived is what counts once the per-chunk fixed cost is down to ~0.4 ms)
-        // r03: re-tuned once the per-chunk costs had changed (a chunk may grow ~1.3x + 0.4 M scalars over its predecessor before the
-        // chip waits for its upload: profiles/r03_ab_accum0_variants.txt) -- was {0.045, 0.15, 0.32, 0.53, 0.77}
-        std::vector<double> frac = {0.024, 0.089, 0.208, 0.399, 0.677};
+        // r03: re-tuned twice as the per-chunk costs fell (profiles/r03_ab_accum0_variants.txt, r03_ab_commit_cuts.txt).  With the
+        // faster accumulation the chip keeps up with the uploads until the last chunk, so what counts is the MSM left once the last
+        // byte has arrived: seven chunks, the last one 26 % -- was {0.045, 0.15, 0.32, 0.53, 0.77}, then {0.024, 0.089, 0.208, 0.399, 0.677}
+        std::vector<double> frac = {0.02, 0.07, 0.16, 0.30, 0.50, 0.74};
         if (const char *e = std::getenv("SRS_COMMIT_CUTS")) {      // tuning: cumulative fractions, e.g. "0.1,0.4"
             frac.clear();
             for (const char *q = e; *q;) {
