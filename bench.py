@@ -219,6 +219,21 @@ class SangriaSide:
             c = self.ck.commit(self.inW)
         self.inC = D.combine(self.curve, c)
 
+    def prove_incoming(self, S, ro_challenge=False):
+        """The freshly synthesised trace (host) is uploaded, committed and folded by ONE library call: its commitment and the
+        cross terms' come out of the same batched MSM (srs_sangria_prove_incoming; one process only)."""
+        self.settle()
+        ro = None
+        if ro_challenge:
+            ro = self.ro.reset()
+            for pt in (self.accCW, self.accCE):
+                ro.absorb_point(self.curve, pt)
+        pr = S.sangria_prove(self.ck, self.S, self.u1c, self.u1u, self.accW, self.u2c, self.inW, self.accE, self.accCW, self.accCE,
+                             r=None if ro_challenge else self.r, ro=ro, incoming=True, incoming_host=self.host_W.array)
+        self.r, self.inC = pr["r"], pr["incoming_commitment"]
+        self.pending = (pr["E_commitment"], pr["W_commitment"])
+        self._keep = pr
+
     def prove(self, S, D, ro_challenge=False, count_nonzero=False):
         """VanillaFS::prove hot path (src/nifs/sangria/mod.rs:253-277)."""
         self.settle()
@@ -370,11 +385,17 @@ def PGint(fe):
     return from_mont(0, fe)
 
 
+SPLIT_SUPPORT = os.environ.get("SRS_BENCH_SPLIT_SUPPORT", "0") == "1"      # A/B: the support trace committed, then folded (two MSM chains)
+
+
 def cyclefold_step(S, D, pri, sup, ro=False, count=False):
     """CyclefoldIVC::next hot path (src/ivc/cyclefold/incrementally_verifiable_computation/mod.rs:210-335)."""
     pri.prove(S, D, ro)                       # A
-    sup.witness_commit(S, D, True)            # B: support-circuit trace ...
-    sup.prove(S, D, ro, count)                #    ... folded into the support accumulator
+    if D.world == 1 and not count and not SPLIT_SUPPORT:
+        sup.prove_incoming(S, ro)             # B: support-circuit trace committed + folded, one batched MSM (srs_sangria_prove_incoming)
+    else:
+        sup.witness_commit(S, D, True)        # B: support-circuit trace ...
+        sup.prove(S, D, ro, count)            #    ... folded into the support accumulator
     pri.witness_commit(S, D)                  # C
 
 

@@ -404,6 +404,21 @@ int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_
                       srs_fe *E, void *stream, srs_fe *r_io, srs_fe *const *T_dev, srs_affine *cross_term_commits,
                       const srs_affine *W_commitments, const srs_affine *E_commitment, srs_affine *folded_commitments, uint64_t *jobs);
 
+/* The same prove for an incoming trace that has just been synthesised and is NOT committed yet -- CyclefoldIVC::next's support
+ * circuit (src/ivc/cyclefold/incrementally_verifiable_computation/mod.rs:255-300: the trace is generated, committed by
+ * run_sps_protocol (src/plonk/mod.rs:441-447) and folded at once).  The reference commits it and then, inside prove, the cross
+ * terms: two multi-exponentiations one after the other.  Neither depends on the other's result, so here they are ONE batched MSM
+ * over d+1 vectors (W2 || T_0..T_{d-1}): W2_host (may be NULL when W2 already holds the trace) is uploaded into the device
+ * vector W2 on `stream`, the cross terms are evaluated, all d+1 commitments come out of one chain of launches.
+ * W_commitments[0] = U1's commitment (in), W_commitments[1] = the incoming trace's commitment (OUT).  Transcript: `ro` holds
+ * pp_digest and U1; the call absorbs W_commitments[1], then u2_tail[0..n_u2_tail) (the rest of U2 -- its instances and
+ * challenges -- as elements of the oracle's field, Montgomery form), then the cross-term commitments, and squeezes r: the same
+ * absorb order as generate_challenge (sangria/mod.rs:162-179).  Everything else as srs_sangria_prove. */
+int srs_sangria_prove_incoming(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, srs_fe *W2,
+                               const srs_fe *W2_host, const srs_fe *u2_tail, size_t n_u2_tail, srs_fe *E, void *stream, srs_fe *r_io,
+                               srs_fe *const *T_dev, srs_affine *cross_term_commits, srs_affine *W_commitments, const srs_affine *E_commitment,
+                               srs_affine *folded_commitments, uint64_t *jobs);
+
 /* ---- ProtoGalaxy NIFS polynomials (src/nifs/protogalaxy/poly/mod.rs), bn256::Fr structures only ----
  * Leaves f_i = S.gates[i / 2^k] at row(i) (get_evaluate_witness_fn, src/plonk/mod.rs:683-718), i < n =
  * (gates * 2^k).next_power_of_two(), zero beyond gates * 2^k; pow_i(c) = prod_{b in bits(i)} c_b.

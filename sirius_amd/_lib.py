@@ -107,6 +107,8 @@ def _prototypes():
         "srs_pg_beta_stroke": (i32, [vp, sz, vp, vp, vp]),
         "srs_pg_prove": (i32, [vp, vp, vp, sz, vp, C.POINTER(vp), C.POINTER(vp), sz, sz, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "srs_sangria_prove": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(C.c_uint64)]),
+        "srs_sangria_prove_incoming": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, sz, vp, vp, vp, C.POINTER(vp), vp, vp, vp, vp,
+                                             C.POINTER(C.c_uint64)]),
         "srs_pg_compute_F": (i32, [vp, vp, sz, vp, vp, vp, sz, i32, i32, vp, vp]),
         "srs_pg_compute_G": (i32, [vp, vp, sz, C.POINTER(vp), C.POINTER(vp), sz, sz, i32, i32, vp, vp]),
         "srs_pg_compute_K_from_G": (i32, [vp, sz, vp, sz, u32, vp, vp]),

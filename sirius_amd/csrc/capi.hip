@@ -2182,11 +2182,16 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
 
 // VanillaFS::prove (src/nifs/sangria/mod.rs:253-277) as ONE call on device-resident traces: cross terms + their commitments, the
 // challenge, the witness / error folds (in place) and the instance fold (host workers, joined with srs_job_wait).
-int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, const srs_fe *W2,
-                      srs_fe *E, void *stream, srs_fe *r_io, srs_fe *const *T_dev, srs_affine *cross_term_commits,
-                      const srs_affine *W_commitments /* [2]: U1, U2 */, const srs_affine *E_commitment, srs_affine *folded_commitments /* [2]: W, E */,
-                      uint64_t *jobs /* [2] */) {
-    if (!S || !ck || !W1 || !W2 || !E || !r_io || !T_dev || !cross_term_commits || !W_commitments || !E_commitment || !folded_commitments || !jobs)
+// VanillaFS::prove on device-resident traces.  `incoming`: the incoming trace is still on the host (W2_host -> W2, uploaded
+// here), its commitment is not known yet and is computed IN THE SAME batched MSM as the cross terms' (one chain of MSM
+// launches for d+1 vectors instead of two chains), written to W_commitments[1] and absorbed -- followed by `u2_tail` -- before
+// the cross-term commitments.
+static int sangria_prove_impl(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, srs_fe *W2,
+                              const srs_fe *W2_host, const srs_fe *u2_tail, size_t n_u2_tail, srs_fe *E, void *stream, srs_fe *r_io,
+                              srs_fe *const *T_dev, srs_affine *cross_term_commits, srs_affine *W_commitments, const srs_affine *E_commitment,
+                              srs_affine *folded_commitments, uint64_t *jobs, bool incoming) {
+    if (!S || !ck || !W1 || !W2 || !E || !r_io || !T_dev || !cross_term_commits || !W_commitments || !E_commitment || !folded_commitments || !jobs ||
+        (n_u2_tail && !u2_tail))
         return fail(SRS_ERR_INVALID, "srs_sangria_prove: bad argument");
     const int curve = ck->key.curve, sf = srs_scalar_field_of(curve);
     if (ro && ro->h->field != (curve == SRS_CURVE_BN256 ? SRS_FIELD_FQ : SRS_FIELD_FR))
@@ -2194,8 +2199,48 @@ int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_
     if (rowprog::shard_world(S->s) > 1 || ck->key.world > 1)   // partial cross-term commitments: the challenge needs the exchanged ones
         return fail(SRS_ERR_INVALID, "srs_sangria_prove: structure / key is sharded over processes; use the step-wise calls and add the ranks' partial commitments");
     const size_t d = srs_structure_num_cross_terms(S), rows = rowprog::rows(S->s), wlen = rowprog::num_witness_columns(S->s) * rows;
-    int rc = srs_commit_cross_terms(S, ck, W1, W2, challenges, n_challenges, SRS_SPACE_DEVICE, stream, T_dev, cross_term_commits);
-    if (rc) return rc;
+    int rc;
+    if (!incoming) {
+        rc = srs_commit_cross_terms(S, ck, W1, W2, challenges, n_challenges, SRS_SPACE_DEVICE, stream, T_dev, cross_term_commits);
+        if (rc) return rc;
+    } else {
+        if (n_challenges && !challenges) return fail(SRS_ERR_INVALID, "srs_sangria_prove_incoming: bad argument");
+        if (wlen > ck->key.global_len || rows > ck->key.global_len)
+            return fail(SRS_ERR_TOO_LONG_INPUT, "Can't commit too long input: input len: " + std::to_string(std::max(wlen, rows)) +
+                                                    ", but limit is " + std::to_string(ck->key.global_len));
+        rc = ensure_device();
+        if (rc) return rc;
+        std::vector<affine_t> cm(d + 1);
+        rc = guarded([&]() -> int {
+            hipStream_t st = (hipStream_t)stream;
+            if (W2_host) SRS_HIP_CHECK(hipMemcpyAsync(W2, W2_host, wlen * sizeof(fe_t), hipMemcpyHostToDevice, st));
+            if (d) {
+                std::vector<fe_t *> dT(d);
+                for (size_t k = 0; k < d; ++k) dT[k] = reinterpret_cast<fe_t *>(T_dev[k]);
+                std::string err;
+                int erc = rowprog::evaluate(S->s, 0, reinterpret_cast<const fe_t *>(W1), reinterpret_cast<const fe_t *>(W2),
+                                            reinterpret_cast<const fe_t *>(challenges), n_challenges, dT.data(), st, err, false);
+                if (erc) return fail(erc, "srs_sangria_prove_incoming: " + err);
+            }
+            std::vector<const srs_fe *> v(d + 1);
+            std::vector<size_t> nn(d + 1, rows);
+            v[0] = W2;
+            nn[0] = wlen;
+            for (size_t k = 0; k < d; ++k) v[k + 1] = T_dev[k];
+            return srs_commit_batch(ck, v.data(), nn.data(), d + 1, SRS_SPACE_DEVICE, SRS_REPR_MONT, stream, reinterpret_cast<srs_affine *>(cm.data()));
+        });
+        if (rc) return rc;
+        std::memcpy(&W_commitments[1], &cm[0], sizeof(affine_t));
+        if (d) std::memcpy(cross_term_commits, &cm[1], d * sizeof(affine_t));
+        if (ro) {   // U2 enters the transcript here: its W commitment, then whatever else the caller's U2 carries
+            rc = srs_poseidon_absorb_point(ro, curve, &W_commitments[1]);
+            if (rc) return rc;
+            if (n_u2_tail) {
+                rc = srs_poseidon_absorb_field(ro, u2_tail, n_u2_tail);
+                if (rc) return rc;
+            }
+        }
+    }
     fe_t r;
     std::memcpy(&r, r_io, 32);
     if (ro) {       // generate_challenge (:162-179): the caller has absorbed pp_digest, U1, U2; the commitments and the squeeze happen here
@@ -2221,6 +2266,22 @@ int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_
     rc = srs_point_lincomb_async(curve, E_commitment, cross_term_commits, rp.data(), d, SRS_REPR_MONT, &folded_commitments[1], &jobs[1]);
     if (rc) (void)srs_job_wait(jobs[0]);     // never leave job 0 writing into folded_commitments[0] after an error return
     return rc;
+}
+
+int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, const srs_fe *W2,
+                      srs_fe *E, void *stream, srs_fe *r_io, srs_fe *const *T_dev, srs_affine *cross_term_commits,
+                      const srs_affine *W_commitments /* [2]: U1, U2 */, const srs_affine *E_commitment, srs_affine *folded_commitments /* [2]: W, E */,
+                      uint64_t *jobs /* [2] */) {
+    return sangria_prove_impl(S, ck, ro, challenges, n_challenges, W1, const_cast<srs_fe *>(W2), nullptr, nullptr, 0, E, stream, r_io, T_dev,
+                              cross_term_commits, const_cast<srs_affine *>(W_commitments), E_commitment, folded_commitments, jobs, false);
+}
+
+int srs_sangria_prove_incoming(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_fe *challenges, size_t n_challenges, srs_fe *W1, srs_fe *W2,
+                               const srs_fe *W2_host, const srs_fe *u2_tail, size_t n_u2_tail, srs_fe *E, void *stream, srs_fe *r_io,
+                               srs_fe *const *T_dev, srs_affine *cross_term_commits, srs_affine *W_commitments /* [2]: U1 in, U2 out */,
+                               const srs_affine *E_commitment, srs_affine *folded_commitments /* [2]: W, E */, uint64_t *jobs /* [2] */) {
+    return sangria_prove_impl(S, ck, ro, challenges, n_challenges, W1, W2, W2_host, u2_tail, n_u2_tail, E, stream, r_io, T_dev, cross_term_commits,
+                              W_commitments, E_commitment, folded_commitments, jobs, true);
 }
 
 int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n, int space, void *stream) {

@@ -295,11 +295,16 @@ class VanillaFS:
         return terms, commits
 
 
-def sangria_prove(ck, S, U1_challenges, U1_u, W1, U2_challenges, W2, E, W_commitments, E_commitment, r=None, ro=None):
+def sangria_prove(ck, S, U1_challenges, U1_u, W1, U2_challenges, W2, E, W_commitments, E_commitment, r=None, ro=None,
+                  incoming=False, incoming_host=None, u2_tail=None):
     """`VanillaFS::prove` (src/nifs/sangria/mod.rs:253-277) as one library call (srs_sangria_prove) on device-resident traces:
     W1 and E are folded IN PLACE.  r: the challenge (when `ro` is None) -- otherwise squeezed from `ro` (a PoseidonHash over the
     curve's base field that has absorbed pp_digest, U1, U2) after the cross-term commitments.
-    -> dict(terms, commits, r, W_commitment: PendingPoint, E_commitment: PendingPoint)."""
+    incoming=True (srs_sangria_prove_incoming): W2 is a freshly synthesised trace without a commitment -- `incoming_host` (if
+    given) is uploaded into W2, its commitment is computed in the same batched MSM as the cross terms' and returned as
+    `incoming_commitment`; W_commitments = U1's only; `ro` holds pp_digest and U1, the call absorbs the new commitment, `u2_tail`
+    (oracle-field elements) and the cross-term commitments.
+    -> dict(terms, commits, r, W_commitment: PendingPoint, E_commitment: PendingPoint[, incoming_commitment])."""
     from .commitment import PendingPoint
     ch = VanillaFS.cross_term_challenges(U1_challenges, U1_u, U2_challenges, S.field)
     a1, sp1, n1, k1 = _buf(W1, 4)
@@ -311,15 +316,30 @@ def sangria_prove(ck, S, U1_challenges, U1_u, W1, U2_challenges, W2, E, W_commit
     tp = (C.c_void_p * max(d, 1))(*[(t.data_ptr() if _is_torch(t) else t.ctypes.data) for t in terms])
     commits = np.zeros((d, 8), dtype=np.uint64)
     rr = np.zeros(4, dtype=np.uint64) if r is None else np.ascontiguousarray(r, dtype=np.uint64).reshape(4).copy()
-    wc = np.ascontiguousarray(W_commitments, dtype=np.uint64).reshape(2, 8)
+    wc = np.zeros((2, 8), dtype=np.uint64)
+    wc[: (1 if incoming else 2)] = np.ascontiguousarray(W_commitments, dtype=np.uint64).reshape(-1, 8)[: (1 if incoming else 2)]
     ec = np.ascontiguousarray(E_commitment, dtype=np.uint64).reshape(8)
     folded = np.zeros((2, 8), dtype=np.uint64)
     jobs = (C.c_uint64 * 2)()
     lib = L.lib()
-    L.check(lib.srs_sangria_prove(S._h, ck._h, None if ro is None else ro._h, ch.ctypes.data, ch.shape[0], a1, a2, ae, _stream(), rr.ctypes.data, tp,
-                                  commits.ctypes.data, wc.ctypes.data, ec.ctypes.data, folded.ctypes.data, jobs))
-    return dict(terms=terms, commits=commits, r=rr, W_commitment=PendingPoint(jobs[0], folded[0], lib), E_commitment=PendingPoint(jobs[1], folded[1], lib),
-                _keep=(folded, wc, ec))
+    roh = None if ro is None else ro._h
+    if incoming:
+        hw = None
+        if incoming_host is not None:
+            hw = np.ascontiguousarray(incoming_host, dtype=np.uint64).reshape(-1, 4)
+            assert hw.shape[0] == n2
+        tail = None if u2_tail is None else np.ascontiguousarray(u2_tail, dtype=np.uint64).reshape(-1, 4)
+        L.check(lib.srs_sangria_prove_incoming(S._h, ck._h, roh, ch.ctypes.data, ch.shape[0], a1, a2, None if hw is None else hw.ctypes.data,
+                                               None if tail is None else tail.ctypes.data, 0 if tail is None else tail.shape[0], ae, _stream(),
+                                               rr.ctypes.data, tp, commits.ctypes.data, wc.ctypes.data, ec.ctypes.data, folded.ctypes.data, jobs))
+    else:
+        L.check(lib.srs_sangria_prove(S._h, ck._h, roh, ch.ctypes.data, ch.shape[0], a1, a2, ae, _stream(), rr.ctypes.data, tp,
+                                      commits.ctypes.data, wc.ctypes.data, ec.ctypes.data, folded.ctypes.data, jobs))
+    out = dict(terms=terms, commits=commits, r=rr, W_commitment=PendingPoint(jobs[0], folded[0], lib), E_commitment=PendingPoint(jobs[1], folded[1], lib),
+               _keep=(folded, wc, ec))
+    if incoming:
+        out["incoming_commitment"] = wc[1].copy()
+    return out
 
 
 class RelaxedPlonkWitness:

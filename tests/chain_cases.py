@@ -12,9 +12,11 @@ import random
 import numpy as np
 
 
-def product_chain(S, k, log_key, ks, steps, emu=False, compat=True, ro=True):
-    """bench.py's chain objects, `steps` CycleFold steps -> state_digest (hex)."""
+def product_chain(S, k, log_key, ks, steps, emu=False, compat=True, ro=True, split_support=False):
+    """bench.py's chain objects, `steps` CycleFold steps -> state_digest (hex).  split_support: the support trace committed and
+    then folded by two calls (the reference's call order) instead of srs_sangria_prove_incoming's single batched MSM."""
     import bench
+    bench.SPLIT_SUPPORT = bool(split_support)
     D = bench.Dist(argparse.Namespace(emu=emu, gpus=1, dist_backend="nccl"))
     pri, sup, _ = bench.build_cyclefold(S, D, k, log_key, compat, ks)
     for _ in range(steps):

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("k,log_key,ks,steps", [(10, 14, 8, 2), (12, 16, 9, 3)])
 def test_cyclefold_chain_digest_vs_oracle(srs, oracle, k, log_key, ks, steps):
     import chain_cases as CC
-    assert CC.product_chain(srs, k, log_key, ks, steps) == CC.oracle_chain(oracle, srs, k, log_key, ks, steps)
+    want = CC.oracle_chain(oracle, srs, k, log_key, ks, steps)
+    assert CC.product_chain(srs, k, log_key, ks, steps) == want                           # support trace: srs_sangria_prove_incoming
+    assert CC.product_chain(srs, k, log_key, ks, steps, split_support=True) == want       # commit, then srs_sangria_prove
 
 
 def test_cyclefold_chain_true_rows_differs(srs, oracle):

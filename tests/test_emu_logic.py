@@ -338,6 +338,8 @@ def test_emu_chain_digest_vs_oracle():
         "import sirius_amd as S, oracle as O, chain_cases as CC\n"
         "a = CC.product_chain(S, 4, 8, 3, 2, emu=True); b = CC.oracle_chain(O, S, 4, 8, 3, 2)\n"
         "assert a == b, (a, b)\n"
+        "c = CC.product_chain(S, 4, 8, 3, 2, emu=True, split_support=True)\n"
+        "assert c == b, (c, b)\n"
         "print('ok')\n")
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
