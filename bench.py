@@ -303,6 +303,13 @@ class PgPrimary:
         assert n <= (1 << log_key)
         self.ck = S.CommitmentKey.setup_synthetic(S.CURVE_BN256, 1 << log_key, seed=42, rank=D.rank, world=D.world)
         self.accW, self.inW = up(D, w["W1"]), up(D, w["W2"])
+        # fold_witness deferred (DEFER_FOLD): nothing reads the folded witness before the next prove, so the 1.2 GB pass is queued on
+        # a second stream when the next witness starts to come up (the device waits for PCIe there) -- into a SECOND incoming buffer
+        self.inW_next = up(D, w["W2"]) if DEFER_FOLD and not self.sharded else None
+        self.lag, self.side = None, None
+        if self.inW_next is not None and self.inW.is_cuda:
+            import torch
+            self.side = torch.cuda.Stream()
         rng = np.random.default_rng(77)
         self.host_W = [pinned_copy(S, w["W2"]), pinned_copy(S, trace_like(rng, n))]      # two witnesses, alternating
         rnd = random.Random(3)
@@ -336,10 +343,38 @@ class PgPrimary:
         if self.sharded:
             return self.prove_sharded(S, D, ro, m([delta])[0], alpha, gamma)
         # one library call (srs_pg_prove): F -> alpha -> betas' -> G -> K -> gamma -> L(gamma), e, fold_witness
-        pr = PG.prove(ctx, self.betas, m([delta])[0], [self.accW, self.inW], ro=ro,
-                      alpha=None if ro else m([alpha])[0], gamma=None if ro else m([gamma])[0], reference_compat=self.compat)
-        self.e, self.accW, self.betas = pr["e"], pr["W"], pr["betas_stroke"]
+        defer = self.inW_next is not None
+        self.fold_done()
+        pr = PG.prove(ctx, self.betas, m([delta])[0], [self.accW, self.inW], ro=ro, alpha=None if ro else m([alpha])[0],
+                      gamma=None if ro else m([gamma])[0], reference_compat=self.compat, fold=not defer)
+        self.e, self.betas = pr["e"], pr["betas_stroke"]
+        if defer:
+            self.lag = pr["lagrange"]
+        else:
+            self.accW = pr["W"]
         self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), pr["lagrange"][:2])   # fold_instance
+
+    def fold_start(self):
+        """the deferred fold_witness: accW <- L_0(gamma) accW + L_1(gamma) inW, on the side stream"""
+        if self.lag is None:
+            return
+        import torch
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.PG.fold_witness(0, [self.accW, self.inW], self.lag, out=self.accW)
+        else:
+            self.PG.fold_witness(0, [self.accW, self.inW], self.lag, out=self.accW)
+        self.lag = None
+        self.fold_pending = True
+
+    def fold_done(self):
+        """whatever reads accW next (the next prove, the digest) comes after the deferred fold"""
+        self.fold_start()
+        if getattr(self, "fold_pending", False) and self.side is not None:
+            import torch
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.fold_pending = False
 
     def prove_sharded(self, S, D, ro, delta_m, alpha, gamma):
         """The same prove with the leaves sharded over the ranks: every rank evaluates the tiles of ITS stripes, the partial
@@ -372,8 +407,14 @@ class PgPrimary:
         self.step_no += 1
         if D.world > 1 and not self.sharded:          # stripes of the columns are not key stripes: the whole vector goes up
             import torch
+            self.fold_done()                          # (a deferred fold still reads the old incoming trace)
             self.inW.copy_(torch.from_numpy(hb.array.view(np.int64)))
             self.inC = D.combine(S.CURVE_BN256, self.ck.commit(self.inW))
+            return
+        if self.inW_next is not None:                 # the fold of the PREVIOUS incoming trace runs under this upload, which lands in the other buffer
+            self.fold_start()
+            self.inC = D.combine(S.CURVE_BN256, self.ck.commit_upload(hb.array, dev_copy=self.inW_next))
+            self.inW, self.inW_next = self.inW_next, self.inW
             return
         self.inC = D.combine(S.CURVE_BN256, self.ck.commit_upload(hb.array, dev_copy=self.inW))
         if self.sharded:                              # rows the rank's leaf tiles read beyond its stripes (row 0 under reference_compat)
@@ -385,6 +426,7 @@ def PGint(fe):
     return from_mont(0, fe)
 
 
+DEFER_FOLD = os.environ.get("SRS_BENCH_DEFER_FOLD", "1") == "1"             # A/B: the primary's fold_witness under the next witness upload
 SPLIT_SUPPORT = os.environ.get("SRS_BENCH_SPLIT_SUPPORT", "0") == "1"      # A/B: the support trace committed, then folded (two MSM chains)
 
 

@@ -443,7 +443,10 @@ int srs_pg_context_new(const srs_structure *S, size_t traces_len, srs_pg_context
  * random oracle `ro` (over bn256::Fr, already holding that transcript) alpha = ro.absorb(poly_F).squeeze(MAX_BITS = 255) and
  * gamma = ro.absorb(poly_K).squeeze(255) are derived inside (:424-427,445-448) and returned in alpha_gamma[0..1]; with ro = NULL
  * alpha_gamma holds them on entry.  Outputs: poly_F[fft_points_count_F], poly_K[2^fft_log_domain_size_K], betas_stroke[betas_count],
- * e, lagrange[n_instances] = L_j(gamma) (for fold_instance, which stays with the caller), W_folded (device, stream-ordered). */
+ * e, lagrange[n_instances] = L_j(gamma) (for fold_instance, which stays with the caller), W_folded (device, stream-ordered).
+ * W_folded = NULL leaves fold_witness to the caller (srs_fold_lincomb with `lagrange`): nothing in the rest of an IVC step reads
+ * the folded witness before the next prove, so the 3-vector pass can be queued where the device would otherwise wait for the next
+ * witness's upload. */
 int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t n_betas, const srs_fe *delta,
                  const srs_fe *const *W, const srs_fe *const *challenges, size_t n_challenges, size_t n_instances, int reference_compat,
                  void *stream, srs_fe *alpha_gamma, srs_fe *poly_F, srs_fe *poly_K, srs_fe *betas_stroke, srs_fe *e, srs_fe *lagrange,

@@ -2100,7 +2100,7 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
                  const srs_fe *const *W, const srs_fe *const *challenges, size_t n_challenges, size_t n_instances, int reference_compat,
                  void *stream, srs_fe *alpha_gamma, srs_fe *poly_F, srs_fe *poly_K, srs_fe *betas_stroke, srs_fe *e, srs_fe *lagrange,
                  srs_fe *W_folded) {
-    if (!S || !betas || !delta || !W || !alpha_gamma || !poly_F || !poly_K || !betas_stroke || !e || !lagrange || !W_folded ||
+    if (!S || !betas || !delta || !W || !alpha_gamma || !poly_F || !poly_K || !betas_stroke || !e || !lagrange ||
         (n_challenges && !challenges))
         return fail(SRS_ERR_INVALID, "srs_pg_prove: bad argument");
     if (n_instances < 2) return fail(SRS_ERR_INVALID, "You can't fold 0 traces");                // poly/mod.rs:27
@@ -2169,8 +2169,10 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
         const fe_t zg = Fr::sub(Fr::pow_u64(gamma, (uint64_t)1 << z.lagrange_domain), Fr::one());
         const fe_t kg = rowprog::poly_eval(reinterpret_cast<const fe_t *>(poly_K), n_K, gamma);
         const fe_t ev = Fr::add(Fr::mul(f_alpha, L[0]), Fr::mul(zg, kg));
-        erc = rowprog::lincomb(SRS_FIELD_FR, reinterpret_cast<fe_t *>(W_folded), dW.data(), L.data(), n_instances, wlen, st, err);
-        if (erc) return fail(erc, "srs_pg_prove (fold_witness): " + err);
+        if (W_folded) {      // NULL: the caller folds later (srs_fold_lincomb with `lagrange`), e.g. under the next witness upload
+            erc = rowprog::lincomb(SRS_FIELD_FR, reinterpret_cast<fe_t *>(W_folded), dW.data(), L.data(), n_instances, wlen, st, err);
+            if (erc) return fail(erc, "srs_pg_prove (fold_witness): " + err);
+        }
         std::memcpy(&alpha_gamma[0], &alpha, 32);
         std::memcpy(&alpha_gamma[1], &gamma, 32);
         std::memcpy(betas_stroke, bs.data(), bs.size() * sizeof(fe_t));

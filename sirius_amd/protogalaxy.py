@@ -128,10 +128,11 @@ def fold_witness(field, Ws, lagrange_for_gamma, out=None, shard=None):
     return out
 
 
-def prove(ctx, betas, delta, Ws, ro=None, alpha=None, gamma=None, challenges_list=None, reference_compat=True):
+def prove(ctx, betas, delta, Ws, ro=None, alpha=None, gamma=None, challenges_list=None, reference_compat=True, fold=True):
     """`ProtoGalaxy::prove` (src/nifs/protogalaxy/mod.rs:400-481) as one library call (srs_pg_prove) on device-resident
     witnesses Ws = [accumulator, incoming...].  With `ro` (a PoseidonHash over Fr holding the transcript so far) alpha and gamma
-    are squeezed inside; otherwise they are given.  -> dict(alpha, gamma, poly_F, poly_K, betas_stroke, e, lagrange, W)."""
+    are squeezed inside; otherwise they are given.  fold=False: W is None and fold_witness(field, Ws, lagrange) is the caller's to
+    queue later.  -> dict(alpha, gamma, poly_F, poly_K, betas_stroke, e, lagrange, W)."""
     bs = _fe(betas)
     bufs = [_buf(w, 4) for w in Ws]
     assert all(b[1] == L.SPACE_DEVICE for b in bufs) or not _is_torch(Ws[0]) or not Ws[0].is_cuda, "device-resident witnesses"
@@ -144,12 +145,12 @@ def prove(ctx, betas, delta, Ws, ro=None, alpha=None, gamma=None, challenges_lis
         ag[0], ag[1] = _fe(alpha).reshape(4), _fe(gamma).reshape(4)
     out = dict(poly_F=np.zeros((ctx.fft_points_count_F, 4), np.uint64), poly_K=np.zeros((1 << ctx.fft_log_domain_size_K, 4), np.uint64),
                betas_stroke=np.zeros((ctx.betas_count, 4), np.uint64), e=np.zeros(4, np.uint64), lagrange=np.zeros((J, 4), np.uint64),
-               W=_alloc_like(Ws[0], bufs[0][2]))
+               W=_alloc_like(Ws[0], bufs[0][2]) if fold else None)
     d = _fe(delta)
     Wf = out["W"]
     L.check(L.lib().srs_pg_prove(ctx.S._h, None if ro is None else ro._h, bs.ctypes.data, bs.shape[0], d.ctypes.data, wp, cp, chs[0].shape[0], J,
                                  1 if reference_compat else 0, _stream(), ag.ctypes.data, out["poly_F"].ctypes.data, out["poly_K"].ctypes.data,
                                  out["betas_stroke"].ctypes.data, out["e"].ctypes.data, out["lagrange"].ctypes.data,
-                                 Wf.data_ptr() if _is_torch(Wf) else Wf.ctypes.data))
+                                 None if Wf is None else (Wf.data_ptr() if _is_torch(Wf) else Wf.ctypes.data)))
     out["alpha"], out["gamma"] = ag[0].copy(), ag[1].copy()
     return out
