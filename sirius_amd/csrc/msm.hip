@@ -375,6 +375,9 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     }
 }
 
+#ifndef SCATTER_RES_INFLIGHT
+#define SCATTER_RES_INFLIGHT 4
+#endif
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     k_scatter(const uint16_t *__restrict__ dig, size_t dig_stride, BatchDesc bd,
               uint32_t *__restrict__ cursor /* [batch][NBUCKET] */, uint32_t *__restrict__ sorted,
@@ -388,14 +391,17 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     const uint16_t *d = dig + (size_t)m * dig_stride + (size_t)w * n;
     tile_histogram(h, d, lo, hi);
     uint32_t *cur = cursor + (size_t)m * NBUCKET;
-    for (uint32_t b0 = threadIdx.x; b0 < NBUCKET; b0 += 4 * blockDim.x) {   // 4 reservations in flight per thread
-        uint32_t c[4], r[4];
+    // the reservations are returning device-scope atomics: RES in flight per thread (32 = all of a thread's buckets in one round
+    // measured no faster, r03: the kernel waits for its scattered 4-byte stores, profiles/r03_sq_counters_msm.txt)
+    constexpr int RES = SCATTER_RES_INFLIGHT;
+    for (uint32_t b0 = threadIdx.x; b0 < NBUCKET; b0 += RES * blockDim.x) {
+        uint32_t c[RES], r[RES];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = h[b0 + u * blockDim.x];
+        for (int u = 0; u < RES; ++u) c[u] = b0 + u * blockDim.x < NBUCKET ? h[b0 + u * blockDim.x] : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&cur[b0 + u * blockDim.x], c[u]) : 0u;   // reserve [base, base+c)
+        for (int u = 0; u < RES; ++u) r[u] = c[u] ? atomicAdd(&cur[b0 + u * blockDim.x], c[u]) : 0u;   // reserve [base, base+c)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (c[u]) h[b0 + u * blockDim.x] = r[u];
+        for (int u = 0; u < RES; ++u) if (c[u]) h[b0 + u * blockDim.x] = r[u];
     }
     __syncthreads();
     uint32_t *out = sorted + (size_t)m * sorted_stride;
@@ -866,6 +872,20 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     parts[slot] = E29::pack(acc);                                // canonical R'-form: the later levels stay on the 29-bit multiplier
 }
 
+// 64-lane exchange of an XYZZ point
+__device__ __forceinline__ xyzz_t shfl_down_point(const xyzz_t &p, unsigned delta) {
+    xyzz_t o;
+    shfl_down_words<32>(reinterpret_cast<const uint32_t *>(&p), reinterpret_cast<uint32_t *>(&o), delta, 64);
+    return o;
+}
+
+// 64-lane exchange of a point in 9-limb coordinates (36 words), inside groups of `width` lanes
+__device__ __forceinline__ xyzz29_t shfl_down_point29(const xyzz29_t &p, unsigned delta, int width) {
+    xyzz29_t o;
+    shfl_down_words<36>(reinterpret_cast<const uint32_t *>(&p), reinterpret_cast<uint32_t *>(&o), delta, width);
+    return o;
+}
+
 // level >= 1: (bucket, part) over the previous level's parts, <= L1 full adds each.
 // Two modes, chosen on the device from the number of outputs of this level:
 //   many outputs  -> one lane per output (throughput-bound, every lane runs its own additions)
@@ -875,11 +895,11 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum1(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
              size_t plan_stride, int level, xyzz_t *__restrict__ out, size_t out_stride, uint32_t l1,
-             const Link *__restrict__ link, uint32_t quad_max) {
+             const Link *__restrict__ link, uint32_t quad_max, uint32_t tree_max) {
     uint32_t m = blockIdx.y;
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t t;
-    bool quad;
+    bool quad, tree = false;
     size_t in_off, out_off;
     if (link) {                                // wide windows: flat thread space of this level over the segments
         const uint32_t n_all = link->base[level][NSEG_W];
@@ -900,7 +920,8 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     const uint32_t n_out = tp[NBUCKET];
     if (!link) {
         quad = (uint64_t)n_out * gridDim.y <= quad_max;   // whole batch: latency-bound only while the chip is not full
-        t = quad ? (lin >> 2) : lin;
+        tree = !quad && (uint64_t)n_out * gridDim.y <= tree_max;
+        t = (quad || tree) ? (lin >> 2) : lin;
     }
     if (t >= n_out) return;                    // in quad mode the 4 lanes of a quad leave together
     uint32_t b = upper_bucket(tp, t);
@@ -910,6 +931,22 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     if (e > s + l1) e = s + l1;
     using E29 = Ec29<C>;
     const xyzz_t *src = in + in_off;
+    if (tree) {
+        // a level with too many outputs for the quad mode and too few to fill the chip one lane each (< ~1.5 wavefronts per SIMD, every
+        // lane a chain of l1 - 1 dependent additions): the 4 lanes of a quad take every 4th part (l1 / 4 - 1 additions), then two
+        // exchange rounds -- 5 dependent additions instead of 15 and 4x the wavefronts to interleave them
+        const uint32_t q = threadIdx.x & 3u;
+        uint32_t j = s + q;
+        xyzz29_t acc = j < e ? E29::unpack(src[j]) : E29::identity();
+        for (j += 4; j < e; j += 4) acc = E29::add(acc, E29::unpack(src[j]));
+#pragma unroll 1
+        for (unsigned d = 2; d >= 1; d >>= 1) {
+            const xyzz29_t other = shfl_down_point29(acc, d, 4);
+            if (q < d) acc = E29::add(acc, other);
+        }
+        if (q == 0) out[out_off + t] = E29::pack(acc);
+        return;
+    }
     xyzz29_t acc = E29::unpack(src[s]);
     if (quad) {
         const uint32_t q = threadIdx.x & 3u;
@@ -919,20 +956,6 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
         for (uint32_t j = s + 1; j < e; ++j) acc = E29::add(acc, E29::unpack(src[j]));
         out[out_off + t] = E29::pack(acc);
     }
-}
-
-// 64-lane exchange of an XYZZ point
-__device__ __forceinline__ xyzz_t shfl_down_point(const xyzz_t &p, unsigned delta) {
-    xyzz_t o;
-    shfl_down_words<32>(reinterpret_cast<const uint32_t *>(&p), reinterpret_cast<uint32_t *>(&o), delta, 64);
-    return o;
-}
-
-// 64-lane exchange of a point in 9-limb coordinates (36 words), inside groups of `width` lanes
-__device__ __forceinline__ xyzz29_t shfl_down_point29(const xyzz29_t &p, unsigned delta, int width) {
-    xyzz29_t o;
-    shfl_down_words<36>(reinterpret_cast<const uint32_t *>(&p), reinterpret_cast<uint32_t *>(&o), delta, width);
-    return o;
 }
 
 // final level: one wavefront per bucket; lanes stride over the remaining parts, then a 6-step
@@ -1257,6 +1280,16 @@ static uint32_t l0_log_for(uint64_t M) {
 // k_accum1 gives every output to a quad of lanes while a level has at most this many outputs (x batch): a level that cannot
 // fill the chip's 2^17.6 resident lanes is a chain of dependent additions, and a quad shortens each by 3.3x for 1.3x the
 // lane-cycles.  SRS_MSM_QUAD_MAX=<log2> overrides (A/B).
+// k_accum1's tree mode for levels of (quad_max, tree_max] outputs; SRS_MSM_TREE_MAX=<log2> (0: off)
+static uint32_t acc1_tree_max() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("SRS_MSM_TREE_MAX");
+        if (!e) return ACC1_TREE_MAX;
+        const int lg = std::atoi(e);
+        return (lg >= 1 && lg <= 24) ? (1u << lg) : 0u;
+    }();
+    return v;
+}
 static uint32_t acc1_quad_max() {
     static const uint32_t v = [] {
         const char *e = std::getenv("SRS_MSM_QUAD_MAX");
@@ -1391,9 +1424,9 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     uint64_t cap = parts0_cap;
     for (int level = 1; level < levels; ++level) {
         cap = cap / ACC_L1 + NBUCKET + 1;
-        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                    (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, level, nxt, nxt_stride,
-                   (uint32_t)ACC_L1, no_link, acc1_quad_max());
+                   (uint32_t)ACC_L1, no_link, acc1_quad_max(), acc1_tree_max());
         std::swap(cur, nxt);
         std::swap(cur_stride, nxt_stride);
         // both buffers can hold any later level: parts shrink monotonically and pong >= level-1 cap
@@ -1524,9 +1557,9 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     uint64_t cap = w.parts0_cap;
     for (int level = 1; level < w.levels; ++level) {
         cap = cap / ACC_L1 + (uint64_t)NSEG_W * (NBUCKET + 1);
-        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS)), (ACC_THREADS), 0,
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS)), (ACC_THREADS), 0,
                    stream, (const xyzz_t *)cur, (size_t)0, (const uint32_t *)plan, w.plan_stride, level, nxt, (size_t)0, (uint32_t)ACC_L1, lk,
-                   acc1_quad_max());
+                   acc1_quad_max(), 0u);
         std::swap(cur, nxt);
     }
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), NSEG_W), (FINAL_THREADS), 0, stream, (const xyzz_t *)ping, (size_t)0,
@@ -1614,9 +1647,9 @@ static void chunked_front_t(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_
         uint64_t cap = ((uint64_t)n * NWIN >> S.l0_log) + NBUCKET + 1;
         for (int level = 1; level < S.levels; ++level) {
             cap = cap / ACC_L1 + NBUCKET + 1;
-            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), 1), (ACC_THREADS), 0,
+            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS), 1), (ACC_THREADS), 0,
                        s_acc, (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, S.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
-                       acc1_quad_max());
+                       acc1_quad_max(), acc1_tree_max());
             std::swap(cur, nxt);
             std::swap(cur_stride, nxt_stride);
         }
@@ -1639,9 +1672,9 @@ static void chunked_tail_t(Key &k, hipStream_t stream, uint32_t slot) {
         uint64_t cap = S.parts0_cap;
         for (int level = 1; level < S.levels; ++level) {
             cap = cap / ACC_L1 + NBUCKET + 1;
-            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), sets), (ACC_THREADS), 0,
+            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS), sets), (ACC_THREADS), 0,
                        stream, (const xyzz_t *)cur, cur_stride, (const uint32_t *)S.plan, S.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
-                       acc1_quad_max());
+                       acc1_quad_max(), acc1_tree_max());
             std::swap(cur, nxt);
             std::swap(cur_stride, nxt_stride);
         }

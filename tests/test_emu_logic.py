@@ -364,6 +364,29 @@ def test_emu_long_level0_parts():
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_emu_accum1_tree_mode():
+    """msm.hip k_accum1's tree mode (4 lanes per output, every lane a quarter of the parts, two exchange rounds) forced on a small MSM
+    whose heavy buckets have hundreds of 2-entry level-0 parts (repeated small / negative scalars), ragged part counts included."""
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "import oracle as O, sirius_amd as S\n"
+        "from oracle import pyref as P\n"
+        "from sirius_amd import _lib\n"
+        "from conftest import seeded_scalars\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "q = P.CURVES[1].q\n"
+        "vals = [3] * 301 + [q - 5] * 187 + [7] * 33 + [1 << 16] * 18 + [(1 << 32) + 9] * 5 + [0] * 11\n"
+        "v = np.concatenate([O.ints_to_mont(O.SCALAR_FIELD[1], vals), seeded_scalars(O, 1, 60, 9, 'trace'), seeded_scalars(O, 1, 25, 3, 'uniform')])\n"
+        "bases = O.make_bases(1, 4, len(v)); ck = S.CommitmentKey(1, bases)\n"
+        "assert np.array_equal(ck.commit(v), O.msm(1, v, bases))\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0="1", SRS_MSM_QUAD_MAX="1", SRS_MSM_TREE_MAX="17"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_wide_windows():
     """msm.hip wide pipeline (13 x 20-bit windows, 16 segments of 2^15 buckets) forced on a small MSM: digit-boundary values,
     zeros / bits / small values (every entry of a segment in a few buckets) and full-width scalars in one commit."""
