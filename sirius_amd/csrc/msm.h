@@ -15,8 +15,9 @@ constexpr uint32_t SORT_THREADS = 1024;   // one workgroup per CU: 128 KiB LDS h
 constexpr uint32_t SORT_TILE_MIN = 8192;       // digits per workgroup (lower bound)
 constexpr uint32_t SORT_TARGET_BLOCKS = 256;   // ~one 128-KiB-LDS workgroup per CU
 constexpr uint32_t SEG = 128, SEG_BUCKETS = NBUCKET / SEG;   // two-pass scatter: segments of 256 consecutive buckets
-constexpr uint32_t SORT_TILE2 = 65536;          // entries per workgroup of the second pass
-constexpr uint64_t TWO_PASS_MIN_SLOTS = 1ull << 28;   // digit slots (16 n x batch) from which the two-pass scatter wins (measured: 2^24-point MSMs)
+constexpr uint32_t SORT_TILE2 = 8192;           // entries per workgroup of the second pass (8 per thread, sorted inside LDS)
+constexpr uint64_t TWO_PASS_MIN_SLOTS = 1ull << 23;   // digit slots (16 n x batch) from which the two-pass scatter wins (r03, LDS-staged passes: from ~0.5 M scalars;
+                                                      // profiles/r03_ab_two_pass_sort.txt -- was 2^28 with lane-per-entry stores)
 constexpr uint32_t PLAN_THREADS = 1024;
 constexpr uint32_t ACC_THREADS = 256;        // r03 A/B (profiles/r03_ab_accum0_variants.txt): 256 beats 128 and 64 by 2-3 % of a k = 20 step
 constexpr uint32_t ACC_L0_LOG = 4, ACC_L0 = 1u << ACC_L0_LOG;   // gathered mixed adds per level-0 thread

@@ -311,41 +311,89 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     }
 }
 
+// r03: both passes go through LDS.  A lane-per-entry global store of the first version met ~50 different cache lines per
+// wavefront instruction -- the address path of a CU takes about one line per cycle, so k_group / k_scatter2 ran at ~1/4 of what
+// their traffic costs.  Now a workgroup sorts a sub-tile of entries by segment (bucket) inside LDS and copies it out in index
+// order: consecutive lanes store consecutive addresses of a run.
+constexpr uint32_t GRP_PER = 16, GRP_SUB = SORT_THREADS * GRP_PER;      // digit slots per thread / per sub-tile of k_group
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     k_group(const uint16_t *__restrict__ dig, size_t dig_stride, BatchDesc bd, const uint32_t *__restrict__ tile_hist,
             uint16_t *__restrict__ gkey, uint32_t *__restrict__ gpay, size_t g_stride, uint32_t table_stride, uint32_t SORT_TILE) {
-    __shared__ uint32_t cur[SEG];
-    uint32_t m = blockIdx.z, w = blockIdx.y;
-    uint32_t n = bd.n[m];
-    uint32_t lo = blockIdx.x * SORT_TILE;
+    __shared__ uint32_t cur[SEG], cnt[SEG], lb[SEG], sc[64];
+    __shared__ uint32_t spay[GRP_SUB];
+    __shared__ uint16_t skey[GRP_SUB];
+    const uint32_t m = blockIdx.z, w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t n = bd.n[m];
+    const uint32_t lo = blockIdx.x * SORT_TILE;
     if (lo >= n) return;
-    uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    const uint32_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
     const uint32_t T1 = gridDim.x * NWIN, t1 = w * gridDim.x + blockIdx.x;
-    for (uint32_t sgm = threadIdx.x; sgm < SEG; sgm += blockDim.x) cur[sgm] = tile_hist[((size_t)m * SEG + sgm) * T1 + t1];
-    __syncthreads();
+    for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cur[sgm] = tile_hist[((size_t)m * SEG + sgm) * T1 + t1];
     const uint16_t *d = dig + (size_t)m * dig_stride + (size_t)w * n;
     uint16_t *ok = gkey + (size_t)m * g_stride;
     uint32_t *op = gpay + (size_t)m * g_stride;
-    for_each_digit(d, lo, hi, [&](uint32_t i, uint32_t code) {
-        if (code != 0xFFFFu) {
-            uint32_t pos = atomicAdd(&cur[(code & 0x7FFFu) / SEG_BUCKETS], 1u);
-            ok[pos] = (uint16_t)(code & 0x7FFFu);
-            op[pos] = (w * table_stride + bd.base[m] + i) | ((code & 0x8000u) << 16);
+    const uint32_t pay0 = w * table_stride + bd.base[m];
+    for (uint32_t sub = lo; sub < hi; sub += GRP_SUB) {                 // workgroup-uniform
+        for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cnt[sgm] = 0;
+        __syncthreads();
+        // the thread's GRP_PER consecutive digit slots (two 16-byte loads when they are aligned and inside the tile)
+        const uint32_t i0 = sub + tid * GRP_PER;
+        uint32_t code[GRP_PER], rank[GRP_PER];
+        if (i0 + GRP_PER <= hi && (reinterpret_cast<uintptr_t>(d + i0) & 15u) == 0) {
+            const uint4 *v = reinterpret_cast<const uint4 *>(d + i0);
+#pragma unroll
+            for (uint32_t q = 0; q < GRP_PER / 8; ++q) {
+                const uint4 x = v[q];
+                code[8 * q + 0] = x.x & 0xFFFFu; code[8 * q + 1] = x.x >> 16;
+                code[8 * q + 2] = x.y & 0xFFFFu; code[8 * q + 3] = x.y >> 16;
+                code[8 * q + 4] = x.z & 0xFFFFu; code[8 * q + 5] = x.z >> 16;
+                code[8 * q + 6] = x.w & 0xFFFFu; code[8 * q + 7] = x.w >> 16;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < GRP_PER; ++k) code[k] = i0 + k < hi ? (uint32_t)d[i0 + k] : 0xFFFFu;
         }
-    });
+#pragma unroll
+        for (uint32_t k = 0; k < GRP_PER; ++k)
+            rank[k] = code[k] != 0xFFFFu ? atomicAdd(&cnt[(code[k] & 0x7FFFu) / SEG_BUCKETS], 1u) : 0u;
+        __syncthreads();
+        uint32_t n_sub;
+        const uint32_t ex = block_exclusive_scan(tid < SEG ? cnt[tid] : 0u, sc, &n_sub);
+        if (tid < SEG) lb[tid] = ex;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < GRP_PER; ++k) {
+            if (code[k] != 0xFFFFu) {
+                const uint32_t bkt = code[k] & 0x7FFFu, pos = lb[bkt / SEG_BUCKETS] + rank[k];
+                skey[pos] = (uint16_t)bkt;
+                spay[pos] = (pay0 + i0 + k) | ((code[k] & 0x8000u) << 16);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n_sub; i += blockDim.x) {             // index order: a segment's run goes out as one contiguous piece
+            const uint32_t key = skey[i], sgm = key / SEG_BUCKETS, g = cur[sgm] + (i - lb[sgm]);
+            ok[g] = (uint16_t)key;
+            op[g] = spay[i];
+        }
+        __syncthreads();
+        if (tid < SEG) cur[tid] += cnt[tid];
+    }
 }
 
-__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+constexpr uint32_t S2_PER = 8, S2_RANGE = 2 * SEG_BUCKETS;               // entries per thread; buckets a tile may span on the LDS path
+static_assert(SORT_TILE2 == SORT_THREADS * S2_PER, "k_scatter2: one tile = S2_PER entries per thread");
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
     k_scatter2(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ gpay, size_t g_stride,
                const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t *__restrict__ cursor /* [batch][NBUCKET] */,
                uint32_t *__restrict__ sorted, size_t sorted_stride, uint32_t TILE2) {
-    __shared__ uint32_t h[NBUCKET];
-    const uint32_t m = blockIdx.y;
+    __shared__ uint32_t cnt[S2_RANGE], lb[S2_RANGE], gb[S2_RANGE], sc[64];
+    __shared__ uint32_t spay[SORT_TILE2];
+    __shared__ uint16_t skey[SORT_TILE2];
+    const uint32_t m = blockIdx.y, tid = threadIdx.x;
     const uint32_t total = plan[(size_t)m * plan_stride + NBUCKET];        // number of non-zero digits of this MSM
     // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
     // takes tile (b % 8) * ceil(tiles / 8) + b / 8 -- every XCD sorts one contiguous eighth of the grouped array, i.e.
-    // one eighth of the buckets, and the 4-byte stores to a cache line all come from the same L2 and merge there
-    // (lines written from several XCDs go out as partial writes: 8x write amplification measured on the single pass).
+    // one eighth of the buckets, and the stores to a cache line all come from the same L2 and merge there
     const uint32_t n_tiles = (total + TILE2 - 1) / TILE2, per_xcd = (n_tiles + 7) / 8;
     if (blockIdx.x / 8 >= per_xcd) return;
     const uint32_t tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -355,23 +403,55 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     const uint32_t hi = lo + TILE2 < total ? lo + TILE2 : total;
     const uint16_t *key = gkey + (size_t)m * g_stride;
     const uint32_t *pay = gpay + (size_t)m * g_stride;
+    uint32_t *cur = cursor + (size_t)m * NBUCKET;
+    uint32_t *out = sorted + (size_t)m * sorted_stride;
     // the grouped array is ordered by segment: this tile only holds buckets of segments seg(first) .. seg(last)
     const uint32_t b_lo = ((uint32_t)key[lo] / SEG_BUCKETS) * SEG_BUCKETS;
     const uint32_t b_hi = ((uint32_t)key[hi - 1] / SEG_BUCKETS + 1) * SEG_BUCKETS;
-    for (uint32_t b = b_lo + threadIdx.x; b < b_hi; b += blockDim.x) h[b] = 0;
+    if (b_hi - b_lo > S2_RANGE) {            // a tile over more than two segments (few entries for the bucket range): entry by entry
+        for (uint32_t i = lo + tid; i < hi; i += blockDim.x) out[atomicAdd(&cur[key[i]], 1u)] = pay[i];
+        return;
+    }
+    for (uint32_t b = tid; b < S2_RANGE; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[key[i]], 1u);
+    const uint32_t i0 = lo + tid * S2_PER;
+    uint32_t kk[S2_PER], pp[S2_PER], rank[S2_PER];
+    if (i0 + S2_PER <= hi && (reinterpret_cast<uintptr_t>(key + i0) & 15u) == 0 && (reinterpret_cast<uintptr_t>(pay + i0) & 15u) == 0) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(key + i0);
+        kk[0] = x.x & 0xFFFFu; kk[1] = x.x >> 16; kk[2] = x.y & 0xFFFFu; kk[3] = x.y >> 16;
+        kk[4] = x.z & 0xFFFFu; kk[5] = x.z >> 16; kk[6] = x.w & 0xFFFFu; kk[7] = x.w >> 16;
+        const uint4 p0 = *reinterpret_cast<const uint4 *>(pay + i0), p1 = *reinterpret_cast<const uint4 *>(pay + i0 + 4);
+        pp[0] = p0.x; pp[1] = p0.y; pp[2] = p0.z; pp[3] = p0.w; pp[4] = p1.x; pp[5] = p1.y; pp[6] = p1.z; pp[7] = p1.w;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < S2_PER; ++k) {
+            kk[k] = i0 + k < hi ? (uint32_t)key[i0 + k] : 0xFFFFu;
+            pp[k] = i0 + k < hi ? pay[i0 + k] : 0u;
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < S2_PER; ++k) rank[k] = kk[k] != 0xFFFFu ? atomicAdd(&cnt[kk[k] - b_lo], 1u) : 0u;
     __syncthreads();
-    uint32_t *cur = cursor + (size_t)m * NBUCKET;
-    for (uint32_t b = b_lo + threadIdx.x; b < b_hi; b += blockDim.x) {
-        uint32_t c = h[b];
-        if (c) h[b] = atomicAdd(&cur[b], c);                               // reserve [base, base + c)
+    uint32_t n_tile;
+    const uint32_t c = tid < S2_RANGE ? cnt[tid] : 0u;
+    const uint32_t ex = block_exclusive_scan(c, sc, &n_tile);
+    if (tid < S2_RANGE) {
+        lb[tid] = ex;
+        gb[tid] = c ? atomicAdd(&cur[b_lo + tid], c) : 0u;                 // reserve [base, base + c) of the bucket
     }
     __syncthreads();
-    uint32_t *out = sorted + (size_t)m * sorted_stride;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t pos = atomicAdd(&h[key[i]], 1u);
-        out[pos] = pay[i];
+#pragma unroll
+    for (uint32_t k = 0; k < S2_PER; ++k) {
+        if (kk[k] != 0xFFFFu) {
+            const uint32_t pos = lb[kk[k] - b_lo] + rank[k];
+            skey[pos] = (uint16_t)(kk[k] - b_lo);
+            spay[pos] = pp[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_tile; i += blockDim.x) {
+        const uint32_t b = skey[i];
+        out[gb[b] + (i - lb[b])] = spay[i];
     }
 }
 

@@ -164,9 +164,18 @@ def test_emu_two_pass_scatter():
         "for n in (9000, 4097, 3):\n"
         "    v = seeded_scalars(O, 1, n, n, 'uniform')\n"
         "    assert np.array_equal(ck.commit(v), O.msm(1, v, bases[:n]))\n"
+        "# dense buckets: every 16-bit digit in a few hundred buckets (tiles of the grouped array inside one or two segments: the LDS\n"
+        "# path of k_scatter2), alone and mixed with uniform scalars (tiles over many segments: entry by entry), negative digits too\n"
+        "import random; rnd = random.Random(5)\n"
+        "dense = lambda lo, hi: sum(rnd.randrange(lo, hi) << (16 * w) for w in range(15))\n"
+        "vals = [dense(1, 200) for _ in range(3000)] + [dense(250, 300) for _ in range(1500)] + [dense(0xFF00, 0xFFFF) for _ in range(700)]\n"
+        "vd = O.ints_to_mont(O.SCALAR_FIELD[1], vals)\n"
+        "assert np.array_equal(ck.commit(vd), O.msm(1, vd, bases[:len(vals)]))\n"
+        "vm = np.concatenate([vd[:2500], seeded_scalars(O, 1, 1500, 7, 'uniform'), seeded_scalars(O, 1, 600, 8, 'trace')])\n"
+        "assert np.array_equal(ck.commit(vm), O.msm(1, vm, bases[:len(vm)]))\n"
         "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT="2"), capture_output=True, text=True,
-                       timeout=900)
+                       timeout=1800)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
 
 
