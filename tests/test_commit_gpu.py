@@ -310,7 +310,7 @@ def test_commit_config_k22_vs_oracle(srs, oracle):
 
 
 def test_two_pass_scatter_matches_single_pass(srs, oracle):
-    """The MSD two-pass scatter (k_group + k_scatter2, used from 2^24-point MSMs on) against the single-pass one and the
+    """The MSD two-pass scatter (k_group + k_scatter2, used from 2^23 digit slots on) against the single-pass one and the
     oracle on sizes the oracle can do: forced through SRS_MSM_SORT (read once per process -> subprocesses)."""
     import os
     import subprocess
@@ -323,6 +323,13 @@ def test_two_pass_scatter_matches_single_pass(srs, oracle):
         "    bases = O.make_bases(cid, 4, n); ck = S.CommitmentKey(cid, bases)\n"
         "    vs = [seeded_scalars(O, cid, n, 9 + j, kind) for j in range(3)]\n"
         "    for g, v in zip(ck.commit_batch(vs), vs): assert np.array_equal(g, O.msm(cid, v, bases))\n"
+        "# heavy buckets (every digit in a few hundred buckets: a tile of the grouped array holds 1-2 buckets) next to uniform scalars\n"
+        "import random; rnd = random.Random(5)\n"
+        "dense = lambda lo, hi: sum(rnd.randrange(lo, hi) << (16 * w) for w in range(15))\n"
+        "vals = [dense(1, 200) for _ in range(30000)] + [dense(0xFF00, 0xFFFF) for _ in range(9000)] + [3] * 7000\n"
+        "vd = np.concatenate([O.ints_to_mont(O.SCALAR_FIELD[0], vals), seeded_scalars(O, 0, 20000, 4, 'uniform')])\n"
+        "bases = O.make_bases(0, 4, len(vd)); ck = S.CommitmentKey(0, bases)\n"
+        "assert np.array_equal(ck.commit(vd), O.msm(0, vd, bases))\n"
         "print('ok')\n")
     from conftest import ROOT
     for mode in ("1", "2"):
