@@ -269,6 +269,36 @@ def _fold_then_decide(S, O, field, curve, k, gate_T):
     assert O.mont_to_ints(sf, pr2["r"]) == [oro.squeeze(128)]
     assert np.array_equal(host(dW1b), O.fold_w(field, W1, W2, pr2["r"]))
     pr2["W_commitment"].wait(); pr2["E_commitment"].wait()
+    # srs_sangria_prove_incoming: the incoming trace arrives from the HOST without a commitment -- uploaded, committed in the same batched
+    # MSM as the cross terms, absorbed (+ the rest of U2: `u2_tail`) before the cross-term commitments
+    tail = rand_fe(rng, 3)
+    ro3, oro3 = S.PoseidonHash(bf, 5, 4, 10, 10), OP.PoseidonHash(P.MODULI[bf], 5, 4, 10, 10)
+    ro3.absorb_point(curve, cW1); oro3.absorb_point(tuple(O.mont_to_ints(bf, cW1.reshape(2, 4))))
+    dW1c, dEc, dW2c = dv(W1), dv(zeroE), dv(np.zeros_like(W2))
+    pr3 = S.sangria_prove(ck, St, y1, one, dW1c, y2, dW2c, dEc, cW1, np.zeros(8, np.uint64), ro=ro3, incoming=True, incoming_host=W2,
+                          u2_tail=tail)
+    assert np.array_equal(pr3["incoming_commitment"], cW2) and np.array_equal(host(dW2c), W2)
+    assert np.array_equal(pr3["commits"], commits) and all(np.array_equal(host(a), b) for a, b in zip(pr3["terms"], terms))
+    oro3.absorb_point(tuple(O.mont_to_ints(bf, cW2.reshape(2, 4))))
+    oro3.absorb_field_iter(O.mont_to_ints(bf, tail))
+    for c in commits:
+        oro3.absorb_point(tuple(O.mont_to_ints(bf, c.reshape(2, 4))))
+    assert O.mont_to_ints(sf, pr3["r"]) == [oro3.squeeze(128)]
+    assert np.array_equal(host(dW1c), O.fold_w(field, W1, W2, pr3["r"])) and np.array_equal(host(dEc), O.fold_e(field, zeroE, terms, pr3["r"]))
+    assert np.array_equal(pr3["W_commitment"].wait(), S.point_lincomb(curve, cW1, cW2.reshape(1, 8), pr3["r"].reshape(1, 4)))
+    pr3["E_commitment"].wait()
+    # ... with a given challenge and a resident trace it equals srs_sangria_prove
+    dW1d, dEd = dv(W1), dv(zeroE)
+    pr4 = S.sangria_prove(ck, St, y1, one, dW1d, y2, dv(W2), dEd, cW1, np.zeros(8, np.uint64), r=r, incoming=True)
+    assert np.array_equal(pr4["incoming_commitment"], cW2) and np.array_equal(host(dW1d), acc.W[0]) and np.array_equal(host(dEd), acc.E)
+    assert np.array_equal(pr4["W_commitment"].wait(), ck.commit(acc.W[0])) and np.array_equal(pr4["E_commitment"].wait(), ck.commit(acc.E))
+    # a key shorter than the trace: the reference's TooLongInput, before anything is written
+    short = S.CommitmentKey.setup_synthetic(curve, rows, seed=5)
+    dW1e = dv(W1)
+    with pytest.raises(Exception) as ei:
+        S.sangria_prove(short, St, y1, one, dW1e, y2, dv(W2), dv(zeroE), cW1, np.zeros(8, np.uint64), r=r, incoming=True)
+    assert "too long input" in str(ei.value) and np.array_equal(host(dW1e), W1)
+    short.close()
     St.close()
 
 
