@@ -219,9 +219,9 @@ class SangriaSide:
             c = self.ck.commit(self.inW)
         self.inC = D.combine(self.curve, c)
 
-    def prove_incoming(self, S, ro_challenge=False):
-        """The freshly synthesised trace (host) is uploaded, committed and folded by ONE library call: its commitment and the
-        cross terms' come out of the same batched MSM (srs_sangria_prove_incoming; one process only)."""
+    def prove_incoming(self, S, ro_challenge=False, from_host=True):
+        """The freshly synthesised trace (host; from_host=False: already resident) is uploaded, committed and folded by ONE library
+        call: its commitment and the cross terms' come out of the same batched MSM (srs_sangria_prove_incoming; one process only)."""
         self.settle()
         ro = None
         if ro_challenge:
@@ -229,7 +229,7 @@ class SangriaSide:
             for pt in (self.accCW, self.accCE):
                 ro.absorb_point(self.curve, pt)
         pr = S.sangria_prove(self.ck, self.S, self.u1c, self.u1u, self.accW, self.u2c, self.inW, self.accE, self.accCW, self.accCE,
-                             r=None if ro_challenge else self.r, ro=ro, incoming=True, incoming_host=self.host_W.array)
+                             r=None if ro_challenge else self.r, ro=ro, incoming=True, incoming_host=self.host_W.array if from_host else None)
         self.r, self.inC = pr["r"], pr["incoming_commitment"]
         self.pending = (pr["E_commitment"], pr["W_commitment"])
         self._keep = pr
@@ -272,6 +272,12 @@ class SangriaSide:
 
 def sangria_step(S, D, pri, sec, from_host, ro=False, count=False):
     """SangriaIVC::fold_step hot path (src/ivc/sangria/incrementally_verifiable_computation.rs:429-635)."""
+    if not from_host and D.world == 1 and not count and not SPLIT_SUPPORT:
+        # resident traces: a trace's commitment shares the batched MSM of the prove that folds it (the secondary's at the start of the
+        # next step, where both are first needed).  Traces coming from the host keep the streamed commit: its upload overlaps the MSM.
+        sec.prove_incoming(S, ro, False)
+        pri.prove_incoming(S, ro, False)
+        return
     sec.prove(S, D, ro, count)
     pri.witness_commit(S, D, from_host)
     pri.prove(S, D, ro, count)
@@ -602,7 +608,7 @@ def extras_sangria(S, D, args, k=17, log_key=21, steps=20, warmup=3):
         out[name] = {"fold_steps_per_s": round(steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4)}
         if not from_host:
             nz = sum(nonzero_rows(sd.inW) + sd.nz_terms for sd in (pri, sec))
-            out["roofline"] = msm_roofline(S, "30 * 2^17 scalars per step over 4 launches", 16.0 * nz * steps / D.world, D.world)
+            out["roofline"] = msm_roofline(S, "30 * 2^17 scalars per step over 2 batched launches (a trace and its cross terms each)", 16.0 * nz * steps / D.world, D.world)
             ct = S.profile_get("rowprog_cross_terms")
             out["cross_terms_ms_per_launch"] = round(ct["total_ms"] / ct["launches"], 4) if ct and ct["launches"] else None
     out["workload"] = f"sangria_poseidon fold_step hot path, k={k}, bn256/grumpkin, key 2^{log_key} (BASELINE configs[1])"

@@ -355,6 +355,33 @@ def test_emu_chain_digest_vs_oracle():
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_emu_sangria_step_merged_commits():
+    """bench.py's k=17-shaped Sangria step with resident traces: a trace's commitment in the same batched MSM as the cross terms of the
+    prove that folds it (srs_sangria_prove_incoming, W2 resident) == commit, then srs_sangria_prove; Poseidon-derived challenges."""
+    import sys
+    code = (
+        "import sys, argparse, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from sirius_amd import _lib\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "import sirius_amd as S, bench\n"
+        "from workloads import make_structure_inputs\n"
+        "D = bench.Dist(argparse.Namespace(emu=True, gpus=1, dist_backend='nccl'))\n"
+        "def chain(split):\n"
+        "    bench.SPLIT_SUPPORT = split\n"
+        "    pri = bench.SangriaSide(S, D, make_structure_inputs('primary', 4, seed=11), 8, 'primary')\n"
+        "    sec = bench.SangriaSide(S, D, make_structure_inputs('secondary', 4, seed=12), 8, 'secondary')\n"
+        "    pri.witness_commit(S, D, False); sec.witness_commit(S, D, False)\n"
+        "    for _ in range(2): bench.sangria_step(S, D, pri, sec, False, True)\n"
+        "    pri.settle(); sec.settle()\n"
+        "    return [np.array(x).copy() for sd in (pri, sec) for x in (sd.accCW, sd.accCE, sd.inC, sd.r)]\n"
+        "a, b = chain(False), chain(True)\n"
+        "assert all(np.array_equal(x, y) for x, y in zip(a, b)) and any(x.any() for x in a)\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_long_level0_parts():
     """msm.hip l0_log_for: 64 gathered additions per level-0 thread (the setting of large MSMs), forced on a small one."""
     import sys
