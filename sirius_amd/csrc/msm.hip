@@ -783,14 +783,19 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     k_plan(const uint32_t *__restrict__ count, uint32_t *__restrict__ cursor, uint32_t *__restrict__ plan,
            size_t plan_stride, int nlevels, uint32_t l0_log, uint32_t l1_log,
            const uint32_t *__restrict__ seg_off /* wide windows: entry offsets are absolute, segment m starts at seg_off[m] */) {
-    // One workgroup scans all 2^15 buckets.  Thread t owns PER consecutive buckets (registers), but
+    // grid = (batch, nlevels + 1): workgroup (m, y) scans ONE array of MSM m -- y = 0 the raw counts (entry offsets), y = l + 1 the
+    // part counts of level l -- over all 2^15 buckets.  The arrays only depend on the counts (parts of level l = ceil(parts of level
+    // l - 1 / 2^l1_log)), so the levels do not wait for each other (r03: one workgroup did them in turn, 45-55 us of pure latency
+    // per MSM launch; now ~one round).  Every workgroup derives the number of levels actually needed the same way.
+    // Thread t owns PER consecutive buckets (registers), but
     // global traffic goes through an LDS transposition so that every load/store instruction is
     // coalesced (a single CU issuing 4-byte accesses at 128-byte stride was 5x slower than the scan).
     constexpr uint32_t PER = NBUCKET / PLAN_THREADS;             // 32
     __shared__ uint32_t tile[NBUCKET + NBUCKET / PER];           // index i lives at i + i / PER: conflict-free both ways
     __shared__ uint32_t lds[64];
     const uint32_t t = threadIdx.x;
-    uint32_t m = blockIdx.x;
+    const uint32_t m = blockIdx.x;
+    const int my_level = (int)blockIdx.y - 1;
     const uint32_t *cnt = count + (size_t)m * NBUCKET;
     uint32_t *cur = cursor + (size_t)m * NBUCKET;
     uint32_t *pl = plan + (size_t)m * plan_stride;
@@ -802,7 +807,7 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     for (uint32_t j = 0; j < PER; ++j) vals[j] = tile[base + j + t];
     int needed = nlevels;
     uint32_t total_entries = 0;
-    for (int level = -1; level < needed; ++level) {
+    for (int level = -1; level <= my_level; ++level) {
         // level -1: scan the raw counts (entry offsets); level >= 0: scan the part counts
         if (level >= 0) {
             uint32_t lg = level == 0 ? l0_log : l1_log;
@@ -831,16 +836,19 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
                     ++by_mean;
                 }
                 needed = by_mean > needed ? by_mean : needed;
-                if (t == 0) pl[plan_stride - 4] = (uint32_t)needed;
+                if (t == 0 && my_level == 0) pl[plan_stride - 4] = (uint32_t)needed;
+                if (my_level >= needed) return;                  // a level nobody runs (workgroup-uniform)
             }
         }
+        if (level != -1 && level != my_level) continue;          // only the counts' total and the own array need a scan
         uint32_t local = 0;
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) local += vals[j];
         uint32_t total;
         uint32_t run = block_exclusive_scan(local, lds, &total);
         if (level < 0) total_entries = total;
-        __syncthreads();                                         // previous copy-out has finished reading `tile`
+        if (level != my_level) continue;
+        __syncthreads();                                         // the load of the counts has finished reading `tile`
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
             tile[base + j + t] = run;
@@ -858,7 +866,7 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     }
     // every bucket already a single part after the last level?  Then the wave-level pass is a pure copy:
     // k_accum_final exits and k_rowcol reads the last level's parts directly (part index == bucket index).
-    {
+    if (my_level == needed - 1) {
         uint32_t mx = 0;
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) mx = vals[j] > mx ? vals[j] : mx;
@@ -867,7 +875,6 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     }
 }
 
-// wide windows: base[l][v] from the level sizes the NSEG_W plans ended with (one wavefront)
 __global__ void k_link(const uint32_t *__restrict__ plan, size_t plan_stride, int nlevels, Link *__restrict__ link) {
     const uint32_t t = threadIdx.x;
     for (int l = 0; l < nlevels; ++l) {
@@ -1473,7 +1480,7 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     const uint32_t tiles = ceil_div(n_max, tile);
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
-    SRS_LAUNCH(k_plan, (batch), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
+    SRS_LAUNCH(k_plan, (batch, levels + 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
                levels, l0_log, (uint32_t)ACC_L1_LOG, (const uint32_t *)nullptr);
     if (two_pass) {
         const uint32_t T1 = tiles * NWIN;
@@ -1620,7 +1627,7 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     SRS_LAUNCH((k_seg_pass<C, true>), (w.T), (WIDE_THREADS), 0, stream, wd, tile_cnt, w.T, seg_total, gkey, gpay, table_stride);
     SRS_LAUNCH(k_hist_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)seg_off,
                (const uint32_t *)tile_base, count);
-    SRS_LAUNCH(k_plan, (NSEG_W), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, w.plan_stride, w.levels, w.l0_log,
+    SRS_LAUNCH(k_plan, (NSEG_W, w.levels + 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, w.plan_stride, w.levels, w.l0_log,
                (uint32_t)ACC_L1_LOG, (const uint32_t *)seg_off);
     SRS_LAUNCH(k_scatter_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay,
                (const uint32_t *)seg_off, (const uint32_t *)tile_base, cursor, sorted);
@@ -1703,7 +1710,7 @@ static void chunked_front_t(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_
     // the three 150-VGPR waves k_accum0 keeps on every SIMD and run under the previous chunk's accumulation instead of after it.
     const uint32_t sort_threads = s_sort != s_acc ? chunked_sort_threads() : SORT_THREADS;
     SRS_LAUNCH(k_hist, (tiles, NWIN, 1), (sort_threads), 0, s_sort, (const uint16_t *)dig, (size_t)M, bd, count, tile, (uint32_t *)nullptr);
-    SRS_LAUNCH(k_plan, (1), (PLAN_THREADS), 0, s_sort, (const uint32_t *)count, cursor, plan, S.plan_stride, S.levels, S.l0_log,
+    SRS_LAUNCH(k_plan, (1, S.levels + 1), (PLAN_THREADS), 0, s_sort, (const uint32_t *)count, cursor, plan, S.plan_stride, S.levels, S.l0_log,
                (uint32_t)ACC_L1_LOG, (const uint32_t *)nullptr);
     SRS_LAUNCH(k_scatter, (tiles, NWIN, 1), (sort_threads), 0, s_sort, (const uint16_t *)dig, (size_t)M, bd, cursor, sorted, (size_t)M,
                (uint32_t)k.len, tile);
