@@ -210,27 +210,26 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
     subprocess.check_call(["make", "-C", emu_dir, "-j4"], stdout=subprocess.DEVNULL)
     common = ["--emu", "--k", "11", "--log-key", "15", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HIPEMU_THREADS="4")
-    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
-                        timeout=900, cwd=ROOT, env=env)
-    assert r1.returncode == 0, r1.stderr[-3000:]
-    one = json.loads(r1.stdout.strip().splitlines()[-1])
-    # no torchrun around it: `bench.py --gpus 2` launches its two ranks itself (spawn_ranks)
+    # no torchrun around the 2-rank runs: `bench.py --gpus 2` launches its two ranks itself (spawn_ranks).  The four runs are independent:
+    # side by side (N > 1 secondary object in the first 2-rank run: the sharded MSM microbenchmark)
     env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo"] +
-                        [a for a in common if a != "--no-extras"],          # N > 1 secondary object: the sharded MSM microbenchmark
-                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env2)
-    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
-    two = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
+    bench = [sys.executable, os.path.join(ROOT, "bench.py")]
+    jobs = {"r1": (bench + ["--gpus", "1"] + common, env),
+            "r2": (bench + ["--gpus", "2", "--dist-backend", "gloo"] + [a for a in common if a != "--no-extras"], env2),
+            "r1t": (bench + ["--gpus", "1", "--leaf-rows", "true"] + common, env),
+            "r2t": (bench + ["--gpus", "2", "--dist-backend", "gloo", "--leaf-rows", "true"] + common, env2)}
+    procs = {k: subprocess.Popen(a, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k, (a, e) in jobs.items()}
+    res = {}
+    for k, p in procs.items():
+        so, se = p.communicate(timeout=900)
+        res[k] = (p.returncode, so, se)
+        assert p.returncode == 0, (k, so[-2000:], se[-4000:])
+    last_json = lambda so: json.loads([l for l in so.strip().splitlines() if l.startswith("{")][-1])
+    one, two = last_json(res["r1"][1]), last_json(res["r2"][1])
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "msm+leaf-shard2"
     assert one["state_digest"] == two["state_digest"]
     assert one["config"]["leaf_rows"] == "compat" and one["config"]["challenges"] == "poseidon-ro"      # the headline configuration
     assert two["secondary"]["microbench_msm_sharded"]["msm_uniform"]["n_gpus"] == 2
     # the intended leaf rows shard the same way
-    r1t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--leaf-rows", "true"] + common, capture_output=True,
-                         text=True, timeout=900, cwd=ROOT, env=env)
-    r2t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--leaf-rows", "true"] + common,
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env2)
-    assert r1t.returncode == 0 and r2t.returncode == 0, r2t.stdout[-2000:] + r2t.stderr[-4000:]
-    d1 = json.loads(r1t.stdout.strip().splitlines()[-1])["state_digest"]
-    d2 = json.loads([l for l in r2t.stdout.strip().splitlines() if l.startswith("{")][-1])["state_digest"]
+    d1, d2 = last_json(res["r1t"][1])["state_digest"], last_json(res["r2t"][1])["state_digest"]
     assert d1 == d2 and d1 != one["state_digest"]

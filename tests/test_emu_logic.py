@@ -24,6 +24,16 @@ def emu():
     _lib._lib = None          # the real library is (re)loaded lazily by later tests
 
 
+def _run_all(jobs, timeout=900):
+    """Independent subprocesses side by side (the emulator runs one kernel at a time per process): [(tag, argv, env)] -> {tag: CompletedProcess}"""
+    procs = [(tag, subprocess.Popen(argv, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for tag, argv, env in jobs]
+    out = {}
+    for tag, p in procs:
+        so, se = p.communicate(timeout=timeout)
+        out[tag] = subprocess.CompletedProcess(p.args, p.returncode, so, se)
+    return out
+
+
 def test_emu_commit(emu, oracle):
     O = oracle
     for cid, n, kind in ((0, 300, "uniform"), (1, 300, "trace"), (0, 1, "uniform")):
@@ -308,9 +318,8 @@ def test_emu_sharded_commit_upload_chunked():
     code = ("import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\nfrom sirius_amd import _lib\n"
             f"_lib.load({EMU_LIB!r})\nimport sirius_amd as S\n" + SHARDED_UPLOAD_CODE)
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    for chunks in ("1", "3"):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS=chunks), capture_output=True,
-                           text=True, timeout=900)
+    res = _run_all([(chunks, [sys.executable, "-c", code], dict(os.environ, SRS_COMMIT_CHUNKS=chunks)) for chunks in ("1", "3")])
+    for chunks, r in res.items():
         assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])
 
 
@@ -330,9 +339,9 @@ def test_emu_commit_pipeline_variants():
         "    assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases[:n])), (cid, n)\n"
         "print('ok')\n")
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    for extra in ({"SRS_COMMIT_SLOTS": "1"}, {"SRS_COMMIT_SLOTS": "1", "SRS_COMMIT_DEFER": "1"}):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS="3", **extra), capture_output=True,
-                           text=True, timeout=900)
+    variants = ({"SRS_COMMIT_SLOTS": "1"}, {"SRS_COMMIT_SLOTS": "1", "SRS_COMMIT_DEFER": "1"})
+    res = _run_all([(str(extra), [sys.executable, "-c", code], dict(os.environ, SRS_COMMIT_CHUNKS="3", **extra)) for extra in variants])
+    for extra, r in res.items():
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
 
 
@@ -371,7 +380,7 @@ def test_emu_sangria_step_merged_commits():
         "    pri = bench.SangriaSide(S, D, make_structure_inputs('primary', 4, seed=11), 8, 'primary')\n"
         "    sec = bench.SangriaSide(S, D, make_structure_inputs('secondary', 4, seed=12), 8, 'secondary')\n"
         "    pri.witness_commit(S, D, False); sec.witness_commit(S, D, False)\n"
-        "    for _ in range(2): bench.sangria_step(S, D, pri, sec, False, True)\n"
+        "    bench.sangria_step(S, D, pri, sec, False, True)\n"
         "    pri.settle(); sec.settle()\n"
         "    return [np.array(x).copy() for sd in (pri, sec) for x in (sd.accCW, sd.accCE, sd.inC, sd.r)]\n"
         "a, b = chain(False), chain(True)\n"
