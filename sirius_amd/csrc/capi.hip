@@ -26,6 +26,28 @@
 
 namespace srs {
 static thread_local std::string g_err;
+
+// SRS_HOST_TRACE=1: host-clock checkpoints of the composite entries (where the time BETWEEN kernels goes), printed to stderr per call
+#include <chrono>
+struct HostTrace {
+    const char *name;
+    bool on;
+    std::vector<std::pair<const char *, double>> pts;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    explicit HostTrace(const char *n) : name(n) {
+        static const bool enabled = [] { const char *e = std::getenv("SRS_HOST_TRACE"); return e && e[0] == '1'; }();
+        on = enabled;
+        if (on) pts.emplace_back("enter", now());
+    }
+    void mark(const char *what) { if (on) pts.emplace_back(what, now()); }
+    ~HostTrace() {
+        if (!on || pts.size() < 2) return;
+        std::string line = std::string("[srs host trace] ") + name + ":";
+        for (size_t i = 1; i < pts.size(); ++i) line += " " + std::string(pts[i].first) + " +" + std::to_string((long)(pts[i].second - pts[i - 1].second)) + "us";
+        line += " | total " + std::to_string((long)(pts.back().second - pts.front().second)) + "us, entered at " + std::to_string((long long)pts.front().second) + "\n";
+        fputs(line.c_str(), stderr);
+    }
+};
 // device scratch of the handle-less entry points (folds, lookup h/g) when they are given HOST operands: grow-only, one
 // per calling thread, so that a fold does not pay a hipMalloc + hipFree (an implicit device synchronisation) per call
 static thread_local srs::Arena g_scratch;
@@ -877,6 +899,7 @@ void upload_range(fe_t *dst, const std::vector<Seg> &segs, size_t a, size_t b, h
 // accumulates only THIS rank's block-cyclic stripes of its range -- the same overlap of upload and MSM, 1 / world of both per rank.
 int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const std::vector<size_t> &cut, fe_t *dst, int repr,
                     hipStream_t st, srs_affine *out) {
+    HostTrace ht("commit_streamed");
     const size_t chunks = cut.size() - 1;
     const uint32_t W = ck->key.world, R = ck->key.rank;
     const size_t SL = (size_t)1 << msm::STRIPE_LOG;
@@ -954,8 +977,10 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
         if (j + 1 < chunks) upload(j + 1);
         launch(j);
     }
+    ht.mark("enqueued");
     SRS_HIP_CHECK(hipStreamSynchronize(st));
     SRS_HIP_CHECK(hipGetLastError());
+    ht.mark("device done");
     auto go = [&](auto tag) {
         using C = decltype(tag);
         xyzz_t acc = Ec<C>::identity(), part;
@@ -967,7 +992,9 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
         std::memcpy(out, &a, sizeof(a));
     };
     if (ck->key.curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
+    ht.mark("host finish");
     prof::collect();
+    ht.mark("prof");
     return SRS_OK;
 }
 
@@ -2111,6 +2138,7 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
     int rc = ensure_device();
     if (rc) return rc;
     return guarded([&]() -> int {
+        HostTrace ht("srs_pg_prove");
         hipStream_t st = (hipStream_t)stream;
         rowprog::Structure *s = S->s;
         rowprog::PgSizes z;
@@ -2128,6 +2156,7 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
         int erc = rowprog::pg_sum(s, 0, dW.data(), ch.data(), n_challenges, 1, reinterpret_cast<const fe_t *>(betas), n_betas,
                                   reinterpret_cast<const fe_t *>(delta), reference_compat, st, reinterpret_cast<fe_t *>(poly_F), &n_out, err);
         if (erc) return fail(erc, "srs_pg_prove (compute_F): " + err);
+        ht.mark("compute_F");
         // alpha = ro.absorb(poly_F).squeeze(MAX_BITS)                                                     :424-427
         fe_t alpha, gamma;
         std::memcpy(&alpha, &alpha_gamma[0], 32);
@@ -2149,21 +2178,25 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
             }
         }
         const fe_t f_alpha = rowprog::poly_eval(reinterpret_cast<const fe_t *>(poly_F), z.points_F, alpha);
+        ht.mark("alpha,betas'");
         // poly_K = compute_K(F(alpha), betas_stroke, accumulator, incoming)                               :437-443
         std::vector<fe_t> poly_G(z.points_G);
         // G(1) = F(alpha) by definition (rowprog.hip, pg_sum): one evaluation point less for the leaf kernel
         erc = rowprog::pg_sum(s, 1, dW.data(), ch.data(), n_challenges, n_instances, bs.data(), bs.size(), nullptr, reference_compat, st,
                               poly_G.data(), &n_out, err, &f_alpha);
         if (erc) return fail(erc, "srs_pg_prove (compute_G): " + err);
+        ht.mark("compute_G");
         erc = rowprog::pg_K_from_G(poly_G.data(), poly_G.size(), f_alpha, z.instances_to_fold, z.log_domain_K, st,
                                    reinterpret_cast<fe_t *>(poly_K), err);
         if (erc) return fail(erc, "srs_pg_prove (compute_K_from_G): " + err);
+        ht.mark("compute_K");
         const size_t n_K = (size_t)1 << z.log_domain_K;
         // gamma = ro.absorb(poly_K).squeeze(MAX_BITS)                                                     :445-448
         if (ro) {
             poseidon::absorb(*ro->h, reinterpret_cast<const fe_t *>(poly_K), n_K);
             if (!poseidon::squeeze(*ro->h, 255, SRS_FIELD_FR, gamma, err)) return fail(SRS_ERR_INVALID, "srs_pg_prove (gamma): " + err);
         }
+        ht.mark("gamma");
         // L_j(gamma), e = F(alpha) L_0(gamma) + Z(gamma) K(gamma)  (calculate_e :748-764), fold_witness :176-210
         const std::vector<fe_t> L = rowprog::lagrange_eval(gamma, (uint32_t)z.lagrange_domain);
         const fe_t zg = Fr::sub(Fr::pow_u64(gamma, (uint64_t)1 << z.lagrange_domain), Fr::one());
@@ -2178,6 +2211,7 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
         std::memcpy(betas_stroke, bs.data(), bs.size() * sizeof(fe_t));
         std::memcpy(e, &ev, 32);
         std::memcpy(lagrange, L.data(), n_instances * sizeof(fe_t));
+        ht.mark("e,L,fold");
         return SRS_OK;
     });
 }
@@ -2201,6 +2235,7 @@ static int sangria_prove_impl(srs_structure *S, srs_ck *ck, srs_poseidon *ro, co
     if (rowprog::shard_world(S->s) > 1 || ck->key.world > 1)   // partial cross-term commitments: the challenge needs the exchanged ones
         return fail(SRS_ERR_INVALID, "srs_sangria_prove: structure / key is sharded over processes; use the step-wise calls and add the ranks' partial commitments");
     const size_t d = srs_structure_num_cross_terms(S), rows = rowprog::rows(S->s), wlen = rowprog::num_witness_columns(S->s) * rows;
+    HostTrace ht("srs_sangria_prove");
     int rc;
     if (!incoming) {
         rc = srs_commit_cross_terms(S, ck, W1, W2, challenges, n_challenges, SRS_SPACE_DEVICE, stream, T_dev, cross_term_commits);
@@ -2243,6 +2278,7 @@ static int sangria_prove_impl(srs_structure *S, srs_ck *ck, srs_poseidon *ro, co
             }
         }
     }
+    ht.mark("cross terms + commitments");
     fe_t r;
     std::memcpy(&r, r_io, 32);
     if (ro) {       // generate_challenge (:162-179): the caller has absorbed pp_digest, U1, U2; the commitments and the squeeze happen here
@@ -2254,6 +2290,7 @@ static int sangria_prove_impl(srs_structure *S, srs_ck *ck, srs_poseidon *ro, co
         if (rc) return rc;
         std::memcpy(r_io, &r, 32);
     }
+    ht.mark("challenge");
     // W' = W1 + r W2, E' = E + sum r^k T_k  (accumulator.rs:364-404): stream-ordered, in place
     rc = srs_fold_witness(sf, W1, W1, W2, reinterpret_cast<const srs_fe *>(&r), wlen, SRS_SPACE_DEVICE, stream);
     if (rc) return rc;
@@ -2267,6 +2304,7 @@ static int sangria_prove_impl(srs_structure *S, srs_ck *ck, srs_poseidon *ro, co
     if (rc) return rc;
     rc = srs_point_lincomb_async(curve, E_commitment, cross_term_commits, rp.data(), d, SRS_REPR_MONT, &folded_commitments[1], &jobs[1]);
     if (rc) (void)srs_job_wait(jobs[0]);     // never leave job 0 writing into folded_commitments[0] after an error return
+    ht.mark("folds queued");
     return rc;
 }
 

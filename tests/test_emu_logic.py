@@ -183,6 +183,11 @@ def test_emu_two_pass_scatter():
         "assert np.array_equal(ck.commit(vd), O.msm(1, vd, bases[:len(vals)]))\n"
         "vm = np.concatenate([vd[:2500], seeded_scalars(O, 1, 1500, 7, 'uniform'), seeded_scalars(O, 1, 600, 8, 'trace')])\n"
         "assert np.array_equal(ck.commit(vm), O.msm(1, vm, bases[:len(vm)]))\n"
+        "# extremes: one bucket holds everything / nothing to sort / one entry\n"
+        "q = __import__('oracle.pyref', fromlist=['x']).CURVES[1].q\n"
+        "for vals in ([1] * 9000, [0] * 5000, [0] * 4999 + [q - 1], [(1 << 16) - 1] * 700 + [1 << 255 >> 2] * 9):\n"
+        "    ve = O.ints_to_mont(O.SCALAR_FIELD[1], [x % q for x in vals])\n"
+        "    assert np.array_equal(ck.commit(ve), O.msm(1, ve, bases[:len(vals)])), vals[-1]\n"
         "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT="2"), capture_output=True, text=True,
                        timeout=1800)
