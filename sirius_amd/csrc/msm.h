@@ -43,8 +43,8 @@ constexpr uint32_t NSEG_W = 16;           // 2^(WBITS_W - 1) / NBUCKET
 constexpr uint32_t WIDE_THREADS = 256, WIDE_PER = 2, WIDE_TILE = WIDE_THREADS * WIDE_PER;   // scalars per workgroup of the segment passes
 // Measured (profiles/r02_wide_windows.txt): the wide pipeline wins from ~8 M scalars (12 * 2^20 uniform: 20.3 vs 22.2 ms);
 // below, its 16 bucket reductions and the extra grouping pass cost more than the 3 / 16 of the additions it saves.
-constexpr uint32_t WIDE_MIN_KEY_LOG = 23; // keys from 2^23 bases get the second (13-window) table (SRS_MSM_WIDE=0 / 1: never / always)
-constexpr uint32_t WIDE_MIN_N_LOG = 23;   // MSMs from 2^23 scalars take the wide path (SRS_MSM_WIDE_MIN=<log2> overrides)
+constexpr uint32_t WIDE_MIN_KEY_LOG = 23; // (r02: keys from 2^23 bases got the second, 13-window table; r03: only with SRS_MSM_WIDE=1, see wants_wide_table)
+constexpr uint32_t WIDE_MIN_N_LOG = 23;   // with SRS_MSM_WIDE=1: MSMs from 2^23 scalars take the wide path (SRS_MSM_WIDE_MIN=<log2> overrides)
 
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
 static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
@@ -70,7 +70,7 @@ struct Key {
     uint32_t rank = 0, world = 1;
     bool compact_scalars = false;   // world > 1: the scalar vectors handed to run() hold ONLY this rank's stripes, gathered (multi-device keys)
     affine_t *table = nullptr;
-    affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (keys of >= 2^WIDE_MIN_KEY_LOG bases; owned by the key: release())
+    affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (only with SRS_MSM_WIDE=1; owned by the key: release())
     xyzz_t *fold_buckets = nullptr;   // running bucket sums of a chunked commit (enqueue(.., fold)); owned by the key
     bool slot_wide[LANDING_SLOTS] = {};       // landing slot -> which pipeline produced it (finish() combines 3 or 4 partial sums)
     Chunked chunked;          // layout of the running chunked commit (pointers into `arena`)
@@ -78,7 +78,7 @@ struct Key {
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
 };
 
-// fills table[len .. 16*len) from table[0 .. len); keys of >= 2^WIDE_MIN_KEY_LOG bases also get table_w
+// fills table[len .. 16*len) from table[0 .. len); with SRS_MSM_WIDE=1 the key also gets table_w
 void build_table(Key &k, hipStream_t stream);
 // frees what the key owns besides `table`: table_w, the scratch arena, the landing buffer
 void release(Key &k);

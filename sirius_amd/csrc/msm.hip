@@ -1273,11 +1273,13 @@ static void expand_windows(affine_t *table, uint32_t n, int nwin, int nbits, xyz
     }
 }
 
+// r03: with the two-pass sort through LDS the 16-bit windows beat the 20-bit ones at every size measured (2^24 uniform 22.1 vs 25.8 ms,
+// trace-like 10.8 vs 12.1; k = 22 step 41.9 vs 44.0 ms: profiles/r03_ab_wide_vs_narrow.txt) -- the wide pipeline's own counting sort
+// still stores entry by entry.  It is therefore OFF unless SRS_MSM_WIDE=1 asks for it (then: the second table for every key, wide
+// from 2^WIDE_MIN_N_LOG scalars / SRS_MSM_WIDE_MIN); keys no longer pay the +81 % of table memory.
 static bool wants_wide_table(size_t len) {
-    static const int forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();   // 0: never, 1: always
-    if (forced == 0) return false;
-    if (forced == 1) return len > 0;
-    return len >= ((size_t)1 << WIDE_MIN_KEY_LOG);
+    static const int forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();   // 1: on, else off
+    return forced == 1 && len > 0;
 }
 
 template <class C>
