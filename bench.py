@@ -312,7 +312,7 @@ class PgPrimary:
         # fold_witness deferred (DEFER_FOLD): nothing reads the folded witness before the next prove, so the 1.2 GB pass is queued on
         # a second stream when the next witness starts to come up (the device waits for PCIe there) -- into a SECOND incoming buffer
         self.inW_next = up(D, w["W2"]) if DEFER_FOLD and not self.sharded else None
-        self.lag, self.side = None, None
+        self.lag, self.side, self.fold_pending = None, None, False
         if self.inW_next is not None and self.inW.is_cuda:
             import torch
             self.side = torch.cuda.Stream()
@@ -377,7 +377,7 @@ class PgPrimary:
     def fold_done(self):
         """whatever reads accW next (the next prove, the digest) comes after the deferred fold"""
         self.fold_start()
-        if getattr(self, "fold_pending", False) and self.side is not None:
+        if self.fold_pending and self.side is not None:
             import torch
             torch.cuda.current_stream().wait_stream(self.side)
         self.fold_pending = False
