@@ -1502,12 +1502,9 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
     const Link *no_link = nullptr;
     SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap, no_link);
-    {
-        prof::Scope ps("msm_accum0", stream, units);
-        SRS_LAUNCH((k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
-                   (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride, (const uint16_t *)tb, (size_t)parts0_cap,
-                   (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log, no_link);
-    }
+    SRS_LAUNCH_TIMED("msm_accum0", units, (k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+                     (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride, (const uint16_t *)tb, (size_t)parts0_cap,
+                     (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log, no_link);
     xyzz_t *cur = ping, *nxt = pong;
     size_t cur_stride = parts0_cap, nxt_stride = parts1_cap;
     uint64_t cap = parts0_cap;
@@ -1636,12 +1633,9 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     SRS_LAUNCH(k_link, (1), (64), 0, stream, (const uint32_t *)plan, w.plan_stride, w.levels, link);
     const Link *lk = link;
     SRS_LAUNCH(k_expand, (NBUCKET / 4, NSEG_W), (256), 0, stream, (const uint32_t *)plan, w.plan_stride, tb, (size_t)0, lk);
-    {
-        prof::Scope ps("msm_accum0", stream, n);
-        SRS_LAUNCH((k_accum0<C>), (ceil_div(w.parts0_cap, ACC_THREADS)), (ACC_THREADS), 0, stream, (const uint32_t *)sorted, (size_t)0,
-                   (const uint32_t *)plan, w.plan_stride, (const uint16_t *)tb, (size_t)0, (const affine_t *)k.table_w, ping, (size_t)0,
-                   1u << w.l0_log, lk);
-    }
+    SRS_LAUNCH_TIMED("msm_accum0", n, (k_accum0<C>), (ceil_div(w.parts0_cap, ACC_THREADS)), (ACC_THREADS), 0, stream, (const uint32_t *)sorted,
+                     (size_t)0, (const uint32_t *)plan, w.plan_stride, (const uint16_t *)tb, (size_t)0, (const affine_t *)k.table_w, ping, (size_t)0,
+                     1u << w.l0_log, lk);
     xyzz_t *cur = ping, *nxt = pong;
     uint64_t cap = w.parts0_cap;
     for (int level = 1; level < w.levels; ++level) {

@@ -7,6 +7,9 @@
 #include <vector>
 
 #include "devrt.h"
+#if !defined(SRS_EMU)
+#include <hip/hip_ext.h>
+#endif
 
 namespace srs {
 namespace prof {
@@ -63,6 +66,50 @@ struct Scope {
         s.pending.push_back(p);
     }
 };
+
+// The same timing for ONE kernel launch without event packets around it: the two events are bound to the kernel's own dispatch
+// (hipExtLaunchKernelGGL), so the stream carries no extra markers -- a Scope's hipEventRecord pair costs ~9 us of idle device before
+// and after the kernel it brackets (r03 kernel traces: the only gaps inside an MSM chunk were the two around k_accum0).
+struct KernelEvents {
+    bool live = false;
+    Pending p;
+    KernelEvents(const char *name, uint64_t units) {
+        State &s = state();
+        if (!s.on) return;
+        std::lock_guard<std::mutex> lk(s.mu);
+        auto take = [&]() {
+            hipEvent_t e;
+            if (!s.pool.empty()) { e = s.pool.back(); s.pool.pop_back(); return e; }
+            if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        p.name = name;
+        p.units = units;
+        p.e0 = take();
+        p.e1 = take();
+        live = p.e0 && p.e1;
+    }
+    void launched() {
+        State &s = state();
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.pending.push_back(p);
+    }
+};
+#if defined(SRS_EMU)
+#define SRS_LAUNCH_TIMED(name, units, kernel, grid, block, smem, stream, ...) SRS_LAUNCH(kernel, grid, block, smem, stream, __VA_ARGS__)
+#else
+#define SRS_LAUNCH_TIMED(name, units, kernel, grid, block, smem, stream, ...)                                                        \
+    do {                                                                                                                            \
+        ::srs::prof::KernelEvents ke_(name, units);                                                                                 \
+        if (ke_.live) {                                                                                                             \
+            hipExtLaunchKernelGGL(kernel, dim3 grid, dim3 block, (uint32_t)(smem), (hipStream_t)(stream), ke_.p.e0, ke_.p.e1, 0u,   \
+                                  __VA_ARGS__);                                                                                     \
+            ke_.launched();                                                                                                         \
+        } else {                                                                                                                    \
+            SRS_LAUNCH(kernel, grid, block, smem, stream, __VA_ARGS__);                                                             \
+        }                                                                                                                           \
+    } while (0)
+#endif
 
 // call after the stream has been synchronised: folds finished event pairs into the statistics
 void collect();
