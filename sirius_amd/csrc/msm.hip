@@ -190,11 +190,16 @@ struct BatchDesc {
 };
 
 template <class C>
-__global__ void k_digits(BatchDesc bd, uint16_t *__restrict__ dig, size_t dig_stride, int is_mont, uint32_t rank, uint32_t world) {
+__global__ void k_digits(BatchDesc bd, uint16_t *__restrict__ dig, size_t dig_stride, int is_mont, uint32_t rank, uint32_t world,
+                         uint32_t *__restrict__ count_zero, uint32_t n_zero) {
     using S = typename C::S;
     uint32_t m = blockIdx.y;
     uint32_t n = bd.n[m];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the bucket counters k_hist adds into start at zero: cleared here (k_digits precedes k_hist on the stream) instead of by a
+    // memset launch of its own per MSM
+    for (uint32_t j = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; j < n_zero; j += gridDim.x * gridDim.y * blockDim.x)
+        count_zero[j] = 0;
     if (i >= n) return;
     fe_t s = bd.ptr[m][shard_global_index(i, rank, world)];
     if (is_mont) s = S::from_mont(s);
@@ -1470,10 +1475,8 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
         bd.n[m] = m < batch ? n_host[m] : 0;
         bd.base[m] = (m < batch && base_host) ? base_host[m] : 0;
     }
-    SRS_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)NBUCKET * batch * sizeof(uint32_t), stream));
-
     SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont,
-               k.compact_scalars ? 0u : k.rank, k.compact_scalars ? 1u : k.world);
+               k.compact_scalars ? 0u : k.rank, k.compact_scalars ? 1u : k.world, count, (uint32_t)(NBUCKET * batch));
     // tile = digits per workgroup: large enough that the fixed 2^15-bin zero/scan of the LDS histogram is
     // amortised, small enough to give ~SORT_TARGET_BLOCKS workgroups (one per CU, 128 KiB LDS each)
     uint32_t tile = (uint32_t)(((uint64_t)n_max * NWIN * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
@@ -1697,7 +1700,7 @@ static void chunked_front_t(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_
         bd.base[m] = m == 0 ? base : 0;
     }
     SRS_LAUNCH((k_digits<C>), (ceil_div(n, 256), 1), (256), 0, s_sort, bd, dig, (size_t)M, is_mont, k.compact_scalars ? 0u : k.rank,
-               k.compact_scalars ? 1u : k.world);
+               k.compact_scalars ? 1u : k.world, (uint32_t *)nullptr, 0u);      // the slots' counters are cleared by chunked_begin
     uint32_t tile = (uint32_t)(((uint64_t)n * NWIN + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
     tile = (tile + 1023u) & ~1023u;
     if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
