@@ -643,7 +643,8 @@ __global__ void SRS_KERNEL_BOUNDS(WIDE_THREADS, 1)
 // tile_base[v] = first workgroup of segment v when every segment is cut into tiles of `tile_g` entries.
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_seg_scan(uint32_t *__restrict__ tile_cnt, uint32_t T, const uint32_t *__restrict__ seg_total, uint32_t *__restrict__ seg_off,
-               uint32_t *__restrict__ tile_base /* [NSEG_W + 1], then the tile size */) {
+               uint32_t *__restrict__ tile_base /* [NSEG_W + 1], then the tile size */,
+               uint32_t *__restrict__ tile_base2 /* [NSEG_W + 1]: the same for tiles of SORT_TILE2 entries (k_scatter2_g) */) {
     __shared__ uint32_t lds[64];
     const uint32_t v = blockIdx.x;
     uint32_t base = 0;
@@ -666,6 +667,12 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
         }
         seg_off[NSEG_W] = run;
         tile_base[NSEG_W] = tr;
+        uint32_t t2 = 0;
+        for (uint32_t u = 0; u < NSEG_W; ++u) {
+            tile_base2[u] = t2;
+            t2 += (seg_total[u] + SORT_TILE2 - 1) / SORT_TILE2;
+        }
+        tile_base2[NSEG_W] = t2;
     }
     uint32_t *row = tile_cnt + (size_t)v * T;
     uint32_t carry = 0;
@@ -694,7 +701,7 @@ __device__ __forceinline__ bool wide_tile(const uint32_t *__restrict__ seg_off, 
 
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     k_hist_g(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ tile_base,
-             uint32_t *__restrict__ count /* [NSEG_W][NBUCKET] */) {
+             uint32_t *__restrict__ count /* [NSEG_W][NBUCKET] */, uint32_t *__restrict__ tile_hist /* [SEG][gridDim.x] or nullptr */) {
     __shared__ uint32_t h[NBUCKET];
     uint32_t v, lo, hi;
     if (!wide_tile(seg_off, tile_base, v, lo, hi)) return;
@@ -703,6 +710,143 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     for (uint32_t b = threadIdx.x; b < NBUCKET; b += blockDim.x) {
         uint32_t c = h[b];
         if (c) atomicAdd(&cnt[b], c);
+    }
+    if (tile_hist) {                       // entries of this tile per sub-segment (= SEG_BUCKETS consecutive buckets of its segment)
+        for (uint32_t sgm = threadIdx.x; sgm < SEG; sgm += blockDim.x) {
+            uint32_t c = 0;
+            for (uint32_t b = 0; b < SEG_BUCKETS; ++b) c += h[sgm * SEG_BUCKETS + ((b + sgm) & (SEG_BUCKETS - 1))];
+            tile_hist[(size_t)sgm * gridDim.x + blockIdx.x] = c;
+        }
+    }
+}
+
+// ---- the wide pipeline's counting sort in two passes through LDS (r03; the narrow pipeline's k_group / k_scatter2 on the grouped pairs of a
+// segment): k_scan_seg_g turns the per-tile sub-segment counts into offsets, k_group_g sorts sub-tiles of a tile's pairs by sub-segment
+// inside LDS and copies the runs out, k_scatter2_g sorts 8192-entry tiles of a segment by bucket inside LDS.
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_scan_seg_g(uint32_t *__restrict__ tile_hist, uint32_t TG, const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ plan,
+                 size_t plan_stride) {
+    // grid = (SEG, NSEG_W): the tiles of segment v are the workgroups tile_base[v] .. tile_base[v + 1] of k_hist_g
+    __shared__ uint32_t lds[64];
+    const uint32_t sgm = blockIdx.x, v = blockIdx.y;
+    const uint32_t t0 = tile_base[v], t1 = tile_base[v + 1];
+    uint32_t *row = tile_hist + (size_t)sgm * TG;
+    const uint32_t base = plan[(size_t)v * plan_stride + (size_t)sgm * SEG_BUCKETS];        // absolute entry offset of the sub-segment's first bucket
+    uint32_t carry = 0;
+    for (uint32_t at = t0; at < t1; at += blockDim.x) {                                     // workgroup-uniform
+        const uint32_t i = at + threadIdx.x;
+        const uint32_t c = i < t1 ? row[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(c, lds, &total);
+        if (i < t1) row[i] = base + carry + ex;
+        carry += total;
+    }
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_group_g(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ gpay, const uint32_t *__restrict__ seg_off,
+              const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ tile_hist, uint16_t *__restrict__ gkey2,
+              uint32_t *__restrict__ gpay2) {
+    __shared__ uint32_t cur[SEG], cnt[SEG], lb[SEG], sc[64];
+    __shared__ uint32_t spay[GRP_SUB];
+    __shared__ uint16_t skey[GRP_SUB];
+    const uint32_t tid = threadIdx.x;
+    uint32_t v, lo, hi;
+    if (!wide_tile(seg_off, tile_base, v, lo, hi)) return;
+    for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cur[sgm] = tile_hist[(size_t)sgm * gridDim.x + blockIdx.x];
+    for (uint32_t sub = lo; sub < hi; sub += GRP_SUB) {                 // workgroup-uniform
+        for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cnt[sgm] = 0;
+        __syncthreads();
+        uint32_t key[GRP_PER], pay[GRP_PER], rank[GRP_PER];
+#pragma unroll
+        for (uint32_t k = 0; k < GRP_PER; ++k) {                        // lane-consecutive entries: coalesced 2- and 4-byte loads
+            const uint32_t i = sub + k * SORT_THREADS + tid;
+            key[k] = i < hi ? (uint32_t)gkey[i] : 0xFFFFu;
+            pay[k] = i < hi ? gpay[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < GRP_PER; ++k) rank[k] = key[k] != 0xFFFFu ? atomicAdd(&cnt[key[k] / SEG_BUCKETS], 1u) : 0u;
+        __syncthreads();
+        uint32_t n_sub;
+        const uint32_t ex = block_exclusive_scan(tid < SEG ? cnt[tid] : 0u, sc, &n_sub);
+        if (tid < SEG) lb[tid] = ex;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < GRP_PER; ++k) {
+            if (key[k] != 0xFFFFu) {
+                const uint32_t pos = lb[key[k] / SEG_BUCKETS] + rank[k];
+                skey[pos] = (uint16_t)key[k];
+                spay[pos] = pay[k];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n_sub; i += blockDim.x) {
+            const uint32_t kk = skey[i], sgm = kk / SEG_BUCKETS, g = cur[sgm] + (i - lb[sgm]);
+            gkey2[g] = (uint16_t)kk;
+            gpay2[g] = spay[i];
+        }
+        __syncthreads();
+        if (tid < SEG) cur[tid] += cnt[tid];
+    }
+}
+
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
+    k_scatter2_g(const uint16_t *__restrict__ gkey2, const uint32_t *__restrict__ gpay2, const uint32_t *__restrict__ seg_off,
+                 const uint32_t *__restrict__ tile_base2, uint32_t *__restrict__ cursor /* [NSEG_W][NBUCKET], absolute */,
+                 uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t cnt[S2_RANGE], lb[S2_RANGE], gb[S2_RANGE], sc[64];
+    __shared__ uint32_t spay[SORT_TILE2];
+    __shared__ uint16_t skey[SORT_TILE2];
+    const uint32_t tid = threadIdx.x;
+    // XCD-aware tile mapping as in k_scatter2: every XCD sorts one contiguous eighth of the flat tile space
+    const uint32_t n_tiles = tile_base2[NSEG_W], per_xcd = (n_tiles + 7) / 8;
+    if (blockIdx.x / 8 >= per_xcd) return;
+    const uint32_t tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile_id >= n_tiles) return;
+    const uint32_t v = link_segment(tile_base2, tile_id);
+    const uint32_t lo = seg_off[v] + (tile_id - tile_base2[v]) * SORT_TILE2;
+    const uint32_t hi = lo + SORT_TILE2 < seg_off[v + 1] ? lo + SORT_TILE2 : seg_off[v + 1];
+    if (lo >= hi) return;
+    uint32_t *cur = cursor + (size_t)v * NBUCKET;
+    // the grouped array of a segment is ordered by sub-segment: this tile only holds buckets of sub-segments seg(first) .. seg(last)
+    const uint32_t b_lo = ((uint32_t)gkey2[lo] / SEG_BUCKETS) * SEG_BUCKETS;
+    const uint32_t b_hi = ((uint32_t)gkey2[hi - 1] / SEG_BUCKETS + 1) * SEG_BUCKETS;
+    if (b_hi - b_lo > S2_RANGE) {            // a tile over more than two sub-segments (few entries for the bucket range): entry by entry
+        for (uint32_t i = lo + tid; i < hi; i += blockDim.x) sorted[atomicAdd(&cur[gkey2[i]], 1u)] = gpay2[i];
+        return;
+    }
+    for (uint32_t b = tid; b < S2_RANGE; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    uint32_t kk[S2_PER], pp[S2_PER], rank[S2_PER];
+#pragma unroll
+    for (uint32_t k = 0; k < S2_PER; ++k) {
+        const uint32_t i = lo + k * SORT_THREADS + tid;
+        kk[k] = i < hi ? (uint32_t)gkey2[i] : 0xFFFFu;
+        pp[k] = i < hi ? gpay2[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < S2_PER; ++k) rank[k] = kk[k] != 0xFFFFu ? atomicAdd(&cnt[kk[k] - b_lo], 1u) : 0u;
+    __syncthreads();
+    uint32_t n_tile;
+    const uint32_t c = tid < S2_RANGE ? cnt[tid] : 0u;
+    const uint32_t ex = block_exclusive_scan(c, sc, &n_tile);
+    if (tid < S2_RANGE) {
+        lb[tid] = ex;
+        gb[tid] = c ? atomicAdd(&cur[b_lo + tid], c) : 0u;                 // reserve [base, base + c) of the bucket (absolute)
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < S2_PER; ++k) {
+        if (kk[k] != 0xFFFFu) {
+            const uint32_t pos = lb[kk[k] - b_lo] + rank[k];
+            skey[pos] = (uint16_t)(kk[k] - b_lo);
+            spay[pos] = pp[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_tile; i += blockDim.x) {
+        const uint32_t b = skey[i];
+        sorted[gb[b] + (i - lb[b])] = spay[i];
     }
 }
 
@@ -1571,8 +1715,10 @@ static size_t workspace_bytes_wide(uint32_t n) {
     size_t b = 0;
     b += Arena::pad((4 + 4 * NSEG_W) * sizeof(xyzz_t));                          // results
     b += Arena::pad(w.M * sizeof(uint16_t)) + 2 * Arena::pad(w.M * sizeof(uint32_t));   // grouped keys / payloads, sorted
+    b += Arena::pad(w.M * sizeof(uint16_t)) + Arena::pad(w.M * sizeof(uint32_t));       // ... grouped again by sub-segment (two-pass sort)
+    b += Arena::pad((size_t)SEG * w.tiles_g * sizeof(uint32_t));                 // per-tile sub-segment counts
     b += Arena::pad((size_t)NSEG_W * w.T * sizeof(uint32_t));                    // per-tile segment counts
-    b += Arena::pad(3 * (NSEG_W + 2) * sizeof(uint32_t)) + Arena::pad(sizeof(Link));
+    b += Arena::pad(4 * (NSEG_W + 2) * sizeof(uint32_t)) + Arena::pad(sizeof(Link));
     b += 2 * Arena::pad((size_t)NSEG_W * NBUCKET * sizeof(uint32_t));            // count, cursor
     b += Arena::pad(w.plan_stride * NSEG_W * sizeof(uint32_t));
     b += Arena::pad(w.parts0_cap * sizeof(xyzz_t)) + Arena::pad(w.parts0_cap * sizeof(uint16_t));   // ping, map
@@ -1599,8 +1745,14 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     uint32_t *gpay = A.take<uint32_t>(w.M);
     uint32_t *sorted = A.take<uint32_t>(w.M);
     uint32_t *tile_cnt = A.take<uint32_t>((size_t)NSEG_W * w.T);
-    uint32_t *seg3 = A.take<uint32_t>(3 * (NSEG_W + 2));
-    uint32_t *seg_total = seg3, *seg_off = seg3 + (NSEG_W + 2), *tile_base = seg3 + 2 * (NSEG_W + 2);
+    // the counting sort inside the segments: two passes through LDS (k_group_g + k_scatter2_g) unless SRS_MSM_WIDE_SORT=1 asks for the
+    // single pass (k_scatter_g: every entry stored on its own)
+    static const bool two_pass = [] { const char *e = std::getenv("SRS_MSM_WIDE_SORT"); return !(e && e[0] == '1'); }();
+    uint16_t *gkey2 = two_pass ? A.take<uint16_t>(w.M) : nullptr;
+    uint32_t *gpay2 = two_pass ? A.take<uint32_t>(w.M) : nullptr;
+    uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * w.tiles_g) : nullptr;
+    uint32_t *seg3 = A.take<uint32_t>(4 * (NSEG_W + 2));
+    uint32_t *seg_total = seg3, *seg_off = seg3 + (NSEG_W + 2), *tile_base = seg3 + 2 * (NSEG_W + 2), *tile_base2 = seg3 + 3 * (NSEG_W + 2);
     Link *link = A.take<Link>(1);
     uint32_t *count = A.take<uint32_t>((size_t)NSEG_W * NBUCKET);
     uint32_t *cursor = A.take<uint32_t>((size_t)NSEG_W * NBUCKET);
@@ -1625,14 +1777,24 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     SRS_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)NSEG_W * NBUCKET * sizeof(uint32_t), stream));
     SRS_LAUNCH((k_seg_pass<C, false>), (w.T), (WIDE_THREADS), 0, stream, wd, tile_cnt, w.T, seg_total, (uint16_t *)nullptr,
                (uint32_t *)nullptr, table_stride);
-    SRS_LAUNCH(k_seg_scan, (NSEG_W), (1024), 0, stream, tile_cnt, w.T, (const uint32_t *)seg_total, seg_off, tile_base);
+    SRS_LAUNCH(k_seg_scan, (NSEG_W), (1024), 0, stream, tile_cnt, w.T, (const uint32_t *)seg_total, seg_off, tile_base, tile_base2);
     SRS_LAUNCH((k_seg_pass<C, true>), (w.T), (WIDE_THREADS), 0, stream, wd, tile_cnt, w.T, seg_total, gkey, gpay, table_stride);
     SRS_LAUNCH(k_hist_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)seg_off,
-               (const uint32_t *)tile_base, count);
+               (const uint32_t *)tile_base, count, tile_hist);
     SRS_LAUNCH(k_plan, (NSEG_W, w.levels + 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, w.plan_stride, w.levels, w.l0_log,
                (uint32_t)ACC_L1_LOG, (const uint32_t *)seg_off);
-    SRS_LAUNCH(k_scatter_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay,
-               (const uint32_t *)seg_off, (const uint32_t *)tile_base, cursor, sorted);
+    if (two_pass) {
+        SRS_LAUNCH(k_scan_seg_g, (SEG, NSEG_W), (1024), 0, stream, tile_hist, w.tiles_g, (const uint32_t *)tile_base, (const uint32_t *)plan,
+                   w.plan_stride);
+        SRS_LAUNCH(k_group_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay, (const uint32_t *)seg_off,
+                   (const uint32_t *)tile_base, (const uint32_t *)tile_hist, gkey2, gpay2);
+        // tiles of SORT_TILE2 entries cut per segment: at most M / SORT_TILE2 + NSEG_W of them; 8 x ceil(. / 8) workgroups (XCD mapping)
+        SRS_LAUNCH(k_scatter2_g, (8 * ceil_div(ceil_div(w.M, SORT_TILE2) + NSEG_W, 8)), (SORT_THREADS), 0, stream, (const uint16_t *)gkey2,
+                   (const uint32_t *)gpay2, (const uint32_t *)seg_off, (const uint32_t *)tile_base2, cursor, sorted);
+    } else {
+        SRS_LAUNCH(k_scatter_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay,
+                   (const uint32_t *)seg_off, (const uint32_t *)tile_base, cursor, sorted);
+    }
     SRS_LAUNCH(k_link, (1), (64), 0, stream, (const uint32_t *)plan, w.plan_stride, w.levels, link);
     const Link *lk = link;
     SRS_LAUNCH(k_expand, (NBUCKET / 4, NSEG_W), (256), 0, stream, (const uint32_t *)plan, w.plan_stride, tb, (size_t)0, lk);
