@@ -1422,10 +1422,12 @@ static void expand_windows(affine_t *table, uint32_t n, int nwin, int nbits, xyz
     }
 }
 
-// r03: with the two-pass sort through LDS the 16-bit windows beat the 20-bit ones at every size measured (2^24 uniform 22.1 vs 25.8 ms,
-// trace-like 10.8 vs 12.1; k = 22 step 41.9 vs 44.0 ms: profiles/r03_ab_wide_vs_narrow.txt) -- the wide pipeline's own counting sort
-// still stores entry by entry.  It is therefore OFF unless SRS_MSM_WIDE=1 asks for it (then: the second table for every key, wide
-// from 2^WIDE_MIN_N_LOG scalars / SRS_MSM_WIDE_MIN); keys no longer pay the +81 % of table memory.
+// r03: with the narrow pipeline's two-pass sort and the wide pipeline still on its entry-by-entry counting sort the 16-bit windows won at
+// every size (2^24 uniform 22.1 vs 25.8 ms, k = 22 step 41.9 vs 44.0 ms: profiles/r03_ab_wide_vs_narrow.txt), so the wide pipeline went
+// OFF by default (no second table: -45 % key memory).  Later in r03 its segments got the same two passes (k_group_g / k_scatter2_g) and it
+// is ahead again from ~12 M scalars -- 2^24 uniform 20.5 vs 22.5 ms, trace-like 10.4 vs 10.8; 12 * 2^20: 16.2 vs 16.9 / 8.2 vs 8.3; green
+// against the oracle at 2^24 and 12 * 2^22 -- but it stays opt-in (SRS_MSM_WIDE=1: second table for every key, wide from
+// 2^WIDE_MIN_N_LOG scalars / SRS_MSM_WIDE_MIN) until a clean full bench with it on: same file, last section.
 static bool wants_wide_table(size_t len) {
     static const int forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();   // 1: on, else off
     return forced == 1 && len > 0;
