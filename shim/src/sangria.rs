@@ -64,3 +64,34 @@ pub fn point_lincomb<C: GpuCurve>(acc: Option<&C>, points: &[C], scalars: &[C::S
                                      &mut out as *mut C as *mut srs_affine) })?;
     Ok(out)
 }
+
+/// Device-resident accumulator of one Sangria-folded circuit: the running (W, E) and the incoming trace buffer live in HBM
+/// (`srs_dev_alloc`), the cross-term vectors too; only commitments and the challenge cross the boundary.
+pub struct ResidentTraces { pub acc_w: *mut srs_fe, pub inc_w: *mut srs_fe, pub acc_e: *mut srs_fe, pub t: Vec<*mut srs_fe> }
+
+/// What `prove_incoming` hands back: the fresh trace's commitment (for `PlonkTrace.u.W_commitments[0]`), the cross-term commitments,
+/// the challenge, and the two library jobs computing the folded W / E commitments (`srs_job_wait`).
+pub struct ProvedIncoming<C: GpuCurve> { pub incoming: C, pub cross_term_commits: Vec<C>, pub r: C::ScalarExt, pub folded: Box<[C; 2]>, pub jobs: [u64; 2] }
+
+/// `VanillaFS::prove` (src/nifs/sangria/mod.rs:253-277) for a trace that has just been synthesised and is not committed yet
+/// (CyclefoldIVC::next's support circuit, src/ivc/cyclefold/incrementally_verifiable_computation/mod.rs:255-300): upload, cross terms,
+/// ONE batched MSM for the trace's commitment and the cross terms', challenge, folds in place.  `ro`: the transcript holding pp_digest
+/// and U1; `u2_tail`: what `generate_challenge` (:162-179) absorbs of U2 after its W commitment.  `acc_commitments` = (U1.W, U1.E).
+#[allow(clippy::too_many_arguments)]
+pub fn prove_incoming<C: GpuCurve>(s: &GpuStructure, ck: &GpuKey<C>, ro: *mut srs_poseidon, challenges: &[C::ScalarExt], tr: &ResidentTraces,
+                                   incoming_host: &[C::ScalarExt], u2_tail: &[C::Base], acc_commitments: (&C, &C), stream: *mut std::ffi::c_void)
+    -> Result<ProvedIncoming<C>, ShimError> {
+    use halo2_proofs::halo2curves::ff::Field;
+    let d = s.num_cross_terms();
+    let mut commits = vec![C::identity(); d];
+    let mut w_commitments = [*acc_commitments.0, C::identity()];
+    let mut folded = Box::new([C::identity(); 2]);
+    let mut r = C::ScalarExt::ZERO;
+    let mut jobs = [0u64; 2];
+    check(unsafe { srs_sangria_prove_incoming(s.raw, ck.raw, ro, challenges.as_ptr() as *const srs_fe, challenges.len(), tr.acc_w, tr.inc_w,
+                                              incoming_host.as_ptr() as *const srs_fe, u2_tail.as_ptr() as *const srs_fe, u2_tail.len(), tr.acc_e,
+                                              stream, &mut r as *mut C::ScalarExt as *mut srs_fe, tr.t.as_ptr(), commits.as_mut_ptr() as *mut srs_affine,
+                                              w_commitments.as_mut_ptr() as *mut srs_affine, acc_commitments.1 as *const C as *const srs_affine,
+                                              folded.as_mut_ptr() as *mut srs_affine, jobs.as_mut_ptr()) })?;
+    Ok(ProvedIncoming { incoming: w_commitments[1], cross_term_commits: commits, r, folded, jobs })
+}
