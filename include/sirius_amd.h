@@ -166,6 +166,11 @@ int srs_commit_upload_columns(srs_ck *ck, const srs_fe *const *columns_host, con
 int srs_ck_create_multi(int curve, const srs_affine *bases, size_t len, int space, int n_devices, srs_ck **out);
 int srs_ck_setup_synthetic_multi(int curve, size_t len, uint64_t seed, int n_devices, srs_ck **out);
 int srs_ck_num_shards(const srs_ck *ck);      /* 1 for an ordinary key */
+/* Diagnostics of the MSM engine behind `ck` (no reference counterpart; tests and tuning): out[0] = sets of launches that ran in
+ * slot mode (persistent per-bucket partial sums, csrc/msm.h), out[1] = those that met hot buckets (parts beyond the slots),
+ * out[2] = commits that were run a second time because such parts had not been expected, out[3] = sets on the other flows.
+ * Multi-device keys report the sum over their shards. */
+int srs_ck_msm_stats(const srs_ck *ck, uint64_t *out4);
 
 /* out = sum of `n` affine points (host); combines per-rank partial commitments. */
 int srs_point_sum(int curve, const srs_affine *points, size_t n, srs_affine *out);

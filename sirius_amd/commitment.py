@@ -111,6 +111,12 @@ class CommitmentKey:
     def num_shards(self):
         return L.lib().srs_ck_num_shards(self._h)
 
+    def msm_stats(self):
+        """Diagnostics of the MSM engine (srs_ck_msm_stats): dict(slot_sets, hot_sets, redo, other_sets)."""
+        out = (C.c_uint64 * 4)()
+        L.check(L.lib().srs_ck_msm_stats(self._h, out))
+        return dict(slot_sets=int(out[0]), hot_sets=int(out[1]), redo=int(out[2]), other_sets=int(out[3]))
+
     @classmethod
     def load_from_file(cls, curve, file_path, k, rank=0, world=1):
         """`CommitmentKey::load_from_file` + the on-curve validation of `load_or_setup_cache`

@@ -788,6 +788,19 @@ int srs_ck_setup_synthetic_multi(int curve, size_t len, uint64_t seed, int n_dev
     });
 }
 int srs_ck_num_shards(const srs_ck *ck) { return ck ? (ck->shards.empty() ? 1 : (int)ck->shards.size()) : 0; }
+int srs_ck_msm_stats(const srs_ck *ck, uint64_t *out) {
+    if (!ck || !out) return fail(SRS_ERR_INVALID, "srs_ck_msm_stats: bad argument");
+    for (int i = 0; i < 4; ++i) out[i] = 0;
+    auto add = [&](const msm::Key &k) {
+        out[0] += k.stat_slot_sets;
+        out[1] += k.stat_hot_sets;
+        out[2] += k.stat_redo;
+        out[3] += k.stat_other_sets;
+    };
+    if (ck->shards.empty()) add(ck->key);
+    for (const auto &sh : ck->shards) add(sh->key);
+    return SRS_OK;
+}
 
 void srs_ck_free(srs_ck *ck) {
     if (!ck) return;
@@ -981,13 +994,32 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
     SRS_HIP_CHECK(hipStreamSynchronize(st));
     SRS_HIP_CHECK(hipGetLastError());
     ht.mark("device done");
+    // slot mode: a set that met hot buckets without its overflow kernels (msm.h: overflow_missed) left an incomplete sum -- the whole
+    // vector is in HBM by now, so the commit is simply run again, device-resident, with the prediction switched
+    bool missed = false;
+    std::vector<uint32_t> used_slots;
+    for (size_t j = 0; j < chunks; ++j) {
+        if (!launched[j]) continue;
+        used_slots.push_back((uint32_t)j);
+        missed = missed || msm::overflow_missed(ck->key, (uint32_t)j);
+    }
+    msm::note_commit(ck->key, used_slots.data(), (uint32_t)used_slots.size());
+    xyzz_t redo;
+    if (missed) {
+        ++ck->key.stat_redo;
+        const fe_t *whole = dst;
+        const uint32_t n_local = (uint32_t)local(0, n);
+        msm::run(ck->key, &whole, &n_local, 1, repr == SRS_REPR_MONT, st, &redo);
+        ht.mark("overflow redo");
+    }
     auto go = [&](auto tag) {
         using C = decltype(tag);
         xyzz_t acc = Ec<C>::identity(), part;
-        for (size_t j = fold ? chunks - 1 : 0; j < chunks; ++j) {          // folded chunks: the last set holds the whole sum
+        for (size_t j = fold ? chunks - 1 : 0; j < chunks && !missed; ++j) {          // folded chunks: the last set holds the whole sum
             msm::finish(ck->key, 1, (uint32_t)j, launched[j], &part);
             acc = Ec<C>::add(acc, part);
         }
+        if (missed) acc = redo;
         affine_t a = Ec<C>::to_affine(acc);
         std::memcpy(out, &a, sizeof(a));
     };

@@ -34,6 +34,12 @@ constexpr uint32_t ACC1_QUAD_MAX = 1u << 16;     // k_accum1 runs one quad per o
 constexpr uint32_t BATCH_ARGS = 16;    // MSMs per set of launches (batch descriptor = kernel argument); larger batches are chunked
 constexpr uint32_t LANDING_SLOTS = 16;  // sets of launches whose results may be in flight at once (chunked commits)
 constexpr uint32_t NORM_G = 16;           // points per inversion in the key-expansion normalise
+// Slot mode (r04): every bucket owns 2^SLOT_LOG persistent partial sums ("slots") in HBM.  Part p of bucket b adds its entries INTO
+// slot (b, p) -- across all the chunks of a streamed commit -- so the accumulation levels, the wave-level pass and the bucket fold that
+// every chunk used to run are replaced by ONE reduction of the slots per commit.  The last slot of a bucket takes the (rare) parts
+// beyond 2^SLOT_LOG - 1, which go through the level kernels as before.  SRS_MSM_SLOT_LOG=<2..8> overrides (tests force overflow).
+constexpr uint32_t SLOT_LOG = 6;
+constexpr uint32_t SLOT_L0_MIN_LOG = 2, SLOT_L0_MAX_LOG = 16;   // part length 2^l0, chosen on the device from the mean bucket load (k_plan_s)
 // Wide windows for large MSMs: 13 signed 20-bit digits per scalar instead of 16 signed 16-bit ones (19 % fewer bucket additions).
 // The 2^19 buckets are NSEG_W "virtual MSMs" of NBUCKET buckets each (bucket = seg * NBUCKET + lo): one MSD pass groups the
 // entries by segment, then every stage of the 16-bit pipeline runs on the 16 segments as a batch.
@@ -74,6 +80,19 @@ struct Key {
     xyzz_t *fold_buckets = nullptr;   // running bucket sums of a chunked commit (enqueue(.., fold)); owned by the key
     bool slot_wide[LANDING_SLOTS] = {};       // landing slot -> which pipeline produced it (finish() combines 3 or 4 partial sums)
     Chunked chunked;          // layout of the running chunked commit (pointers into `arena`)
+    // slot mode (see SLOT_LOG): owned by the key, grow-only
+    xyzz_t *slots = nullptr;          // [batch][NBUCKET][S] persistent partial sums of the running commit
+    size_t slots_pts = 0;
+    uint8_t *used = nullptr;          // [2][BATCH_ARGS][NBUCKET]: slots of a bucket that hold a sum (parity = set index inside the commit)
+    uint32_t *h_ovf = nullptr;        // page-locked [LANDING_SLOTS][BATCH_ARGS]: parts beyond the slots, reported by k_plan_s
+    uint32_t slot_s = 0;              // S of the running commit
+    uint32_t seq = 0;                 // sets enqueued in the running commit
+    bool commit_ovf = false;          // the running commit launches the overflow kernels
+    bool expect_ovf = false;          // prediction for the next commit (= the last one had parts beyond the slots)
+    bool slot_mode[LANDING_SLOTS] = {};     // landing slot -> the set ran in slot mode ...
+    bool slot_ovf_on[LANDING_SLOTS] = {};   // ... with its overflow kernels launched
+    uint32_t slot_batch[LANDING_SLOTS] = {};
+    uint64_t stat_slot_sets = 0, stat_hot_sets = 0, stat_redo = 0, stat_other_sets = 0;   // srs_ck_msm_stats
     Arena arena;              // per-key scratch (grow-only)
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
 };
@@ -114,6 +133,12 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
              hipStream_t stream, uint32_t slot, Fold fold = FOLD_NONE);
 void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host);
 void reserve(Key &k, uint32_t n_max, uint32_t batch);
+// Slot mode predicts per key whether a commit has parts beyond the slots (hot buckets: 0 / 1 / small witnesses) and launches the
+// overflow kernels only then.  After the stream has been synchronised: overflow_missed(slot) says that the set in `slot` HAD such parts
+// while its overflow kernels were not launched -- its result is incomplete and the caller must run the MSM again (the prediction has
+// been switched, so the second run is complete); note_commit() records what the finished commit saw for the next prediction.
+bool overflow_missed(const Key &k, uint32_t slot);
+void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots);
 
 // Chunked commit with a DEFERRED TAIL (one 16-bit-window MSM cut into `sets` <= BATCH_ARGS chunks of <= n_max scalars, all over one
 // bucket set): chunked_begin lays the sets out as the batch slots of one workspace; chunked_front(j) runs only the sort and k_accum0

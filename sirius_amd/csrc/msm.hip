@@ -1024,6 +1024,117 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     }
 }
 
+// ---- slot mode (msm.h: SLOT_LOG) ---------------------------------------------------------------------------------------------
+// k_plan_s: the plan of one set in slot mode.   grid = (batch, nlevels + 2), block = PLAN_THREADS.   Arrays of NBUCKET + 1 per MSM:
+//   [0]            off  : entry offsets of the sorted list (as k_plan)
+//   [1]            tpo  : prefix of the OVERFLOW parts  max(0, parts(b) - (S - 1))   (level 0 of the overflow levels: these parts start
+//                         from the identity and leave a partial sum in `ping`, which k_accum1 / k_ovf_final combine into slot S - 1)
+//   [2 .. nlevels]      : prefix of the overflow parts after each further level (ceil(. / 2^l1_log))
+//   [nlevels + 1]  tp0  : prefix of ALL level-0 parts  parts(b) = ceil(count(b) / 2^l0)  -- the dense thread space of k_accum0s
+// The part length 2^l0 is chosen HERE from the mean bucket load, so that a typical bucket (mean + 6 sigma of a Poisson load) fits its
+// S - 1 regular slots whatever the share of zero digits, and small sets get short parts (more threads): every workgroup derives the
+// same value.  Header (last 4 words): [0] overflow levels needed, [1] 0, [2] l0, [3] overflow parts (also written to *h_ovf, which
+// the host reads after the stream has been synchronised: msm::overflow_missed).
+__device__ __forceinline__ uint32_t slot_l0_log(uint32_t total_entries, uint32_t S) {
+    const uint32_t mean = total_entries / NBUCKET;
+    uint32_t r = 0;
+    while ((r + 1) * (r + 1) <= mean) ++r;                       // isqrt: <= 256 rounds, workgroup-uniform
+    const uint32_t thresh = mean + 6 * r + 1;
+    uint32_t lg = SLOT_L0_MIN_LOG;
+    while (((thresh + (1u << lg) - 1) >> lg) > S - 1 && lg < SLOT_L0_MAX_LOG) ++lg;
+    // not shorter than needed to fill the chip ~2.5 times over (2^19 threads), up to the 16 entries that amortise a part's load / store
+    uint32_t want = 0;
+    while (want < 4 && (total_entries >> (19 + want + 1)) != 0) ++want;
+    return lg > want ? lg : want;
+}
+
+__global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
+    k_plan_s(const uint32_t *__restrict__ count, uint32_t *__restrict__ cursor, uint32_t *__restrict__ plan, size_t plan_stride, int nlevels,
+             uint32_t S, uint32_t l1_log, const uint8_t *__restrict__ used_prev, uint8_t *__restrict__ used_next, int first,
+             uint32_t *__restrict__ h_ovf) {
+    constexpr uint32_t PER = NBUCKET / PLAN_THREADS;             // 32
+    __shared__ uint32_t tile[NBUCKET + NBUCKET / PER];           // index i lives at i + i / PER: conflict-free both ways (see k_plan)
+    __shared__ uint32_t lds[64];
+    const uint32_t t = threadIdx.x, m = blockIdx.x, role = blockIdx.y;
+    const uint32_t *cnt = count + (size_t)m * NBUCKET;
+    uint32_t *pl = plan + (size_t)m * plan_stride;
+    for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) tile[i + i / PER] = cnt[i];
+    __syncthreads();
+    uint32_t vals[PER];
+    const uint32_t base = t * PER;
+    uint32_t local = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) {
+        vals[j] = tile[base + j + t];
+        local += vals[j];
+    }
+    uint32_t total_entries;
+    uint32_t run = block_exclusive_scan(local, lds, &total_entries);
+    const uint32_t l0_log = slot_l0_log(total_entries, S);
+    uint32_t total = total_entries;
+    if (role != 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) vals[j] = (vals[j] + (1u << l0_log) - 1) >> l0_log;        // level-0 parts of the bucket
+        if (role == (uint32_t)nlevels + 1) {                     // the dense thread space; slots in use after this set
+            const uint8_t *up = used_prev + (size_t)m * NBUCKET;
+            uint8_t *un = used_next + (size_t)m * NBUCKET;
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) {
+                const uint32_t now = vals[j] < S - 1 ? vals[j] : S - 1, was = first ? 0u : (uint32_t)up[base + j];
+                un[base + j] = (uint8_t)(now > was ? now : was);
+            }
+        } else {                                                 // overflow level role - 1
+            uint32_t mx = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) {
+                vals[j] = vals[j] > S - 1 ? vals[j] - (S - 1) : 0u;
+                mx = vals[j] > mx ? vals[j] : mx;
+            }
+            uint32_t p = block_max(mx, lds);
+            int needed = 1;
+            while (p > FINAL_FANIN && needed < nlevels) {
+                p = (p + (1u << l1_log) - 1) >> l1_log;
+                ++needed;
+            }
+            if (role == 1 && t == 0) {
+                pl[plan_stride - 4] = (uint32_t)needed;
+                pl[plan_stride - 3] = 0;
+                pl[plan_stride - 2] = l0_log;
+            }
+            if ((int)role - 1 >= needed) return;                 // a level nobody runs (workgroup-uniform)
+            for (uint32_t lv = 1; lv < role; ++lv) {
+#pragma unroll
+                for (uint32_t j = 0; j < PER; ++j) vals[j] = (vals[j] + (1u << l1_log) - 1) >> l1_log;
+            }
+        }
+        local = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) local += vals[j];
+        run = block_exclusive_scan(local, lds, &total);
+    }
+    __syncthreads();                                             // the load of the counts has finished reading `tile`
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) {
+        tile[base + j + t] = run;
+        run += vals[j];
+    }
+    __syncthreads();
+    uint32_t *o = pl + (size_t)role * (NBUCKET + 1);
+    uint32_t *cur = cursor + (size_t)m * NBUCKET;
+    for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) {
+        const uint32_t v = tile[i + i / PER];
+        o[i] = v;
+        if (role == 0) cur[i] = v;
+    }
+    if (t == PLAN_THREADS - 1) {
+        o[NBUCKET] = total;
+        if (role == 1) {
+            pl[plan_stride - 1] = total;
+            h_ovf[m] = total;
+        }
+    }
+}
+
 __global__ void k_link(const uint32_t *__restrict__ plan, size_t plan_stride, int nlevels, Link *__restrict__ link) {
     const uint32_t t = threadIdx.x;
     for (int l = 0; l < nlevels; ++l) {
@@ -1053,10 +1164,10 @@ __global__ void k_link(const uint32_t *__restrict__ plan, size_t plan_stride, in
 // One wavefront per bucket writes the (contiguous) range instead; the map is 2 bytes per thread.   grid = (NBUCKET / 4, batch)
 __global__ void SRS_KERNEL_BOUNDS(256, 1)
     k_expand(const uint32_t *__restrict__ plan, size_t plan_stride, uint16_t *__restrict__ tb, size_t tb_stride,
-             const Link *__restrict__ link) {
+             const Link *__restrict__ link, uint32_t arr /* plan array holding the thread prefix: 1, or nlevels + 1 in slot mode */) {
     const uint32_t m = blockIdx.y, lane = threadIdx.x & 63u;
     const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t *tp = plan + (size_t)m * plan_stride + (NBUCKET + 1);
+    const uint32_t *tp = plan + (size_t)m * plan_stride + (size_t)arr * (NBUCKET + 1);
     uint16_t *out = tb + (link ? (size_t)link->base[0][m] : (size_t)m * tb_stride);
     const uint32_t s = tp[b], e = tp[b + 1];
     for (uint32_t t = s + lane; t < e; t += 64) out[t] = (uint16_t)b;
@@ -1224,6 +1335,106 @@ __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
         if (lane < d) acc = E29::add(acc, other);
     }
     if (lane == 0) dst[b] = E29::pack(acc);
+}
+
+// ---- slot mode: bucket accumulation INTO the persistent slots ------------------------------------------------------------------
+// thread t = (bucket b, part p) of the dense thread space tp0 (plan array `arr`): <= 2^l0 gathered mixed additions, like k_accum0, but
+//   p <  S - 1 : the running sum of slot (b, p) is the start value (identity when the slot holds nothing yet) and the result goes back
+//                -- nothing is left for later levels to combine, whatever the number of sets a commit is cut into;
+//   p >= S - 1 : a hot bucket (more entries than S - 1 parts hold): a fresh partial sum into `ovf`, combined by k_accum1 / k_ovf_final.
+// grid = (ceil(cap / ACC_THREADS), batch)
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
+    k_accum0s(const uint32_t *__restrict__ sorted, size_t sorted_stride, const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t arr,
+              const uint16_t *__restrict__ tb, size_t tb_stride, const affine_t *__restrict__ table, xyzz_t *__restrict__ slots, uint32_t S,
+              const uint8_t *__restrict__ used_prev, int first, xyzz_t *__restrict__ ovf, size_t ovf_stride) {
+    const uint32_t m = blockIdx.y;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t *off = plan + (size_t)m * plan_stride;
+    const uint32_t *tp = off + (size_t)arr * (NBUCKET + 1);
+    if (t >= tp[NBUCKET]) return;
+    const uint32_t *tpo = off + (NBUCKET + 1);
+    const uint32_t l0 = 1u << off[plan_stride - 2];
+    const uint32_t b = tb[(size_t)m * tb_stride + t];
+    const uint32_t part = t - tp[b];
+    uint32_t s = off[b] + part * l0;
+    uint32_t e = off[b + 1];
+    if (e > s + l0) e = s + l0;
+    const uint32_t *src = sorted + (size_t)m * sorted_stride;
+    using E29 = Ec29<C>;
+    const bool regular = part < S - 1;
+    xyzz_t *slot = regular ? slots + ((size_t)m * NBUCKET + b) * S + part : ovf + (size_t)m * ovf_stride + tpo[b] + (part - (S - 1));
+    xyzz29_t acc = E29::identity();
+    uint32_t v = src[s];                                   // a part is never empty: s < e
+    affine_t p = table[v & 0x7FFFFFFFu];
+    if (regular && !first && part < (uint32_t)used_prev[(size_t)m * NBUCKET + b]) acc = E29::unpack(*slot);
+    for (uint32_t j = s; j < e; ++j) {
+        uint32_t vn = 0;
+        affine_t pn = p;
+        if (j + 1 < e) {                  // prefetch the next gathered point behind the add
+            vn = src[j + 1];
+            pn = table[vn & 0x7FFFFFFFu];
+        }
+        acc = E29::madd_signed(acc, E29::load_raw(p), (v >> 31) != 0);
+        v = vn;
+        p = pn;
+    }
+    *slot = E29::pack(acc);
+}
+
+// the wave-level pass of the overflow parts: one wavefront per bucket sums what the overflow levels left of it and adds the sum into the
+// bucket's LAST slot (first set of a commit: every bucket's last slot is initialised here).   grid = (NBUCKET / waves_per_block, batch)
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
+    k_ovf_final(const xyzz_t *__restrict__ ping, size_t ping_stride, const xyzz_t *__restrict__ pong, size_t pong_stride,
+                const uint32_t *__restrict__ plan, size_t plan_stride, xyzz_t *__restrict__ slots, uint32_t S, int first) {
+    const uint32_t m = blockIdx.y;
+    const uint32_t level = plan[(size_t)m * plan_stride + plan_stride - 4];   // overflow levels actually run
+    const xyzz_t *in = (level & 1u) ? ping + (size_t)m * ping_stride : pong + (size_t)m * pong_stride;     // level 0 -> ping, level 1 -> pong, ...
+    const uint32_t *tp = plan + (size_t)m * plan_stride + (size_t)level * (NBUCKET + 1);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t s = tp[b], e = tp[b + 1];
+    xyzz_t *dst = slots + ((size_t)m * NBUCKET + b) * S + (S - 1);
+    using E29 = Ec29<C>;
+    if (e == s) {                            // the usual bucket: nothing beyond its regular slots
+        if (first && lane == 0) *dst = E29::pack(E29::identity());
+        return;
+    }
+    xyzz29_t acc = E29::identity();
+    for (uint32_t j = s + lane; j < e; j += 64) acc = E29::add(acc, E29::unpack(in[j]));
+    for (unsigned d = 32; d >= 1; d >>= 1) {
+        xyzz29_t other = shfl_down_point29(acc, d, 64);
+        if (lane < d) acc = E29::add(acc, other);
+    }
+    if (lane == 0) {
+        if (!first) acc = E29::add(acc, E29::unpack(*dst));
+        *dst = E29::pack(acc);
+    }
+}
+
+// the reduction of the slots at the end of a commit, 8 inputs per output: out[B * out_pb + g] = sum_{j < 8} in[B * in_pb + 8 g + j] over
+// the inputs that hold a sum -- index < used[B] (first level; nullptr: all of them) or == extra (the overflow slot, when its kernels ran).
+// B = m * NBUCKET + b.  QUAD: one quad per output (the last level: 2^15 outputs per MSM).   grid = ceil(n_out [* 4] / 256)
+template <class C, bool QUAD>
+__global__ void SRS_KERNEL_BOUNDS(256, 1)
+    k_slot_reduce(const xyzz_t *__restrict__ in, uint32_t in_pb, const uint8_t *__restrict__ used, size_t used_stride, int extra,
+                  xyzz_t *__restrict__ out, uint32_t out_pb, uint32_t n_out /* per MSM */) {
+    using E29 = Ec29<C>;
+    const uint32_t m = blockIdx.y;
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? (lin >> 2) : lin, q = lin & 3u;
+    if (t >= n_out) return;
+    const uint32_t b = t / out_pb, g = t % out_pb;
+    const uint32_t lim = used ? (uint32_t)used[(size_t)m * used_stride + b] : in_pb;
+    const xyzz_t *src = in + ((size_t)m * NBUCKET + b) * in_pb;
+    xyzz29_t acc = E29::identity();
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t idx = g * 8 + j;
+        if (idx >= in_pb || !(idx < lim || (int)idx == extra)) continue;         // uniform inside a quad
+        const xyzz29_t x = E29::unpack(src[idx]);
+        if (QUAD) acc = E29::add_quad(acc, x, q); else acc = E29::add(acc, x);
+    }
+    if (!QUAD || q == 0) out[((size_t)m * NBUCKET + b) * out_pb + g] = E29::pack(acc);
 }
 
 // chunked commits: the finished buckets of this set (where k_rowcol would read them) go into the key's running buckets;
@@ -1650,7 +1861,7 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
     const Link *no_link = nullptr;
-    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap, no_link);
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap, no_link, 1u);
     SRS_LAUNCH_TIMED("msm_accum0", units, (k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                      (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride, (const uint16_t *)tb, (size_t)parts0_cap,
                      (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log, no_link);
@@ -1690,6 +1901,224 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     SRS_HIP_CHECK(hipMemcpyAsync(two, d_out, 3 * (size_t)batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     k.slot_wide[slot] = false;
     return true;
+}
+
+static bool use_wide(const Key &k, uint32_t n_max, uint32_t batch);
+// ---- slot mode: host side -------------------------------------------------------------------------------------------------------
+static uint32_t slot_log() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("SRS_MSM_SLOT_LOG");
+        const int lg = e ? std::atoi(e) : 0;
+        return (lg >= 2 && lg <= 8) ? (uint32_t)lg : SLOT_LOG;
+    }();
+    return v;
+}
+// SRS_MSM_SLOTS=0: the r03 flow (fresh partial sums per set, accumulation levels per set); default: slot mode for every 16-bit-window set
+static bool use_slots(const Key &k, uint32_t n_max, uint32_t batch) {
+    static const bool on = [] { const char *e = std::getenv("SRS_MSM_SLOTS"); return !(e && e[0] == '0'); }();
+    static const uint64_t min_slots = [] { const char *e = std::getenv("SRS_MSM_SLOT_MIN_LOG"); return e ? (1ull << std::atoi(e)) : 0ull; }();
+    return on && !use_wide(k, n_max, batch) && (uint64_t)n_max * NWIN * batch >= min_slots;
+}
+struct SlotShape {
+    uint32_t S, nred;          // slots per bucket; reduction levels at the end of a commit (8 inputs per output)
+    uint64_t M, cap, cap1;     // digit slots; level-0 threads = overflow parts (worst case); parts after the first overflow level
+    int levels;                // overflow levels incl. level 0
+    size_t plan_stride;
+};
+static SlotShape slot_shape(uint32_t n_max) {
+    SlotShape h;
+    h.S = 1u << slot_log();
+    h.nred = (slot_log() + 2) / 3;
+    h.M = (uint64_t)n_max * NWIN;
+    // parts = sum_b ceil(c_b / L0) <= E / L0 + NBUCKET, and k_plan_s picks L0 >= (mean load) / (S - 1): never more than NBUCKET * S parts;
+    // L0 >= 2^SLOT_L0_MIN_LOG bounds them for small sets
+    h.cap = std::min<uint64_t>((uint64_t)NBUCKET * h.S, (h.M >> SLOT_L0_MIN_LOG) + NBUCKET);
+    h.cap1 = h.cap / ACC_L1 + NBUCKET + 1;
+    uint64_t parts = h.cap;
+    h.levels = 1;
+    while (parts > FINAL_FANIN && h.levels < MAX_LEVELS) {
+        parts = (parts + ACC_L1 - 1) / ACC_L1;
+        ++h.levels;
+    }
+    h.plan_stride = (size_t)(h.levels + 2) * (NBUCKET + 1) + 4;
+    return h;
+}
+static size_t workspace_bytes_slots(uint32_t n_max, uint32_t batch) {
+    const SlotShape h = slot_shape(n_max);
+    size_t per = 0;
+    per += Arena::pad(h.M * sizeof(uint16_t)) + Arena::pad(h.M * sizeof(uint32_t));          // digits, sorted
+    per += 2 * Arena::pad(NBUCKET * sizeof(uint32_t)) + Arena::pad(h.plan_stride * sizeof(uint32_t));
+    per += Arena::pad(h.cap * sizeof(xyzz_t)) + Arena::pad(h.cap * sizeof(uint16_t)) + Arena::pad(h.cap1 * sizeof(xyzz_t));   // overflow parts, map, pong
+    per += Arena::pad((size_t)NBUCKET * (h.S / 8 + 1) * sizeof(xyzz_t)) + Arena::pad((size_t)NBUCKET * (h.S / 64 + 1) * sizeof(xyzz_t));   // reduction ping / pong
+    per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
+    if (use_two_pass(h.M, batch)) {
+        per += Arena::pad(h.M * sizeof(uint16_t)) + Arena::pad(h.M * sizeof(uint32_t));
+        per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));
+    }
+    return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 8192;
+}
+
+// one set of <= BATCH_ARGS MSMs in slot mode.  fold: NONE = a whole commit (first and last set), FIRST / MIDDLE / LAST = the sets of a
+// chunked commit (batch == 1): only the last one reduces the slots and lands the 3 partial sums.
+template <class C>
+static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch,
+                            int is_mont, hipStream_t stream, uint32_t slot, Fold fold) {
+    uint32_t n_max = 0;
+    for (uint32_t m = 0; m < batch; ++m) n_max = std::max(n_max, n_host[m]);
+    if (n_max == 0) return false;
+    const bool first = fold == FOLD_NONE || fold == FOLD_FIRST, last = fold == FOLD_NONE || fold == FOLD_LAST;
+    const SlotShape h = slot_shape(n_max);
+    const uint32_t S = h.S;
+    const uint64_t M = h.M;
+    if (first) {
+        k.slot_s = S;
+        k.seq = 0;
+        k.commit_ovf = k.expect_ovf;
+        const size_t need = (size_t)batch * NBUCKET * S;
+        if (k.slots_pts < need) {
+            if (k.slots) SRS_HIP_CHECK(hipFree(k.slots));
+            k.slots = nullptr;
+            k.slots_pts = 0;
+            SRS_HIP_CHECK(hipMalloc((void **)&k.slots, need * sizeof(xyzz_t)));
+            k.slots_pts = need;
+        }
+        if (!k.used) SRS_HIP_CHECK(hipMalloc((void **)&k.used, 2 * (size_t)BATCH_ARGS * NBUCKET));
+        if (!k.h_ovf) {
+            SRS_HIP_CHECK(hipHostMalloc((void **)&k.h_ovf, (size_t)LANDING_SLOTS * BATCH_ARGS * sizeof(uint32_t)));
+            for (size_t i = 0; i < (size_t)LANDING_SLOTS * BATCH_ARGS; ++i) k.h_ovf[i] = 0;
+        }
+    } else if (k.slot_s != S || batch != 1) {
+        set_error("internal: msm slot mode: a commit's sets must share the slot layout");
+        throw DeviceError{5};
+    }
+    const uint8_t *used_prev = k.used + (size_t)(k.seq & 1u) * BATCH_ARGS * NBUCKET;
+    uint8_t *used_next = k.used + (size_t)((k.seq + 1) & 1u) * BATCH_ARGS * NBUCKET;
+    ++k.seq;
+
+    Arena &A = k.arena;
+    A.reserve(workspace_bytes_slots(n_max, batch));
+    A.reset();
+    xyzz_t *d_out = A.take<xyzz_t>(3 * (size_t)batch);
+    uint16_t *dig = A.take<uint16_t>(M * batch);
+    uint32_t *sorted = A.take<uint32_t>(M * batch);
+    uint32_t *count = A.take<uint32_t>((size_t)NBUCKET * batch);
+    uint32_t *cursor = A.take<uint32_t>((size_t)NBUCKET * batch);
+    uint32_t *plan = A.take<uint32_t>(h.plan_stride * batch);
+    xyzz_t *ping = A.take<xyzz_t>(h.cap * batch);
+    uint16_t *tb = A.take<uint16_t>(h.cap * batch);
+    xyzz_t *pong = A.take<xyzz_t>(h.cap1 * batch);
+    xyzz_t *red_a = A.take<xyzz_t>((size_t)NBUCKET * (S / 8 + 1) * batch);
+    xyzz_t *red_b = A.take<xyzz_t>((size_t)NBUCKET * (S / 64 + 1) * batch);
+    xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
+    const bool two_pass = use_two_pass(M, batch);
+    uint16_t *gkey = two_pass ? A.take<uint16_t>(M * batch) : nullptr;
+    uint32_t *gpay = two_pass ? A.take<uint32_t>(M * batch) : nullptr;
+    uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
+
+    BatchDesc bd;
+    for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
+        bd.ptr[m] = m < batch ? scalars_dev[m] : nullptr;
+        bd.n[m] = m < batch ? n_host[m] : 0;
+        bd.base[m] = (m < batch && base_host) ? base_host[m] : 0;
+    }
+    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont,
+               k.compact_scalars ? 0u : k.rank, k.compact_scalars ? 1u : k.world, count, (uint32_t)(NBUCKET * batch));
+    uint32_t tile = (uint32_t)(((uint64_t)n_max * NWIN * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
+    tile = (tile + 1023u) & ~1023u;
+    if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
+    const uint32_t tiles = ceil_div(n_max, tile);
+    SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
+               bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
+    uint32_t *h_ovf = k.h_ovf + (size_t)slot * BATCH_ARGS;
+    SRS_LAUNCH(k_plan_s, (batch, h.levels + 2), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, h.plan_stride, h.levels, S,
+               (uint32_t)ACC_L1_LOG, used_prev, used_next, first ? 1 : 0, h_ovf);
+    if (two_pass) {
+        const uint32_t T1 = tiles * NWIN;
+        SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, h.plan_stride);
+        SRS_LAUNCH(k_group, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M, bd,
+                   (const uint32_t *)tile_hist, gkey, gpay, (size_t)M, (uint32_t)k.len, tile);
+        SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
+                   (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, h.plan_stride, cursor, sorted, (size_t)M,
+                   (uint32_t)SORT_TILE2);
+    } else {
+        SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
+                   bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
+    }
+    uint64_t units = 0;
+    for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
+    const Link *no_link = nullptr;
+    const uint32_t arr = (uint32_t)h.levels + 1;
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, h.plan_stride, tb, (size_t)h.cap, no_link, arr);
+    SRS_LAUNCH_TIMED("msm_accum0", units, (k_accum0s<C>), (ceil_div(h.cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+                     (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, h.plan_stride, arr, (const uint16_t *)tb, (size_t)h.cap,
+                     (const affine_t *)k.table, k.slots, S, used_prev, first ? 1 : 0, ping, (size_t)h.cap);
+    if (k.commit_ovf) {                      // hot buckets expected: the parts beyond the slots go through the level kernels into slot S - 1
+        xyzz_t *cur = ping, *nxt = pong;
+        size_t cur_stride = h.cap, nxt_stride = h.cap1;
+        uint64_t cap = h.cap;
+        for (int level = 1; level < h.levels; ++level) {
+            cap = cap / ACC_L1 + NBUCKET + 1;
+            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+                       (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, h.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
+                       acc1_quad_max(), 0u);
+            std::swap(cur, nxt);
+            std::swap(cur_stride, nxt_stride);
+        }
+        SRS_LAUNCH((k_ovf_final<C>), (NBUCKET / (FINAL_THREADS / 64), batch), (FINAL_THREADS), 0, stream, (const xyzz_t *)ping, (size_t)h.cap,
+                   (const xyzz_t *)pong, (size_t)h.cap1, (const uint32_t *)plan, h.plan_stride, k.slots, S, first ? 1 : 0);
+    }
+    k.slot_mode[slot] = true;
+    ++k.stat_slot_sets;
+    k.slot_ovf_on[slot] = k.commit_ovf;
+    k.slot_batch[slot] = batch;
+    k.slot_wide[slot] = false;
+    if (!last) return true;
+    // the commit's one reduction: slots -> buckets (8 inputs per output and level), then the usual row / column sums
+    const xyzz_t *in = k.slots;
+    uint32_t in_pb = S;
+    xyzz_t *outs[2] = {red_a, red_b};
+    for (uint32_t l = 0; l < h.nred; ++l) {
+        const uint32_t out_pb = (in_pb + 7) / 8, n_out = NBUCKET * out_pb;
+        xyzz_t *out = outs[l & 1u];
+        const uint8_t *used = l == 0 ? used_next : nullptr;
+        const int extra = (l == 0 && k.commit_ovf) ? (int)S - 1 : -1;
+        if (l + 1 == h.nred) {
+            SRS_LAUNCH((k_slot_reduce<C, true>), (ceil_div((uint64_t)n_out * 4, 256), batch), (256), 0, stream, in, in_pb, used, (size_t)NBUCKET, extra,
+                       out, out_pb, n_out);
+        } else {
+            SRS_LAUNCH((k_slot_reduce<C, false>), (ceil_div(n_out, 256), batch), (256), 0, stream, in, in_pb, used, (size_t)NBUCKET, extra, out,
+                       out_pb, n_out);
+        }
+        in = out;
+        in_pb = out_pb;
+    }
+    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, batch), (128), 0, stream, in, (const xyzz_t *)ping, (size_t)h.cap,
+               (const xyzz_t *)pong, (size_t)h.cap1, (const uint32_t *)plan, h.plan_stride, rc, no_link, 1);
+    SRS_LAUNCH((k_reduce_final<C>), (3, batch), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_out);
+    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
+    xyzz_t *two = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
+    SRS_HIP_CHECK(hipMemcpyAsync(two, d_out, 3 * (size_t)batch * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
+    return true;
+}
+
+bool overflow_missed(const Key &k, uint32_t slot) {
+    if (slot >= LANDING_SLOTS || !k.slot_mode[slot] || k.slot_ovf_on[slot] || !k.h_ovf) return false;
+    for (uint32_t m = 0; m < k.slot_batch[slot]; ++m)
+        if (k.h_ovf[(size_t)slot * BATCH_ARGS + m]) return true;
+    return false;
+}
+void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots) {
+    bool any = false, slot_sets = false;
+    for (uint32_t i = 0; i < n_slots; ++i) {
+        const uint32_t sl = slots_used[i];
+        if (sl >= LANDING_SLOTS || !k.slot_mode[sl] || !k.h_ovf) continue;
+        slot_sets = true;
+        bool hot = false;
+        for (uint32_t m = 0; m < k.slot_batch[sl]; ++m) hot = hot || k.h_ovf[(size_t)sl * BATCH_ARGS + m] != 0;
+        if (hot) ++k.stat_hot_sets;
+        any = any || hot;
+    }
+    if (slot_sets) k.expect_ovf = any;
 }
 
 // ---- the wide-window pipeline: ONE MSM of n >= 2^WIDE_MIN_N_LOG scalars over table_w -------------------------------------
@@ -1799,7 +2228,7 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     }
     SRS_LAUNCH(k_link, (1), (64), 0, stream, (const uint32_t *)plan, w.plan_stride, w.levels, link);
     const Link *lk = link;
-    SRS_LAUNCH(k_expand, (NBUCKET / 4, NSEG_W), (256), 0, stream, (const uint32_t *)plan, w.plan_stride, tb, (size_t)0, lk);
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, NSEG_W), (256), 0, stream, (const uint32_t *)plan, w.plan_stride, tb, (size_t)0, lk, 1u);
     SRS_LAUNCH_TIMED("msm_accum0", n, (k_accum0<C>), (ceil_div(w.parts0_cap, ACC_THREADS)), (ACC_THREADS), 0, stream, (const uint32_t *)sorted,
                      (size_t)0, (const uint32_t *)plan, w.plan_stride, (const uint16_t *)tb, (size_t)0, (const affine_t *)k.table_w, ping, (size_t)0,
                      1u << w.l0_log, lk);
@@ -1878,7 +2307,7 @@ static void chunked_front_t(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_
     SRS_LAUNCH(k_scatter, (tiles, NWIN, 1), (sort_threads), 0, s_sort, (const uint16_t *)dig, (size_t)M, bd, cursor, sorted, (size_t)M,
                (uint32_t)k.len, tile);
     const Link *no_link = nullptr;
-    SRS_LAUNCH(k_expand, (NBUCKET / 4, 1), (256), 0, s_sort, (const uint32_t *)plan, S.plan_stride, tb, (size_t)S.parts0_cap, no_link);
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, 1), (256), 0, s_sort, (const uint32_t *)plan, S.plan_stride, tb, (size_t)S.parts0_cap, no_link, 1u);
     if (s_sort != s_acc) {
         SRS_HIP_CHECK(hipEventRecord(sorted_ev, s_sort));
         SRS_HIP_CHECK(hipStreamWaitEvent(s_acc, sorted_ev, 0));
@@ -2038,9 +2467,22 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
     }
     if (batch == 1 && use_wide(k, n_host[0], 1)) {
         const uint32_t base = base_host ? base_host[0] : 0;
+        k.slot_mode[slot] = false;
+        ++k.stat_other_sets;
         return k.curve == 0 ? enqueue_wide_t<Bn256>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot)
                             : enqueue_wide_t<Grumpkin>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot);
     }
+    uint32_t n_max = 0;
+    for (uint32_t m = 0; m < batch; ++m) n_max = std::max(n_max, n_host[m]);
+    // the sets of one commit take the same flow: decided by its first set
+    const bool first = fold == FOLD_NONE || fold == FOLD_FIRST;
+    const bool slots = first ? use_slots(k, n_max, batch) : k.slot_s != 0;
+    if (slots)
+        return k.curve == 0 ? enqueue_slots_t<Bn256>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold)
+                            : enqueue_slots_t<Grumpkin>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold);
+    if (first) k.slot_s = 0;
+    k.slot_mode[slot] = false;
+    ++k.stat_other_sets;
     return k.curve == 0 ? enqueue_t<Bn256>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold)
                         : enqueue_t<Grumpkin>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold);
 }
@@ -2048,7 +2490,9 @@ void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result
     if (k.curve == 0) finish_t<Bn256>(k, batch, slot, launched, result_host); else finish_t<Grumpkin>(k, batch, slot, launched, result_host);
 }
 void reserve(Key &k, uint32_t n_max, uint32_t batch) {
-    k.arena.reserve(use_wide(k, n_max, batch) ? std::max(workspace_bytes_wide(n_max), workspace_bytes(n_max, batch)) : workspace_bytes(n_max, batch));
+    size_t b = use_wide(k, n_max, batch) ? std::max(workspace_bytes_wide(n_max), workspace_bytes(n_max, batch)) : workspace_bytes(n_max, batch);
+    if (use_slots(k, n_max, batch)) b = std::max(b, workspace_bytes_slots(n_max, batch));
+    k.arena.reserve(b);
 }
 
 void release(Key &k) {
@@ -2058,6 +2502,13 @@ void release(Key &k) {
     k.fold_buckets = nullptr;
     if (k.h_result) (void)hipHostFree(k.h_result);
     k.h_result = nullptr;
+    if (k.slots) (void)hipFree(k.slots);
+    k.slots = nullptr;
+    k.slots_pts = 0;
+    if (k.used) (void)hipFree(k.used);
+    k.used = nullptr;
+    if (k.h_ovf) (void)hipHostFree(k.h_ovf);
+    k.h_ovf = nullptr;
     k.arena.release();
 }
 
@@ -2066,10 +2517,19 @@ void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_
     for (uint32_t at = 0; at < batch;) {                           // the batch descriptor is a kernel argument of BATCH_ARGS slots
         uint32_t b = std::min<uint32_t>(BATCH_ARGS, batch - at);
         if (use_wide(k, n_host[at], 1)) b = 1;                     // large vectors go through the wide-window pipeline one by one
-        const bool launched = enqueue(k, scalars_dev + at, n_host + at, nullptr, b, is_mont, stream, 0);
+        bool launched = enqueue(k, scalars_dev + at, n_host + at, nullptr, b, is_mont, stream, 0);
         if (launched) {
             SRS_HIP_CHECK(hipStreamSynchronize(stream));
             SRS_HIP_CHECK(hipGetLastError());
+            const uint32_t sl = 0;
+            if (overflow_missed(k, sl)) {                          // hot buckets the prediction did not expect: once more, with the overflow kernels
+                k.expect_ovf = true;
+                ++k.stat_redo;
+                launched = enqueue(k, scalars_dev + at, n_host + at, nullptr, b, is_mont, stream, 0);
+                SRS_HIP_CHECK(hipStreamSynchronize(stream));
+                SRS_HIP_CHECK(hipGetLastError());
+            }
+            note_commit(k, &sl, 1);
         }
         finish(k, b, 0, launched, result_host + at);
         prof::collect();
