@@ -12,6 +12,7 @@
 #include <functional>
 #include <mutex>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -28,7 +29,6 @@ namespace srs {
 static thread_local std::string g_err;
 
 // SRS_HOST_TRACE=1: host-clock checkpoints of the composite entries (where the time BETWEEN kernels goes), printed to stderr per call
-#include <chrono>
 struct HostTrace {
     const char *name;
     bool on;
@@ -1066,7 +1066,7 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
         }
         for (double f : frac) {
             const size_t c = up((size_t)(f * (double)n));
-            if (c > cut.back() && c < n) cut.push_back(c);
+            if (c > cut.back() && c < n && cut.size() < msm::LANDING_SLOTS) cut.push_back(c);    // one landing slot per chunk
         }
     }
     cut.push_back(n);

@@ -1035,7 +1035,7 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
 // S - 1 regular slots whatever the share of zero digits, and small sets get short parts (more threads): every workgroup derives the
 // same value.  Header (last 4 words): [0] overflow levels needed, [1] 0, [2] l0, [3] overflow parts (also written to *h_ovf, which
 // the host reads after the stream has been synchronised: msm::overflow_missed).
-__device__ __forceinline__ uint32_t slot_l0_log(uint32_t total_entries, uint32_t S) {
+__device__ __forceinline__ uint32_t slot_l0_log(uint32_t total_entries, uint32_t S, uint32_t want_cap) {
     const uint32_t mean = total_entries / NBUCKET;
     uint32_t r = 0;
     while ((r + 1) * (r + 1) <= mean) ++r;                       // isqrt: <= 256 rounds, workgroup-uniform
@@ -1044,14 +1044,14 @@ __device__ __forceinline__ uint32_t slot_l0_log(uint32_t total_entries, uint32_t
     while (((thresh + (1u << lg) - 1) >> lg) > S - 1 && lg < SLOT_L0_MAX_LOG) ++lg;
     // not shorter than needed to fill the chip ~2.5 times over (2^19 threads), up to the 16 entries that amortise a part's load / store
     uint32_t want = 0;
-    while (want < 4 && (total_entries >> (19 + want + 1)) != 0) ++want;
+    while (want < want_cap && (total_entries >> (19 + want + 1)) != 0) ++want;
     return lg > want ? lg : want;
 }
 
 __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     k_plan_s(const uint32_t *__restrict__ count, uint32_t *__restrict__ cursor, uint32_t *__restrict__ plan, size_t plan_stride, int nlevels,
              uint32_t S, uint32_t l1_log, const uint8_t *__restrict__ used_prev, uint8_t *__restrict__ used_next, int first,
-             uint32_t *__restrict__ h_ovf) {
+             uint32_t *__restrict__ h_ovf, uint32_t want_cap) {
     constexpr uint32_t PER = NBUCKET / PLAN_THREADS;             // 32
     __shared__ uint32_t tile[NBUCKET + NBUCKET / PER];           // index i lives at i + i / PER: conflict-free both ways (see k_plan)
     __shared__ uint32_t lds[64];
@@ -1070,7 +1070,7 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     }
     uint32_t total_entries;
     uint32_t run = block_exclusive_scan(local, lds, &total_entries);
-    const uint32_t l0_log = slot_l0_log(total_entries, S);
+    const uint32_t l0_log = slot_l0_log(total_entries, S, want_cap);
     uint32_t total = total_entries;
     if (role != 0) {
 #pragma unroll
@@ -1413,24 +1413,26 @@ __global__ void SRS_KERNEL_BOUNDS(FINAL_THREADS, 1)
     }
 }
 
-// the reduction of the slots at the end of a commit, 8 inputs per output: out[B * out_pb + g] = sum_{j < 8} in[B * in_pb + 8 g + j] over
+// the reduction of the slots at the end of a commit, <= 8 inputs per output: out[B * out_pb + g] = sum_j in[B * in_pb + g + j * out_pb] over
 // the inputs that hold a sum -- index < used[B] (first level; nullptr: all of them) or == extra (the overflow slot, when its kernels ran).
-// B = m * NBUCKET + b.  QUAD: one quad per output (the last level: 2^15 outputs per MSM).   grid = ceil(n_out [* 4] / 256)
+// B = m * NBUCKET + b.  The inputs of an output are STRIDED (a bucket with u slots in use gives every one of its outputs u / out_pb of
+// them, whatever u) and the thread space is g-major (a wavefront = 64 buckets at the same g: the wavefronts of a level carry equal
+// chains, and a small MSM with one or two slots per bucket in use runs a few full wavefronts instead of one lane in eight of all of them).
+// QUAD: one quad per output (the last level: 2^15 outputs per MSM).   grid = (ceil(n_out [* 4] / 256), batch)
 template <class C, bool QUAD>
 __global__ void SRS_KERNEL_BOUNDS(256, 1)
     k_slot_reduce(const xyzz_t *__restrict__ in, uint32_t in_pb, const uint8_t *__restrict__ used, size_t used_stride, int extra,
-                  xyzz_t *__restrict__ out, uint32_t out_pb, uint32_t n_out /* per MSM */) {
+                  xyzz_t *__restrict__ out, uint32_t out_pb) {
     using E29 = Ec29<C>;
     const uint32_t m = blockIdx.y;
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x, t = QUAD ? (lin >> 2) : lin, q = lin & 3u;
-    if (t >= n_out) return;
-    const uint32_t b = t / out_pb, g = t % out_pb;
+    if (t >= NBUCKET * out_pb) return;
+    const uint32_t g = t / NBUCKET, b = t % NBUCKET;
     const uint32_t lim = used ? (uint32_t)used[(size_t)m * used_stride + b] : in_pb;
     const xyzz_t *src = in + ((size_t)m * NBUCKET + b) * in_pb;
     xyzz29_t acc = E29::identity();
-    for (uint32_t j = 0; j < 8; ++j) {
-        const uint32_t idx = g * 8 + j;
-        if (idx >= in_pb || !(idx < lim || (int)idx == extra)) continue;         // uniform inside a quad
+    for (uint32_t idx = g; idx < in_pb; idx += out_pb) {
+        if (!(idx < lim || (int)idx == extra)) continue;                          // uniform inside a quad
         const xyzz29_t x = E29::unpack(src[idx]);
         if (QUAD) acc = E29::add_quad(acc, x, q); else acc = E29::add(acc, x);
     }
@@ -1913,6 +1915,15 @@ static uint32_t slot_log() {
     }();
     return v;
 }
+// the part length a large set prefers when its buckets would fit shorter parts: 2^4 (SRS_MSM_SLOT_L0=<log2> for A/B)
+static uint32_t slot_want_cap() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("SRS_MSM_SLOT_L0");
+        const int lg = e ? std::atoi(e) : 4;
+        return (lg >= 2 && lg <= 8) ? (uint32_t)lg : 4u;
+    }();
+    return v;
+}
 // SRS_MSM_SLOTS=0: the r03 flow (fresh partial sums per set, accumulation levels per set); default: slot mode for every 16-bit-window set
 static bool use_slots(const Key &k, uint32_t n_max, uint32_t batch) {
     static const bool on = [] { const char *e = std::getenv("SRS_MSM_SLOTS"); return !(e && e[0] == '0'); }();
@@ -2031,7 +2042,7 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
                bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
     uint32_t *h_ovf = k.h_ovf + (size_t)slot * BATCH_ARGS;
     SRS_LAUNCH(k_plan_s, (batch, h.levels + 2), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, h.plan_stride, h.levels, S,
-               (uint32_t)ACC_L1_LOG, used_prev, used_next, first ? 1 : 0, h_ovf);
+               (uint32_t)ACC_L1_LOG, used_prev, used_next, first ? 1 : 0, h_ovf, slot_want_cap());
     if (two_pass) {
         const uint32_t T1 = tiles * NWIN;
         SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, h.plan_stride);
@@ -2084,10 +2095,10 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
         const int extra = (l == 0 && k.commit_ovf) ? (int)S - 1 : -1;
         if (l + 1 == h.nred) {
             SRS_LAUNCH((k_slot_reduce<C, true>), (ceil_div((uint64_t)n_out * 4, 256), batch), (256), 0, stream, in, in_pb, used, (size_t)NBUCKET, extra,
-                       out, out_pb, n_out);
+                       out, out_pb);
         } else {
             SRS_LAUNCH((k_slot_reduce<C, false>), (ceil_div(n_out, 256), batch), (256), 0, stream, in, in_pb, used, (size_t)NBUCKET, extra, out,
-                       out_pb, n_out);
+                       out_pb);
         }
         in = out;
         in_pb = out_pb;

@@ -299,6 +299,7 @@ struct Plan {
     bool mul29 = false;                                  // multi-pass plans: butterflies on the 9 x 29-bit multiplier, tables times 2^5
     fe_t scale;                                          // n^-1 for ifft (small path only)
     fe_t *scratch = nullptr;                             // n elements (multi-pass ping buffer)
+    hipEvent_t done = nullptr;                           // recorded behind the last transform that used `scratch` (see run)
 };
 
 static std::mutex g_mu;
@@ -360,6 +361,8 @@ static Plan &get_plan(uint32_t log_n, bool inverse, hipStream_t st) {
             }
         }
         SRS_HIP_CHECK(hipMalloc((void **)&p.scratch, sizeof(fe_t) << log_n));
+        SRS_HIP_CHECK(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+        SRS_HIP_CHECK(hipEventRecord(p.done, st));
     }
     SRS_HIP_CHECK(hipStreamSynchronize(st));
     return g_plans.emplace(key, p).first->second;
@@ -379,6 +382,7 @@ void release_plans() {
             if (kv.second.T[j]) (void)hipFree(kv.second.T[j]);
         }
         if (kv.second.scratch) (void)hipFree(kv.second.scratch);
+        if (kv.second.done) (void)hipEventDestroy(kv.second.done);
     }
     g_plans.clear();
 }
@@ -445,6 +449,13 @@ void run(fe_t *a, uint32_t log_n, size_t stride, uint32_t batch, bool inverse, b
                    (int)(inverse ? 1 : 0), pre, fin);
         return;
     }
+    // A plan owns ONE ping buffer, and plans are shared by every caller of this length: the transforms that use it are ordered here -- the
+    // launches of one transform are issued under the lock (two host threads on one stream cannot interleave their passes) and a transform
+    // on another stream waits for the event recorded behind the previous one (r04: tests/test_commit_gpu.py::
+    // test_two_host_threads_distinct_handles caught two threads' 2^12 transforms sharing the buffer).
+    static std::mutex scratch_mu;
+    std::lock_guard<std::mutex> scratch_lock(scratch_mu);
+    SRS_HIP_CHECK(hipStreamWaitEvent(st, p.done, 0));
     for (uint32_t b = 0; b < batch; ++b) {
         fe_t *v = a + (size_t)b * stride;
         PassArgs pa;
@@ -471,6 +482,7 @@ void run(fe_t *a, uint32_t log_n, size_t stride, uint32_t batch, bool inverse, b
         pa.pass = p.npass - 1;
         DISPATCH_R(launch_last, r, (const fe_t *)p.scratch, v, pa, p, p.npass - 1, fin, st);
     }
+    SRS_HIP_CHECK(hipEventRecord(p.done, st));
 }
 
 }  // namespace ntt

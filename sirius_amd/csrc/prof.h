@@ -54,7 +54,11 @@ struct Scope {
         p.units = units;
         p.e0 = take();
         p.e1 = take();
-        if (!p.e0 || !p.e1) return;
+        if (!p.e0 || !p.e1) {
+            if (p.e0) s.pool.push_back(p.e0);
+            if (p.e1) s.pool.push_back(p.e1);
+            return;
+        }
         (void)hipEventRecord(p.e0, st);
         live = true;
     }
@@ -88,6 +92,10 @@ struct KernelEvents {
         p.e0 = take();
         p.e1 = take();
         live = p.e0 && p.e1;
+        if (!live) {                              // the one event that could be had goes back to the pool
+            if (p.e0) s.pool.push_back(p.e0);
+            if (p.e1) s.pool.push_back(p.e1);
+        }
     }
     void launched() {
         State &s = state();
