@@ -275,8 +275,14 @@ def sangria_step(S, D, pri, sec, from_host, ro=False, count=False):
     if not from_host and D.world == 1 and not count and not SPLIT_SUPPORT:
         # resident traces: a trace's commitment shares the batched MSM of the prove that folds it (the secondary's at the start of the
         # next step, where both are first needed).  Traces coming from the host keep the streamed commit: its upload overlaps the MSM.
-        sec.prove_incoming(S, ro, False)
-        pri.prove_incoming(S, ro, False)
+        # Only a structure WITHOUT challenges may do that (the secondary: one gate): with challenges, U2's are squeezed after its
+        # commitment has been absorbed (src/plonk/mod.rs:465-495), so the primary (two gates, one challenge) commits, then proves.
+        for side, other in ((sec, pri), (pri, sec)):
+            if side.S.num_challenges == 0:
+                side.prove_incoming(S, ro, False)
+            else:
+                side.witness_commit(S, D, False)
+                side.prove(S, D, ro, count)
         return
     sec.prove(S, D, ro, count)
     pri.witness_commit(S, D, from_host)
@@ -398,12 +404,9 @@ class PgPrimary:
         gamma_m = ro.squeeze(255, 0) if ro else m([gamma])[0]
         self.e = PG.calculate_e(pF, pK, gamma_m, alpha_m, ctx.lagrange_domain)
         lag = PG.eval_lagrange_poly_for_cyclic_group(gamma_m, ctx.lagrange_domain)
-        # in place, the rank's stripes only: nothing the rank runs reads another stripe of the accumulator -- except, with the
-        # reference's row-0 leaves, row 0 of every column (+ the first stripe), which every rank folds for itself
-        PG.fold_witness(0, [self.accW, self.inW], lag, out=self.accW, shard=(D.rank, D.world))
-        if self.compat and D.rank != 0:
-            a, b = self.accW.view(-1, self.rows, 4), self.inW.view(-1, self.rows, 4)
-            a[:, 0] = PG.fold_witness(0, [a[:, 0].contiguous(), b[:, 0].contiguous()], lag)
+        # in place: the rank's stripes and the rows its kernels read beyond them (rotation halo; row 0 of every column with the
+        # reference's row-0 leaves) -- srs_structure_fold_sharded
+        PG.fold_witness(0, [self.accW, self.inW], lag, out=self.accW, structure=self.S, reference_compat=self.compat)
         self.betas = bs
         self.pending = S.point_lincomb_async(S.CURVE_BN256, None, np.stack([self.accC, self.inC]), lag[:2])       # fold_instance
 

@@ -412,8 +412,12 @@ int srs_sangria_prove(srs_structure *S, srs_ck *ck, srs_poseidon *ro, const srs_
 /* The same prove for an incoming trace that has just been synthesised and is NOT committed yet -- CyclefoldIVC::next's support
  * circuit (src/ivc/cyclefold/incrementally_verifiable_computation/mod.rs:255-300: the trace is generated, committed by
  * run_sps_protocol (src/plonk/mod.rs:441-447) and folded at once).  The reference commits it and then, inside prove, the cross
- * terms: two multi-exponentiations one after the other.  Neither depends on the other's result, so here they are ONE batched MSM
- * over d+1 vectors (W2 || T_0..T_{d-1}): W2_host (may be NULL when W2 already holds the trace) is uploaded into the device
+ * terms: two multi-exponentiations one after the other.  For a structure WITHOUT challenges (num_challenges == 0: one gate, no
+ * lookups -- the support circuit, the Sangria secondary) neither depends on the other's result, so here they are ONE batched MSM
+ * over d+1 vectors (W2 || T_0..T_{d-1}).  A structure with challenges is refused (SRS_ERR_INVALID): run_sps_protocol_1
+ * (src/plonk/mod.rs:465-495) squeezes U2's challenges from a transcript that has absorbed the trace's commitment, so the commitment
+ * must exist before the cross terms can be evaluated -- commit first, then srs_sangria_prove.
+ * W2_host (may be NULL when W2 already holds the trace) is uploaded into the device
  * vector W2 on `stream`, the cross terms are evaluated, all d+1 commitments come out of one chain of launches.
  * W_commitments[0] = U1's commitment (in), W_commitments[1] = the incoming trace's commitment (OUT).  Transcript: `ro` holds
  * pp_digest and U1; the call absorbs W_commitments[1], then u2_tail[0..n_u2_tail) (the rest of U2 -- its instances and
@@ -486,9 +490,18 @@ int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_f
                      int space, void *stream);
 /* The same fold on a process-per-GPU rank: DEVICE vectors; only the elements of the rank's block-cyclic stripes (2^10 elements
  * each, stripe s belongs to rank s % world -- the key's stripes) of out[0 .. n) are computed and written, everything else is
- * left as it is.  The rank's own kernels read nothing else of the folded accumulator (see srs_structure_set_shard). */
+ * left as it is.  Enough ONLY when the rank's kernels read nothing else of the folded vector: gates without rotated queries and
+ * leaves at their own rows.  For the accumulator of a row-sharded structure use srs_structure_fold_sharded, which also folds
+ * the halo rows (rotations; row 0 under reference_compat). */
 int srs_fold_lincomb_sharded(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n, uint32_t rank,
                              uint32_t world, void *stream);
+/* ProtoGalaxy::fold_witness (protogalaxy/mod.rs:176-210) / RelaxedPlonkWitness::fold for the witness vectors of a ROW-SHARDED
+ * structure (srs_structure_set_shard; W[j] = num_witness_columns * 2^k elements each, DEVICE): folds the rank's stripes and the
+ * rows its leaf / cross-term kernels read beyond them -- the rotation halo of every stripe and, with reference_compat, row 0 of
+ * every column (+ rotations): exactly the rows srs_structure_upload_shard_halo brings up for the incoming trace, so that after
+ * any number of folds every row the rank reads of the accumulator is the reference's.  out may be W[0].  Unsharded: the whole vector. */
+int srs_structure_fold_sharded(srs_structure *S, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, int reference_compat,
+                               void *stream);
 
 #ifdef __cplusplus
 }

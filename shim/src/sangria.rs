@@ -71,11 +71,33 @@ pub struct ResidentTraces { pub acc_w: *mut srs_fe, pub inc_w: *mut srs_fe, pub 
 
 /// What `prove_incoming` hands back: the fresh trace's commitment (for `PlonkTrace.u.W_commitments[0]`), the cross-term commitments,
 /// the challenge, and the two library jobs computing the folded W / E commitments (`srs_job_wait`).
-pub struct ProvedIncoming<C: GpuCurve> { pub incoming: C, pub cross_term_commits: Vec<C>, pub r: C::ScalarExt, pub folded: Box<[C; 2]>, pub jobs: [u64; 2] }
+/// `folded` is written by the library's workers until the jobs have been waited for, so it is private: `finish` waits and is the
+/// only way to read it, and dropping the value early (a `?` return between `prove_incoming` and `finish`) waits too -- the Box is
+/// never freed under a running job.
+pub struct ProvedIncoming<C: GpuCurve> { pub incoming: C, pub cross_term_commits: Vec<C>, pub r: C::ScalarExt, folded: Box<[C; 2]>, jobs: [u64; 2], waited: bool }
+
+impl<C: GpuCurve> ProvedIncoming<C> {
+    /// waits for the two instance-fold jobs: (folded W commitment, folded E commitment)
+    pub fn finish(mut self) -> Result<[C; 2], ShimError> {
+        self.waited = true;
+        let (a, b) = unsafe { (srs_job_wait(self.jobs[0]), srs_job_wait(self.jobs[1])) };
+        check(a)?;
+        check(b)?;
+        Ok(*self.folded)
+    }
+}
+impl<C: GpuCurve> Drop for ProvedIncoming<C> {
+    fn drop(&mut self) {
+        if !self.waited {
+            unsafe { srs_job_wait(self.jobs[0]); srs_job_wait(self.jobs[1]); }
+        }
+    }
+}
 
 /// `VanillaFS::prove` (src/nifs/sangria/mod.rs:253-277) for a trace that has just been synthesised and is not committed yet
 /// (CyclefoldIVC::next's support circuit, src/ivc/cyclefold/incrementally_verifiable_computation/mod.rs:255-300): upload, cross terms,
-/// ONE batched MSM for the trace's commitment and the cross terms', challenge, folds in place.  `ro`: the transcript holding pp_digest
+/// ONE batched MSM for the trace's commitment and the cross terms', challenge, folds in place.  ONLY for structures without
+/// challenges (the library refuses others: U2's challenges depend on the commitment, src/plonk/mod.rs:465-495).  `ro`: the transcript holding pp_digest
 /// and U1; `u2_tail`: what `generate_challenge` (:162-179) absorbs of U2 after its W commitment.  `acc_commitments` = (U1.W, U1.E).
 #[allow(clippy::too_many_arguments)]
 pub fn prove_incoming<C: GpuCurve>(s: &GpuStructure, ck: &GpuKey<C>, ro: *mut srs_poseidon, challenges: &[C::ScalarExt], tr: &ResidentTraces,
@@ -93,5 +115,5 @@ pub fn prove_incoming<C: GpuCurve>(s: &GpuStructure, ck: &GpuKey<C>, ro: *mut sr
                                               stream, &mut r as *mut C::ScalarExt as *mut srs_fe, tr.t.as_ptr(), commits.as_mut_ptr() as *mut srs_affine,
                                               w_commitments.as_mut_ptr() as *mut srs_affine, acc_commitments.1 as *const C as *const srs_affine,
                                               folded.as_mut_ptr() as *mut srs_affine, jobs.as_mut_ptr()) })?;
-    Ok(ProvedIncoming { incoming: w_commitments[1], cross_term_commits: commits, r, folded, jobs })
+    Ok(ProvedIncoming { incoming: w_commitments[1], cross_term_commits: commits, r, folded, jobs, waited: false })
 }

@@ -119,6 +119,7 @@ def _prototypes():
         "srs_poly_eval": (i32, [vp, sz, vp, vp]),
         "srs_fold_lincomb": (i32, [i32, vp, C.POINTER(vp), vp, sz, sz, i32, vp]),
         "srs_fold_lincomb_sharded": (i32, [i32, vp, C.POINTER(vp), vp, sz, sz, u32, u32, vp]),
+        "srs_structure_fold_sharded": (i32, [vp, vp, vp, vp, sz, i32, vp]),
         "srs_ntt": (i32, [i32, vp, sz, i32, i32, i32, vp]),
         "srs_ntt_set_max_radix_bits": (i32, [i32]),
         "srs_ntt_batch": (i32, [i32, vp, sz, sz, sz, i32, i32, i32, vp]),

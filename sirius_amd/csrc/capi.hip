@@ -155,6 +155,11 @@ struct srs_sparse {
 struct srs_structure {
     rowprog::Structure *s = nullptr;
     Arena io;           // staged witnesses / cross-term vectors
+    // rows a sharded rank reads beyond its own stripes (srs_structure_fold_sharded), as a device list per reference_compat value;
+    // valid for the (rank, world) it was built for
+    uint32_t *halo_dev[2] = {nullptr, nullptr};
+    size_t halo_n[2] = {0, 0};
+    uint32_t halo_rank = 0, halo_world = 0;
 };
 
 namespace {
@@ -1053,7 +1058,10 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
         // r03: re-tuned twice as the per-chunk costs fell (profiles/r03_ab_accum0_variants.txt, r03_ab_commit_cuts.txt).  With the
         // faster accumulation the chip keeps up with the uploads until the last chunk, so what counts is the MSM left once the last
         // byte has arrived: seven chunks, the last one 26 % -- was {0.045, 0.15, 0.32, 0.53, 0.77}, then {0.024, 0.089, 0.208, 0.399, 0.677}
-        std::vector<double> frac = {0.02, 0.07, 0.16, 0.30, 0.50, 0.74};
+        // r04 (slot mode: no accumulation levels per chunk, ~0.15 ms of fixed cost per chunk): the chip now WAITED for the uploads of the
+        // steeply growing middle chunks (~0.9 ms per commit in the kernel trace) -- nine chunks, each upload no longer than the chunk before
+        // it takes to accumulate: 12.0 -> 11.6 ms per step (profiles/r04_ab_slots_cuts.txt)
+        std::vector<double> frac = {0.02, 0.063, 0.129, 0.219, 0.336, 0.479, 0.652, 0.856};
         if (const char *e = std::getenv("SRS_COMMIT_CUTS")) {      // tuning: cumulative fractions, e.g. "0.1,0.4"
             frac.clear();
             for (const char *q = e; *q;) {
@@ -1459,6 +1467,8 @@ void srs_structure_free(srs_structure *S) {
     if (!S) return;
     rowprog::destroy(S->s);
     S->io.release();
+    for (int i = 0; i < 2; ++i)
+        if (S->halo_dev[i]) (void)hipFree(S->halo_dev[i]);
     delete S;
 }
 int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world) {
@@ -1466,6 +1476,76 @@ int srs_structure_set_shard(srs_structure *S, uint32_t rank, uint32_t world) {
     rowprog::set_shard(S->s, rank, world);
     return SRS_OK;
 }
+// rows of ONE column a sharded rank's kernels read beyond its own stripes: the rotation halo of every stripe, and row 0 (+ rotations) when
+// every ProtoGalaxy leaf sits at row 0 (reference_compat, src/plonk/mod.rs:714).  Sorted, unique.
+static std::vector<size_t> shard_halo_rows(const srs_structure *S, int reference_compat) {
+    const uint32_t world = rowprog::shard_world(S->s), rank = rowprog::shard_rank(S->s);
+    const size_t rows = rowprog::rows(S->s), SL = (size_t)1 << rowprog::ROW_STRIPE_LOG;
+    int32_t lo = 0, hi = 0;
+    rowprog::rotation_range(S->s, &lo, &hi);
+    auto own = [&](size_t row) { return (row >> rowprog::ROW_STRIPE_LOG) % world == rank; };
+    std::vector<size_t> need;
+    auto add_row = [&](int64_t r) {
+        const size_t row = (size_t)(((r % (int64_t)rows) + (int64_t)rows) % (int64_t)rows);
+        if (!own(row)) need.push_back(row);
+    };
+    if (lo < 0 || hi > 0) {
+        for (size_t s = rank; s < rows / SL; s += world) {
+            for (int64_t r = lo; r < 0; ++r) add_row((int64_t)(s * SL) + r);
+            for (int64_t r = 0; r < hi; ++r) add_row((int64_t)((s + 1) * SL) + r);
+        }
+    }
+    if (reference_compat)
+        for (int64_t r = lo; r <= hi; ++r) add_row(r);
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    return need;
+}
+
+// ProtoGalaxy::fold_witness / RelaxedPlonkWitness::fold of a row-sharded structure's accumulator: the rank's stripes AND the halo rows
+int srs_structure_fold_sharded(srs_structure *S, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, int reference_compat,
+                               void *stream) {
+    if (!S || !out || !W || !coefs || J == 0) return fail(SRS_ERR_INVALID, "srs_structure_fold_sharded: bad argument");
+    const uint32_t world = rowprog::shard_world(S->s), rank = rowprog::shard_rank(S->s), k = rowprog::log_rows(S->s);
+    const size_t rows = rowprog::rows(S->s), cols = rowprog::num_witness_columns(S->s), SL = (size_t)1 << rowprog::ROW_STRIPE_LOG;
+    const int field = rowprog::field(S->s);
+    if (world > 1 && (k < rowprog::ROW_STRIPE_LOG || (rows / SL) % world != 0))
+        return fail(SRS_ERR_INVALID, "srs_structure_fold_sharded: 2^k / 2^10 is not a multiple of the world size -- the row stripes of the "
+                                     "columns do not coincide with the key's stripes; fold the whole vector (srs_fold_lincomb)");
+    int rc = ensure_device();
+    if (rc) return rc;
+    return guarded([&]() -> int {
+        hipStream_t st = (hipStream_t)stream;
+        std::string err;
+        int erc = rowprog::lincomb(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *const *>(W),
+                                   reinterpret_cast<const fe_t *>(coefs), J, rows * cols, st, err, rank, world);
+        if (erc) return fail(erc, "srs_structure_fold_sharded: " + err);
+        if (world <= 1) return SRS_OK;
+        const int c = reference_compat ? 1 : 0;
+        if (S->halo_rank != rank || S->halo_world != world) {           // the shard changed: both lists are stale
+            for (int i = 0; i < 2; ++i) {
+                if (S->halo_dev[i]) (void)hipFree(S->halo_dev[i]);
+                S->halo_dev[i] = nullptr;
+                S->halo_n[i] = 0;
+            }
+            S->halo_rank = rank;
+            S->halo_world = world;
+        }
+        if (!S->halo_dev[c]) {
+            const std::vector<size_t> need = shard_halo_rows(S, reference_compat);
+            std::vector<uint32_t> r32(need.begin(), need.end());
+            SRS_HIP_CHECK(hipMalloc((void **)&S->halo_dev[c], (r32.size() + 1) * sizeof(uint32_t)));
+            if (!r32.empty()) SRS_HIP_CHECK(hipMemcpy(S->halo_dev[c], r32.data(), r32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            S->halo_n[c] = r32.size();
+        }
+        erc = rowprog::lincomb_rows(field, reinterpret_cast<fe_t *>(out), reinterpret_cast<const fe_t *const *>(W),
+                                    reinterpret_cast<const fe_t *>(coefs), J, S->halo_dev[c], S->halo_n[c], cols, rows, st, err);
+        if (erc) return fail(erc, "srs_structure_fold_sharded: " + err);
+        SRS_HIP_CHECK(hipGetLastError());
+        return SRS_OK;
+    });
+}
+
 int srs_structure_upload_shard_halo(const srs_structure *S, const srs_fe *witness_host, srs_fe *dev_copy, size_t n, int reference_compat,
                                     void *stream) {
     if (!S || !witness_host || !dev_copy) return fail(SRS_ERR_INVALID, "srs_structure_upload_shard_halo: bad argument");
@@ -1479,27 +1559,9 @@ int srs_structure_upload_shard_halo(const srs_structure *S, const srs_fe *witnes
                                      "columns do not coincide with the key's stripes; upload the whole witness instead");
     int rc = ensure_device();
     if (rc) return rc;
-    int32_t lo = 0, hi = 0;
-    rowprog::rotation_range(S->s, &lo, &hi);
-    // rows of ONE column this rank reads beyond its own stripes, as a bitmap over the 2^k rows (k <= 28: at most 32 MiB of bits,
-    // built only when there is a rotation); row r of column c is element c * 2^k + r of the witness
+    // row r of column c is element c * 2^k + r of the witness
     std::vector<std::pair<size_t, size_t>> runs;        // [first, last) row intervals to upload, per column
-    auto own = [&](size_t row) { return (row >> rowprog::ROW_STRIPE_LOG) % world == rank; };
-    auto add_row = [&](std::vector<size_t> &v, int64_t r) {
-        const size_t row = (size_t)(((r % (int64_t)rows) + (int64_t)rows) % (int64_t)rows);
-        if (!own(row)) v.push_back(row);
-    };
-    std::vector<size_t> need;
-    if (lo < 0 || hi > 0) {
-        for (size_t s = rank; s < rows / SL; s += world) {
-            for (int64_t r = lo; r < 0; ++r) add_row(need, (int64_t)(s * SL) + r);
-            for (int64_t r = 0; r < hi; ++r) add_row(need, (int64_t)((s + 1) * SL) + r);
-        }
-    }
-    if (reference_compat)
-        for (int64_t r = lo; r <= hi; ++r) add_row(need, r);          // every leaf at row 0 (+ rotations), src/plonk/mod.rs:714
-    std::sort(need.begin(), need.end());
-    need.erase(std::unique(need.begin(), need.end()), need.end());
+    const std::vector<size_t> need = shard_halo_rows(S, reference_compat);
     for (size_t i = 0; i < need.size();) {
         size_t j = i + 1;
         while (j < need.size() && need[j] == need[j - 1] + 1) ++j;
@@ -2274,6 +2336,12 @@ static int sangria_prove_impl(srs_structure *S, srs_ck *ck, srs_poseidon *ro, co
         if (rc) return rc;
     } else {
         if (n_challenges && !challenges) return fail(SRS_ERR_INVALID, "srs_sangria_prove_incoming: bad argument");
+        // run_sps_protocol_1 (src/plonk/mod.rs:465-495) squeezes U2's challenges out of a transcript that has already absorbed
+        // W_commitments: with one or more challenges the reference's order is commit, THEN challenge, THEN cross terms -- the
+        // commitment cannot share the cross terms' MSM.  Only zero-challenge structures (one gate, no lookups) may take this entry.
+        if (rowprog::num_challenges(S->s) != 0)
+            return fail(SRS_ERR_INVALID, "srs_sangria_prove_incoming: the structure has challenges (they depend on the trace's commitment); "
+                                         "commit the trace first (srs_commit_upload), then srs_sangria_prove");
         if (wlen > ck->key.global_len || rows > ck->key.global_len)
             return fail(SRS_ERR_TOO_LONG_INPUT, "Can't commit too long input: input len: " + std::to_string(std::max(wlen, rows)) +
                                                     ", but limit is " + std::to_string(ck->key.global_len));

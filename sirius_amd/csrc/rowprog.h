@@ -56,6 +56,9 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
 // world > 1: only the elements of rank's block-cyclic stripes (2^10 each) of out[0 .. n) are written
 int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, size_t n, hipStream_t st, std::string &err,
             uint32_t rank = 0, uint32_t world = 1);
+// the same sum on `n_rows` listed rows (device array) of each of `cols` columns of length col_len
+int lincomb_rows(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, const uint32_t *rows_dev, size_t n_rows, size_t cols,
+                 size_t col_len, hipStream_t st, std::string &err);
 
 // straight-line C++ of the structure's row program (tools/gen_rowprog_spec.py), its fingerprint and the
 // ahead-of-time kernel it maps to (-1: interpreter)

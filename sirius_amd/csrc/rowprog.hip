@@ -622,6 +622,17 @@ __global__ void k_lincomb(fe_t *__restrict__ out, LincombArgs a, size_t n, uint3
     }
 }
 
+// the same sum on listed rows of every column (the halo rows of a sharded fold): element c * col_len + rows[i]
+template <class F>
+__global__ void k_lincomb_rows(fe_t *__restrict__ out, LincombArgs a, const uint32_t *__restrict__ rows, size_t n_rows, size_t cols, size_t col_len) {
+    size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_rows * cols) return;
+    const size_t i = (l / n_rows) * col_len + rows[l % n_rows];
+    fe_t acc = F::mul(a.coef[0], a.w[0][i]);
+    for (uint32_t j = 1; j < a.J; ++j) acc = F::add(acc, F::mul(a.coef[j], a.w[j][i]));
+    out[i] = acc;
+}
+
 // ---- folds ----
 template <class F>
 __global__ void k_fold_w(fe_t *__restrict__ out, const fe_t *__restrict__ w1, const fe_t *__restrict__ w2, fe_t r, size_t n) {
@@ -2758,6 +2769,22 @@ int lincomb(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, s
         if (affine) SRS_LAUNCH((k_lincomb<Fq, true>), (blocks), (256), 0, st, out, a, n, rank, world);
         else SRS_LAUNCH((k_lincomb<Fq, false>), (blocks), (256), 0, st, out, a, n, rank, world);
     }
+    return 0;
+}
+
+int lincomb_rows(int field, fe_t *out, const fe_t *const *w_dev, const fe_t *coefs, size_t J, const uint32_t *rows_dev, size_t n_rows, size_t cols,
+                 size_t col_len, hipStream_t st, std::string &err) {
+    if (J == 0 || J > JMAX) { err = "unsupported number of witnesses"; return 4; }
+    if (!n_rows || !cols) return 0;
+    LincombArgs a;
+    a.J = (uint32_t)J;
+    for (uint32_t j = 0; j < JMAX; ++j) {
+        a.w[j] = j < J ? w_dev[j] : nullptr;
+        a.coef[j] = j < J ? coefs[j] : Fr::zero();
+    }
+    const uint32_t blocks = (uint32_t)((n_rows * cols + 255) / 256);
+    if (field == 0) SRS_LAUNCH((k_lincomb_rows<Fr>), (blocks), (256), 0, st, out, a, rows_dev, n_rows, cols, col_len);
+    else SRS_LAUNCH((k_lincomb_rows<Fq>), (blocks), (256), 0, st, out, a, rows_dev, n_rows, cols, col_len);
     return 0;
 }
 

@@ -109,9 +109,10 @@ def poly_eval(coeffs, x):
     return out
 
 
-def fold_witness(field, Ws, lagrange_for_gamma, out=None, shard=None):
+def fold_witness(field, Ws, lagrange_for_gamma, out=None, shard=None, structure=None, reference_compat=True):
     """W' = sum_j L_j(gamma) * W_j   (ProtoGalaxy::fold_witness).  shard = (rank, world): device vectors, only the rank's
-    block-cyclic stripes of `out` are computed (srs_fold_lincomb_sharded; `out` may be one of the inputs)."""
+    block-cyclic stripes of `out` are computed (srs_fold_lincomb_sharded; `out` may be one of the inputs).  structure = a
+    row-sharded PlonkStructure: its stripes AND the halo rows its kernels read beyond them (srs_structure_fold_sharded)."""
     bufs = [_buf(w, 4) for w in Ws]
     spaces = {b[1] for b in bufs}
     assert len(spaces) == 1 and len({b[2] for b in bufs}) == 1
@@ -119,6 +120,10 @@ def fold_witness(field, Ws, lagrange_for_gamma, out=None, shard=None):
     wp = (C.c_void_p * len(bufs))(*[b[0] for b in bufs])
     if out is None:
         out = _alloc_like(Ws[0], bufs[0][2])
+    if structure is not None:
+        L.check(L.lib().srs_structure_fold_sharded(structure._h, out.data_ptr() if _is_torch(out) else out.ctypes.data, wp, coefs.ctypes.data,
+                                                   len(bufs), int(bool(reference_compat)), _stream()))
+        return out
     if shard is not None and shard[1] > 1:
         L.check(L.lib().srs_fold_lincomb_sharded(field, out.data_ptr() if _is_torch(out) else out.ctypes.data, wp, coefs.ctypes.data,
                                                  len(bufs), bufs[0][2], shard[0], shard[1], _stream()))

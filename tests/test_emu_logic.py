@@ -476,3 +476,62 @@ def test_emu_concatenate_with_padding(emu, oracle):
     import torch
     from test_commit_gpu import _concat_cases
     _concat_cases(emu, oracle, 1, lambda n: torch.full((n, 4), 7, dtype=torch.int64), k=8)
+
+
+def test_emu_sharded_fold_with_rotations(emu, oracle):
+    """a row-sharded chain over a gate WITH rotated queries.  Two 'ranks' (two structure handles, set_shard(r, 2)) fold two
+    steps; after every fold everything a rank does not own and does not read (non-halo rows) is overwritten with garbage -- the rank's
+    rows of the cross terms must still equal the unsharded chain's.  srs_structure_fold_sharded folds the halo rows that
+    srs_fold_lincomb_sharded left stale; srs_structure_upload_shard_halo brings the incoming trace's."""
+    O = oracle
+    from sirius_amd import expression as X
+    from sirius_amd import protogalaxy as PG
+    from workloads import rand_fe
+    field, k, world = 1, 11, 2
+    rows, SL = 1 << k, 1 << 10
+    rng = np.random.default_rng(41)
+    nfix, nadv = 2, 3
+    # fixed: 0, 1; advice: 2, 3, 4     f0 * (a(+1) * b(-2) - c) + f1 * a(-1)
+    gate = X.Sum(X.Product(X.Polynomial(0), X.Sum(X.Product(X.Polynomial(2, 1), X.Polynomial(3, -2)), X.Negated(X.Polynomial(4)))),
+                 X.Product(X.Polynomial(1), X.Polynomial(2, -1)))
+    fixed = [rand_fe(rng, rows) for _ in range(nfix)]
+    acc0 = rand_fe(rng, nadv * rows)
+    incoming = [rand_fe(rng, nadv * rows) for _ in range(2)]
+    rs = [rand_fe(rng, 1)[0] for _ in range(2)]
+    one = O.ints_to_mont(field, [1])[0]
+    none = rand_fe(rng, 0)
+    u = rand_fe(rng, 1)[0]
+
+    def cross(St, W1, W2):
+        terms, _ = emu.VanillaFS.commit_cross_terms(None, St, none, u, W1, none, W2)
+        return terms
+
+    St = emu.PlonkStructure(field, k, [], fixed, nadv, [gate])
+    ref, acc = [], acc0.copy()
+    for t in range(2):
+        ref.append(cross(St, acc, incoming[t]))
+        acc = PG.fold_witness(field, [acc, incoming[t]], np.stack([one, rs[t]]))
+    St.close()
+    row_of = np.tile(np.arange(rows), nadv)
+    for rank in range(world):
+        Sr = emu.PlonkStructure(field, k, [], fixed, nadv, [gate])
+        Sr.set_shard(rank, world)
+        own = ((row_of >> 10) % world) == rank
+        halo = np.zeros(rows, bool)                         # rotations -2 .. +1 around the rank's stripes
+        for s in range(rank, rows // SL, world):
+            for r in (-2, -1):
+                halo[(s * SL + r) % rows] = True
+            halo[((s + 1) * SL) % rows] = True
+        keep = own | halo[row_of]
+        assert (keep & ~own).any()
+        accr = acc0.copy()
+        for t in range(2):
+            inr = rand_fe(rng, nadv * rows)                  # garbage ...
+            inr[own] = incoming[t][own]                      # ... except the rank's stripes (a sharded commit_upload) ...
+            Sr.upload_shard_halo(incoming[t], inr)           # ... and the halo rows
+            got = cross(Sr, accr, inr)
+            for a, b in zip(got, ref[t]):
+                assert np.array_equal(a[own[:rows]], b[own[:rows]]), (rank, t)
+            PG.fold_witness(field, [accr, inr], np.stack([one, rs[t]]), out=accr, structure=Sr, reference_compat=False)
+            accr[~keep] = rand_fe(rng, int((~keep).sum()))   # what the rank neither owns nor reads may be anything
+        Sr.close()

@@ -271,6 +271,12 @@ def _fold_then_decide(S, O, field, curve, k, gate_T):
     pr2["W_commitment"].wait(); pr2["E_commitment"].wait()
     # srs_sangria_prove_incoming: the incoming trace arrives from the HOST without a commitment -- uploaded, committed in the same batched
     # MSM as the cross terms, absorbed (+ the rest of U2: `u2_tail`) before the cross-term commitments
+    if nch:     # a structure with challenges: U2's challenges come after its commitment (src/plonk/mod.rs:465-495) -> the merged entry refuses
+        with pytest.raises(Exception) as ei:
+            S.sangria_prove(ck, St, y1, one, dv(W1), y2, dv(W2), dv(zeroE), cW1, np.zeros(8, np.uint64), r=r, incoming=True)
+        assert "challenges" in str(ei.value)
+        St.close()
+        return
     tail = rand_fe(rng, 3)
     ro3, oro3 = S.PoseidonHash(bf, 5, 4, 10, 10), OP.PoseidonHash(P.MODULI[bf], 5, 4, 10, 10)
     ro3.absorb_point(curve, cW1); oro3.absorb_point(tuple(O.mont_to_ints(bf, cW1.reshape(2, 4))))
