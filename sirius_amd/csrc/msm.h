@@ -49,8 +49,8 @@ constexpr uint32_t NSEG_W = 16;           // 2^(WBITS_W - 1) / NBUCKET
 constexpr uint32_t WIDE_THREADS = 256, WIDE_PER = 2, WIDE_TILE = WIDE_THREADS * WIDE_PER;   // scalars per workgroup of the segment passes
 // Measured (profiles/r02_wide_windows.txt): the wide pipeline wins from ~8 M scalars (12 * 2^20 uniform: 20.3 vs 22.2 ms);
 // below, its 16 bucket reductions and the extra grouping pass cost more than the 3 / 16 of the additions it saves.
-constexpr uint32_t WIDE_MIN_KEY_LOG = 23; // (r02: keys from 2^23 bases got the second, 13-window table; r03: only with SRS_MSM_WIDE=1, see wants_wide_table)
-constexpr uint32_t WIDE_MIN_N_LOG = 23;   // with SRS_MSM_WIDE=1: MSMs from 2^23 scalars take the wide path (SRS_MSM_WIDE_MIN=<log2> overrides)
+constexpr uint32_t WIDE_MIN_KEY_LOG = 23; // keys from 2^23 bases get the second, 13-window table (r04, see wants_wide_table in msm.hip; SRS_MSM_WIDE=0 / 1)
+constexpr uint32_t WIDE_MIN_N_LOG = 23;   // whole device-resident MSMs from 2^23 scalars take the wide path (SRS_MSM_WIDE_MIN=<log2> overrides)
 
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
 static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
@@ -76,7 +76,7 @@ struct Key {
     uint32_t rank = 0, world = 1;
     bool compact_scalars = false;   // world > 1: the scalar vectors handed to run() hold ONLY this rank's stripes, gathered (multi-device keys)
     affine_t *table = nullptr;
-    affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (only with SRS_MSM_WIDE=1; owned by the key: release())
+    affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (keys of >= 2^WIDE_MIN_KEY_LOG bases; owned by the key: release())
     xyzz_t *fold_buckets = nullptr;   // running bucket sums of a chunked commit (enqueue(.., fold)); owned by the key
     bool slot_wide[LANDING_SLOTS] = {};       // landing slot -> which pipeline produced it (finish() combines 3 or 4 partial sums)
     Chunked chunked;          // layout of the running chunked commit (pointers into `arena`)
@@ -128,7 +128,7 @@ void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_
 // reduction, no result), the FOLD_LAST set adds its own and reduces the total -- one k_rowcol + k_reduce_final + host finish per commit
 // instead of one per chunk.  batch == 1, 16-bit-window sets only (may_fold()).
 enum Fold { FOLD_NONE = 0, FOLD_FIRST = 1, FOLD_MIDDLE = 2, FOLD_LAST = 3 };
-bool may_fold(const Key &k, uint32_t n);     // false when a set of n scalars would take the wide-window pipeline
+bool may_fold(const Key &k, uint32_t n);     // always true since r04 (the sets of a chunked commit never take the wide-window pipeline)
 bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch, int is_mont,
              hipStream_t stream, uint32_t slot, Fold fold = FOLD_NONE);
 void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result_host);

@@ -1052,44 +1052,49 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     k_plan_s(const uint32_t *__restrict__ count, uint32_t *__restrict__ cursor, uint32_t *__restrict__ plan, size_t plan_stride, int nlevels,
              uint32_t S, uint32_t l1_log, const uint8_t *__restrict__ used_prev, uint8_t *__restrict__ used_next, int first,
              uint32_t *__restrict__ h_ovf, uint32_t want_cap) {
+    // Thread t owns PER consecutive buckets; they stay in LDS (index i at i + i / PER: conflict-free for the owner's walk AND for the
+    // coalesced loads / stores) and are walked twice -- sum, then running prefix written in place -- instead of being held in 32 registers
+    // (k_plan's form spilled 100+ bytes per lane to scratch: 34 us per launch, a third of a small chunk's fixed cost).
     constexpr uint32_t PER = NBUCKET / PLAN_THREADS;             // 32
-    __shared__ uint32_t tile[NBUCKET + NBUCKET / PER];           // index i lives at i + i / PER: conflict-free both ways (see k_plan)
+    __shared__ uint32_t tile[NBUCKET + NBUCKET / PER];
     __shared__ uint32_t lds[64];
     const uint32_t t = threadIdx.x, m = blockIdx.x, role = blockIdx.y;
     const uint32_t *cnt = count + (size_t)m * NBUCKET;
     uint32_t *pl = plan + (size_t)m * plan_stride;
     for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) tile[i + i / PER] = cnt[i];
     __syncthreads();
-    uint32_t vals[PER];
-    const uint32_t base = t * PER;
+    const uint32_t base = t * PER + t;
     uint32_t local = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < PER; ++j) {
-        vals[j] = tile[base + j + t];
-        local += vals[j];
-    }
+#pragma unroll 8
+    for (uint32_t j = 0; j < PER; ++j) local += tile[base + j];
     uint32_t total_entries;
     uint32_t run = block_exclusive_scan(local, lds, &total_entries);
     const uint32_t l0_log = slot_l0_log(total_entries, S, want_cap);
     uint32_t total = total_entries;
+    const bool dense = role == (uint32_t)nlevels + 1;
+    const uint32_t lv = role >= 2 && !dense ? role - 1 : 0;      // further levels an overflow role applies
+    // the value of a bucket with c entries in this role's array
+    auto value = [&](uint32_t c) -> uint32_t {
+        if (role == 0) return c;
+        uint32_t p = (c + (1u << l0_log) - 1) >> l0_log;         // level-0 parts
+        if (dense) return p;
+        p = p > S - 1 ? p - (S - 1) : 0u;                        // ... beyond the regular slots
+        for (uint32_t l = 0; l < lv; ++l) p = (p + (1u << l1_log) - 1) >> l1_log;
+        return p;
+    };
     if (role != 0) {
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) vals[j] = (vals[j] + (1u << l0_log) - 1) >> l0_log;        // level-0 parts of the bucket
-        if (role == (uint32_t)nlevels + 1) {                     // the dense thread space; slots in use after this set
-            const uint8_t *up = used_prev + (size_t)m * NBUCKET;
-            uint8_t *un = used_next + (size_t)m * NBUCKET;
-#pragma unroll
-            for (uint32_t j = 0; j < PER; ++j) {
-                const uint32_t now = vals[j] < S - 1 ? vals[j] : S - 1, was = first ? 0u : (uint32_t)up[base + j];
-                un[base + j] = (uint8_t)(now > was ? now : was);
+        local = 0;
+        uint32_t mx = 0;
+#pragma unroll 4
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t c = tile[base + j];
+            local += value(c);
+            if (!dense) {
+                const uint32_t p = (c + (1u << l0_log) - 1) >> l0_log, o = p > S - 1 ? p - (S - 1) : 0u;
+                mx = o > mx ? o : mx;
             }
-        } else {                                                 // overflow level role - 1
-            uint32_t mx = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < PER; ++j) {
-                vals[j] = vals[j] > S - 1 ? vals[j] - (S - 1) : 0u;
-                mx = vals[j] > mx ? vals[j] : mx;
-            }
+        }
+        if (!dense) {
             uint32_t p = block_max(mx, lds);
             int needed = 1;
             while (p > FINAL_FANIN && needed < nlevels) {
@@ -1102,21 +1107,20 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
                 pl[plan_stride - 2] = l0_log;
             }
             if ((int)role - 1 >= needed) return;                 // a level nobody runs (workgroup-uniform)
-            for (uint32_t lv = 1; lv < role; ++lv) {
-#pragma unroll
-                for (uint32_t j = 0; j < PER; ++j) vals[j] = (vals[j] + (1u << l1_log) - 1) >> l1_log;
-            }
         }
-        local = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) local += vals[j];
         run = block_exclusive_scan(local, lds, &total);
     }
-    __syncthreads();                                             // the load of the counts has finished reading `tile`
-#pragma unroll
+    const uint8_t *up = used_prev + (size_t)m * NBUCKET;
+    uint8_t *un = used_next + (size_t)m * NBUCKET;
+#pragma unroll 4
     for (uint32_t j = 0; j < PER; ++j) {
-        tile[base + j + t] = run;
-        run += vals[j];
+        const uint32_t c = tile[base + j], v = value(c);
+        tile[base + j] = run;
+        run += v;
+        if (dense) {                                             // slots in use after this set
+            const uint32_t now = v < S - 1 ? v : S - 1, was = first ? 0u : (uint32_t)up[t * PER + j];
+            un[t * PER + j] = (uint8_t)(now > was ? now : was);
+        }
     }
     __syncthreads();
     uint32_t *o = pl + (size_t)role * (NBUCKET + 1);
@@ -1635,15 +1639,17 @@ static void expand_windows(affine_t *table, uint32_t n, int nwin, int nbits, xyz
     }
 }
 
-// r03: with the narrow pipeline's two-pass sort and the wide pipeline still on its entry-by-entry counting sort the 16-bit windows won at
-// every size (2^24 uniform 22.1 vs 25.8 ms, k = 22 step 41.9 vs 44.0 ms: profiles/r03_ab_wide_vs_narrow.txt), so the wide pipeline went
-// OFF by default (no second table: -45 % key memory).  Later in r03 its segments got the same two passes (k_group_g / k_scatter2_g) and it
-// is ahead again from ~12 M scalars -- 2^24 uniform 20.5 vs 22.5 ms, trace-like 10.4 vs 10.8; 12 * 2^20: 16.2 vs 16.9 / 8.2 vs 8.3; green
-// against the oracle at 2^24 and 12 * 2^22 -- but it stays opt-in (SRS_MSM_WIDE=1: second table for every key, wide from
-// 2^WIDE_MIN_N_LOG scalars / SRS_MSM_WIDE_MIN) until a clean full bench with it on: same file, last section.
+// Which keys carry the second, 13-window table.  r03 ended with the wide pipeline opt-in: ahead at >= 12 M scalars (2^24 uniform 20.5 vs
+// 22.5 ms) but with ONE full bench in which the row-program kernels ran slower on that box.  r04 repeated the comparison (three full
+// benches each way on one box, profiles/r04_ab_wide_vs_narrow.txt): the anomaly did not come back -- the k = 20 step is the same with
+// and without the second table (11.52 / 11.52 vs 11.55 / 11.57 ms), the 2^24 MSM is 19.9-20.0 vs 22.3 ms uniform and 10.30 vs 10.71 ms
+// trace-like.  So: keys of >= 2^WIDE_MIN_KEY_LOG bases get the table (+81 % key memory: 29 GiB instead of 16 at 2^24) and WHOLE,
+// device-resident MSMs of >= 2^WIDE_MIN_N_LOG scalars take the 20-bit windows; the sets of a streamed commit stay on the 16-bit windows
+// and the slots (their chunks are 0.3-3 M scalars, where the wide pipeline's fixed costs lose).  SRS_MSM_WIDE=0 / 1: never / every key.
 static bool wants_wide_table(size_t len) {
-    static const int forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();   // 1: on, else off
-    return forced == 1 && len > 0;
+    static const int forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();
+    if (forced == 0 || len == 0) return false;
+    return forced == 1 || len >= ((size_t)1 << WIDE_MIN_KEY_LOG);
 }
 
 template <class C>
@@ -1924,11 +1930,15 @@ static uint32_t slot_want_cap() {
     }();
     return v;
 }
-// SRS_MSM_SLOTS=0: the r03 flow (fresh partial sums per set, accumulation levels per set); default: slot mode for every 16-bit-window set
-static bool use_slots(const Key &k, uint32_t n_max, uint32_t batch) {
-    static const bool on = [] { const char *e = std::getenv("SRS_MSM_SLOTS"); return !(e && e[0] == '0'); }();
-    static const uint64_t min_slots = [] { const char *e = std::getenv("SRS_MSM_SLOT_MIN_LOG"); return e ? (1ull << std::atoi(e)) : 0ull; }();
-    return on && !use_wide(k, n_max, batch) && (uint64_t)n_max * NWIN * batch >= min_slots;
+// Slot mode is for the sets of a CHUNKED commit (fold != FOLD_NONE): that is where every set used to pay its own accumulation levels, wave-level
+// pass and bucket fold.  A set that is a whole MSM keeps the r03 flow, by measurement (profiles/r04_ab_slots_cuts.txt): the batched
+// cross-term commitments would each pay a slot reduction (k = 17 Sangria step 6.02 vs 5.76 ms), a single 2^24 MSM is 2 % slower (22.3 vs
+// 21.85 ms).  SRS_MSM_SLOTS=0: never; SRS_MSM_SLOTS=2: every 16-bit-window set (what the emulator tests force).
+static bool use_slots(const Key &k, uint32_t n_max, uint32_t batch, Fold fold) {
+    static const int mode = [] { const char *e = std::getenv("SRS_MSM_SLOTS"); return e ? std::atoi(e) : 1; }();
+    if (mode == 0) return false;
+    if (fold != FOLD_NONE) return batch == 1;
+    return mode == 2 && !use_wide(k, n_max, batch);
 }
 struct SlotShape {
     uint32_t S, nred;          // slots per bucket; reduction levels at the end of a commit (8 inputs per output)
@@ -2464,7 +2474,7 @@ static void finish_t(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_
     }
 }
 
-bool may_fold(const Key &k, uint32_t n) { return !use_wide(k, n, 1); }
+bool may_fold(const Key &, uint32_t) { return true; }      // (r03: not for sets that took the wide pipeline; they no longer do)
 
 bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, const uint32_t *base_host, uint32_t batch, int is_mont,
              hipStream_t stream, uint32_t slot, Fold fold) {
@@ -2472,11 +2482,11 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
         set_error("internal: msm::enqueue batch / slot out of range");
         throw DeviceError{5};
     }
-    if (fold != FOLD_NONE && (batch != 1 || use_wide(k, n_host[0], 1))) {
-        set_error("internal: msm::enqueue fold needs one 16-bit-window MSM per set");
+    if (fold != FOLD_NONE && batch != 1) {
+        set_error("internal: msm::enqueue fold needs one MSM per set");
         throw DeviceError{5};
     }
-    if (batch == 1 && use_wide(k, n_host[0], 1)) {
+    if (batch == 1 && fold == FOLD_NONE && use_wide(k, n_host[0], 1)) {      // the sets of a chunked commit stay on the 16-bit windows
         const uint32_t base = base_host ? base_host[0] : 0;
         k.slot_mode[slot] = false;
         ++k.stat_other_sets;
@@ -2487,7 +2497,7 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
     for (uint32_t m = 0; m < batch; ++m) n_max = std::max(n_max, n_host[m]);
     // the sets of one commit take the same flow: decided by its first set
     const bool first = fold == FOLD_NONE || fold == FOLD_FIRST;
-    const bool slots = first ? use_slots(k, n_max, batch) : k.slot_s != 0;
+    const bool slots = first ? use_slots(k, n_max, batch, fold) : k.slot_s != 0;
     if (slots)
         return k.curve == 0 ? enqueue_slots_t<Bn256>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold)
                             : enqueue_slots_t<Grumpkin>(k, scalars_dev, n_host, base_host, batch, is_mont, stream, slot, fold);
@@ -2502,7 +2512,7 @@ void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result
 }
 void reserve(Key &k, uint32_t n_max, uint32_t batch) {
     size_t b = use_wide(k, n_max, batch) ? std::max(workspace_bytes_wide(n_max), workspace_bytes(n_max, batch)) : workspace_bytes(n_max, batch);
-    if (use_slots(k, n_max, batch)) b = std::max(b, workspace_bytes_slots(n_max, batch));
+    if (batch == 1) b = std::max(b, workspace_bytes_slots(n_max, batch));        // (a chunked commit's sets: slot mode)
     k.arena.reserve(b);
 }
 

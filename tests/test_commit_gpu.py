@@ -258,10 +258,13 @@ def _dev(a):
 
 def test_commit_config_sizes_vs_oracle(srs, oracle):
     """BASELINE configs[4] (2^24-point MSM) and configs[2] (12 * 2^20 witness commit, bn256) at FULL size, compared DIRECTLY
-    with the oracle's best_multiexp restatement (src/commitment.rs:81-90) on the key's own bases: the production pipelines --
-    16-bit windows with the two-pass sort through LDS (2^28 digit slots at 2^24), the streamed 7-chunk upload with chunk-folded
-    buckets, a 3-shard multi-device key -- at the sizes BASELINE names, not only forced onto small inputs.  (The 20-bit wide windows
-    are off by default since r03 and keep their own tests under SRS_MSM_WIDE=1.)"""
+    with the oracle's best_multiexp restatement (src/commitment.rs:81-90) on the key's own bases: the production pipelines at the
+    sizes BASELINE names, not only forced onto small inputs --
+      * the 20-bit wide windows (r04: the default again for whole device-resident MSMs of >= 2^23 scalars on keys of >= 2^23 bases):
+        the two 2^24 commits and the resident 12 * 2^20 commit;
+      * the streamed nine-chunk upload on the 16-bit windows in slot mode (persistent per-bucket partial sums, one reduction per
+        commit; the "trace" mixture has hot buckets, so the overflow kernels and the once-per-key redo run too: msm_stats);
+      * a 3-shard multi-device key (16-bit windows per shard)."""
     O = oracle
     cid = 0
     n24 = 1 << 24
@@ -283,6 +286,8 @@ def test_commit_config_sizes_vs_oracle(srs, oracle):
     import torch
     assert torch.equal(d, _dev(v))
     assert np.array_equal(ck.commit_upload(v), want), "12*2^20 commit_upload (pageable)"
+    st = ck.msm_stats()
+    assert st["slot_sets"] >= 18 and st["hot_sets"] >= 1 and st["redo"] <= 1 and st["other_sets"] >= 3, st     # 2 streamed commits in slot mode, 3 wide MSMs
     hb.close()
     ck.close()
     del d
