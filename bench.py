@@ -53,6 +53,19 @@ MAD_ISSUE_PER_S = 31.16e12
 MADD_MULT_INSNS = 8 * 171 + 2 * 135 - 90
 
 
+# No multi-GPU node was available to r01-r04: what the first measured SCALE record can be diffed against (derived from the
+# r04 kernel trace of the N = 1 step: per-row / per-scalar work divides by N, the chain's latency-bound part does not).
+PREDICTED_SCALING = {
+    "note": "PREDICTION, not a measurement: k = 20 CycleFold step, process per GPU (bench.py --gpus N); strong scaling of ONE sequential chain",
+    "ms_per_step": {"1": 11.5, "2": 7.6, "4": 5.3, "8": 4.2},
+    "speedup": {"1": 1.0, "2": 1.5, "4": 2.2, "8": 2.7},
+    "msm_2p24_uniform_ms": {"1": 20.0, "2": 10.4, "4": 5.6, "8": 3.1},
+    "divisible_ms_at_1": 8.9, "replicated_ms": 2.6,
+    "replicated": "transcript (Poseidon, host) 0.35, compute_F tree upper levels + K + e 0.35, bucket reductions + host finish 0.3, k_plan_s / "
+                  "k_hist floors 9 x 0.07, support circuit's latency-bound MSM 0.5, step-wise calls + five <= 2 KB all-gathers 0.45",
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +87,10 @@ def parse():
     ap.add_argument("--emu", action="store_true",
                     help="harness self-test without a GPU: loads the CPU logic emulator (tests/emu, test infrastructure) and keeps "
                          "'device' tensors in host memory; use a tiny --k.  The numbers it prints are meaningless")
+    ap.add_argument("--single-process", action="store_true",
+                    help="with --gpus N: ONE process, the commitment keys are multi-device keys (srs_ck_create_multi: the library owns N devices / "
+                         "shards, partitions the scalars, adds the partial sums on the host) -- the path a single-process Rust IVC driver calls. "
+                         "More logical shards than physical devices are allowed (shard d runs on device d % count)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU exchange; lets 2 ranks share one GPU in tests)")
     args = ap.parse_args()
     args.ro_challenge = args.challenges == "poseidon-ro" or args.ro_challenge
@@ -135,7 +152,9 @@ class Dist:
             else:
                 dist.init_process_group(backend=args.dist_backend)
             self.dist = dist
-        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
+        # --single-process: one rank whatever --gpus says; the keys are multi-device keys with `multi` shards
+        self.multi = args.gpus if getattr(args, "single_process", False) and args.gpus > 1 else 0
+        assert self.world == (1 if self.multi else args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
 
     def combine(self, curve, partial):
         if self.world == 1:
@@ -166,6 +185,13 @@ class Dist:
         return float(tt.item())
 
 
+def make_key(S, D, curve, n, seed):
+    """the commitment key of one circuit: sharded over the ranks (process per GPU), a multi-device key (--single-process), or plain"""
+    if getattr(D, "multi", 0):
+        return S.CommitmentKey.setup_synthetic_multi(curve, n, seed=seed, n_devices=D.multi)
+    return S.CommitmentKey.setup_synthetic(curve, n, seed=seed, rank=D.rank, world=D.world)
+
+
 def up(D, a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(D.dev)
@@ -188,7 +214,7 @@ class SangriaSide:
         if D.world > 1:
             self.S.set_shard(D.rank, D.world)
         assert w["num_advice"] * self.rows <= (1 << log_key)
-        self.ck = S.CommitmentKey.setup_synthetic(self.curve, 1 << log_key, seed=42 + self.curve, rank=D.rank, world=D.world)
+        self.ck = make_key(S, D, self.curve, 1 << log_key, 42 + self.curve)
         self.accW, self.accE = up(D, w["W1"]), up(D, w["E"])
         self.host_W = pinned_copy(S, w["W2"])                    # the incoming witness as the CPU synthesis leaves it
         self.inW = up(D, w["W2"])                                # its device copy (rewritten by every witness commit)
@@ -313,7 +339,7 @@ class PgPrimary:
         self.ctx = PG.PolyContext(self.S, 1)
         n = w["num_advice"] * self.rows
         assert n <= (1 << log_key)
-        self.ck = S.CommitmentKey.setup_synthetic(S.CURVE_BN256, 1 << log_key, seed=42, rank=D.rank, world=D.world)
+        self.ck = make_key(S, D, S.CURVE_BN256, 1 << log_key, 42)
         self.accW, self.inW = up(D, w["W1"]), up(D, w["W2"])
         # fold_witness deferred (DEFER_FOLD): nothing reads the folded witness before the next prove, so the 1.2 GB pass is queued on
         # a second stream when the next witness starts to come up (the device waits for PCIe there) -- into a SECOND incoming buffer
@@ -351,7 +377,7 @@ class PgPrimary:
             ro = self.ro.reset()
             ro.absorb_field(np.concatenate([self.accC.reshape(2, 4), self.inC.reshape(2, 4)]))
             ro.absorb_field(self.betas)
-            delta = PGint(ro.squeeze(128, 0))
+            delta = PGint(ro.squeeze(255, 0))          # MAX_BITS (src/constants.rs:4), as Challenges::generate_one squeezes it
         if self.sharded:
             return self.prove_sharded(S, D, ro, m([delta])[0], alpha, gamma)
         # one library call (srs_pg_prove): F -> alpha -> betas' -> G -> K -> gamma -> L(gamma), e, fold_witness
@@ -459,6 +485,15 @@ def build_cyclefold(S, D, k, log_key, compat, ks=15):
     sup.witness_commit(S, D, False)
     pri.inC = D.combine(S.CURVE_BN256, pri.ck.commit(pri.inW))
     return pri, sup, ks
+
+
+def sangria_chain_digest(pri, sec):
+    """What a Sangria chain has folded so far: both circuits' folded instance commitments, last witness commitments and challenges --
+    what tests/chain_cases.py::oracle_chain_sangria recomputes on the CPU oracle."""
+    import hashlib
+    pri.settle(); sec.settle()
+    return hashlib.sha256(b"".join(np.ascontiguousarray(x, dtype=np.uint64).tobytes() for sd in (pri, sec) for x in
+                                   (sd.accCW, sd.accCE, sd.inC, sd.r))).hexdigest()
 
 
 def chain_digest(pri, sup):
@@ -614,6 +649,13 @@ def extras_sangria(S, D, args, k=17, log_key=21, steps=20, warmup=3):
             out["roofline"] = msm_roofline(S, "30 * 2^17 scalars per step over 2 batched launches (a trace and its cross terms each)", 16.0 * nz * steps / D.world, D.world)
             ct = S.profile_get("rowprog_cross_terms")
             out["cross_terms_ms_per_launch"] = round(ct["total_ms"] / ct["launches"], 4) if ct and ct["launches"] else None
+    # 1 counting step + (warmup + steps) x 2 legs, all on the same two accumulators: the digest of that chain (with Poseidon-derived r it
+    # equals tests/chain_cases.py::oracle_chain_sangria after the same number of steps; checked at k = 10 / 12 in tests/test_chain_gpu.py)
+    out["state_digest"] = sangria_chain_digest(pri, sec)
+    out["steps_folded"] = 1 + 2 * (warmup + steps)
+    out["transcript"] = ("synthetic: r absorbs the accumulator's W / E commitments, the incoming W commitment and the cross-term commitments "
+                         "(generate_challenge, src/nifs/sangria/mod.rs:162-179, without pp_digest / instances / u); the gate-compression "
+                         "challenges and u of both instances are seeded constants")
     out["workload"] = f"sangria_poseidon fold_step hot path, k={k}, bn256/grumpkin, key 2^{log_key} (BASELINE configs[1])"
     out["host_path_ms_per_step"] = out["host_witness"]["ms_per_step"]
     cpu = None
@@ -687,7 +729,7 @@ def extras_msm_sharded(S, D, ck, log_n, reps=3):
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         spawn_ranks(args)
     import torch
     if args.emu:
@@ -714,7 +756,7 @@ def main():
         scalars_per_step = pri.w["num_advice"] * pri.rows + (3 + 2) * sup.rows
         if D.rank == 0:
             nz = sum(nonzero_rows(torch.from_numpy(hb.array.view(np.int64))) for hb in pri.host_W) / 2.0 + nonzero_rows(sup.inW) + sup.nz_terms
-            roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 7 chunks + the support circuit's 5*2^15 per step",
+            roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 9 chunks + the support circuit's 5*2^15 per step",
                                 16.0 * nz * args.steps / D.world, D.world)
             prof = {}
             for name in ("pg_F_leaves", "pg_G_leaves", "rowprog_cross_terms"):
@@ -724,7 +766,7 @@ def main():
             digest = chain_digest(pri, sup)
             out = {
                 "metric": "IVC fold-steps/s (CycleFold IVC::next hot path, Poseidon-shaped synthetic trace, 2^k rows)",
-                "value": round(args.steps / dt, 4), "unit": "fold-steps/s", "n_gpus": D.world, "steps": args.steps,
+                "value": round(args.steps / dt, 4), "unit": "fold-steps/s", "n_gpus": D.multi or D.world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "u256 (modular; 9 x 29-bit / 8 x 32-bit limbs)",
                 "data": "synthetic",
@@ -733,7 +775,16 @@ def main():
                                       f"12*2^{k} witness commit with the witness uploaded from host memory inside the step",
                            "support": f"Sangria prove on the support circuit: k={ks}, 3 advice / 4 fixed / 1 selector, 2 cross terms; 3*2^{ks} witness commit",
                            "leaf_rows": args.leaf_rows, "challenges": "poseidon-ro" if args.ro_challenge else "seeded",
-                           "parallelism": (f"msm+leaf-shard{D.world}" if getattr(pri, "sharded", False) else f"msm-shard{D.world}") if D.world > 1 else "single-gpu"},
+                           "transcript": "synthetic content, the reference's order and widths: delta absorbs the 4 coordinates of the accumulator's and "
+                                         "the incoming W commitments + the betas (Challenges::generate_one absorbs pp_digest, the accumulator and the "
+                                         "instances as limbs, src/nifs/protogalaxy/mod.rs:80-101) and is squeezed with MAX_BITS = 255; alpha / gamma absorb "
+                                         "poly_F / poly_K, 255 bits (:424-448); the support circuit's r as generate_challenge (sangria/mod.rs:162-179), 128 bits",
+                           "witness": "55 % zero scalars, 45 % uniform 254-bit: 7.2 non-zero 16-bit digits (= bucket additions) per scalar, no hot buckets; "
+                                      "SURVEY.md 8d(ii)'s mixture with bits and small values costs ~2.4 per scalar (tests/conftest.py seeded_scalars 'trace')",
+                           "msm": "16 x 16-bit windows, streamed commit in 9 chunks, slot mode (per-bucket persistent partial sums, one reduction per commit)",
+                           "parallelism": (f"msm+leaf-shard{D.world}" if getattr(pri, "sharded", False) else f"msm-shard{D.world}") if D.world > 1
+                                          else (f"msm-multi{D.multi}-single-process ({pri.ck.num_shards} shards on {torch.cuda.device_count() if not D.emu else 0} device(s))"
+                                                if D.multi else "single-gpu")},
                 "msm_scalars_per_s": round(scalars_per_step * args.steps / dt, 1),
                 "witness_upload_bytes_per_step": int(pri.w["num_advice"] * pri.rows * 32 + 3 * sup.rows * 32),
                 "roofline": roof, "kernel_ms": prof, "state_digest": digest,
@@ -769,7 +820,8 @@ def main():
             micro = extras_microbench(S, D, ck24) if ck24 is not None else (extras_microbench(S, D, pri.ck, log_key, 1) if D.emu else None)
             S.profile_enable(False)
             if D.rank == 0:
-                out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "sangria_k17": sec_obj, "microbench_2p24": micro}
+                out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "sangria_k17": sec_obj, "microbench_2p24": micro,
+                                    "predicted_scaling": PREDICTED_SCALING}
                 out["host_path_ms_per_step"] = sec_obj["host_path_ms_per_step"]
         if not args.no_extras and D.world > 1 and (log_key == 24 or D.emu):
             del pri.accW, pri.inW

@@ -25,6 +25,10 @@
 //     quad_perm moves), 3.9 us instead of 9.8 us per addition.
 // Batched entry: the d-1 cross-term commitments share one base prefix and run
 // as one set of launches (grid.y / grid.z = batch index).
+// The 29-bit products of THIS translation unit chain every column's multiply-accumulates from the previous column's carry (inline
+// v_mad_u64_u32, field29.cuh): no 64-bit join per column, 127 instead of 132 VGPRs in k_accum0 / k_accum0s (4 waves per SIMD instead of
+// 3): 13.85 -> 14.4 G mixed additions/s, profiles/r04_ab_slots_cuts.txt.  Device code only; host and emulator builds keep the C form.
+#define SRS_F29_CHAIN 1
 #include "msm.h"
 #include "curve29.cuh"
 #include "prof.h"

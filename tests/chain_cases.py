@@ -75,7 +75,7 @@ def oracle_chain(O, S_for_keys, k, log_key, ks, steps, compat=True):
         ro = OP.PoseidonHash(FR, 5, 4, 10, 10)
         ro.absorb_field_iter(ints(0, np.concatenate([accC.reshape(2, 4), inC.reshape(2, 4)])))     # bench: coordinates as Fr bit patterns
         ro.absorb_field_iter(betas)
-        delta = ro.squeeze(128)
+        delta = ro.squeeze(255)                                                                    # MAX_BITS, protogalaxy/mod.rs:96-101
         pF = OPG.compute_F(oS, octx, betas, delta, accW, [], compat)
         alpha = ro.absorb_field_iter(pF).squeeze(255)
         bs = OPG.beta_stroke(betas, alpha, delta)
@@ -112,3 +112,73 @@ def oracle_chain(O, S_for_keys, k, log_key, ks, steps, compat=True):
     e_m = mont(0, [e])[0]
     return hashlib.sha256(b"".join(np.ascontiguousarray(x, dtype=np.uint64).tobytes() for x in
                                    (e_m, accC, inC, s_accCW, s_accCE, s_inC))).hexdigest()
+
+
+def product_chain_sangria(S, k, log_key, steps, from_host=False, emu=False):
+    """bench.py's Sangria sides (BASELINE configs[1] shapes), `steps` fold steps with Poseidon-derived r -> bench.sangria_chain_digest"""
+    import bench
+    from workloads import make_structure_inputs
+    bench.SPLIT_SUPPORT = False
+    D = bench.Dist(argparse.Namespace(emu=emu, gpus=1, dist_backend="nccl"))
+    pri = bench.SangriaSide(S, D, make_structure_inputs("primary", k, seed=0x5349524955530000 + 2), log_key, "primary")
+    sec = bench.SangriaSide(S, D, make_structure_inputs("secondary", k, seed=0x5349524955530000 + 3), log_key, "secondary")
+    pri.witness_commit(S, D, False)
+    sec.witness_commit(S, D, False)
+    for _ in range(steps):
+        bench.sangria_step(S, D, pri, sec, from_host, True)
+    return bench.sangria_chain_digest(pri, sec)
+
+
+def oracle_chain_sangria(O, S_for_keys, k, log_key, steps):
+    """The same two-curve Sangria chain (SangriaIVC::fold_step's hot path, src/ivc/sangria/incrementally_verifiable_computation.rs:429-635;
+    VanillaFS::prove, src/nifs/sangria/mod.rs:253-277) on the oracle: literal GroupedPoly / GraphEvaluator cross terms, best_multiexp,
+    the Poseidon transcript of generate_challenge (:162-179), the witness / error / instance folds (accumulator.rs:201-264, 364-404).
+    Every step folds the same incoming trace into each circuit's accumulator (the bench's synthetic traces are fixed), so the order of the
+    two circuits inside a step does not matter."""
+    from oracle import expr as OE
+    from oracle import poseidon as OP
+    from oracle import pyref as P
+    from workloads import make_structure_inputs, sangria_shape
+    ints = lambda f, a: O.mont_to_ints(f, np.asarray(a).reshape(-1, 4))
+    ident = np.zeros(8, np.uint64)
+    sides = []
+    for which, seed in (("primary", 2), ("secondary", 3)):
+        w = make_structure_inputs(which, k, seed=0x5349524955530000 + seed)
+        gate_T = sangria_shape(which)["gate_T"]
+        nfix = sum(2 * T + 5 for T in gate_T)
+        og, fo, ao = [], 0, 0
+        for T in gate_T:
+            og.append(OE.main_gate_expression(T, 0, fo, ao, nfix))
+            fo += 2 * T + 5
+            ao += T + 2
+        field, curve = w["field"], w["curve"]
+        ck = S_for_keys.CommitmentKey.setup_synthetic(curve, 1 << log_key, seed=42 + curve)
+        bases = ck.bases()
+        ck.close()
+        n = w["num_advice"] * w["rows"]
+        one = O.ints_to_mont(field, [1])
+        ch = np.concatenate([w["u1_challenges"].reshape(-1, 4), w["u1_u"].reshape(1, 4), w["u2_challenges"].reshape(-1, 4), one])
+        sides.append(dict(w=w, og=og, field=field, curve=curve, bases=bases, n=n, ch=ch, accW=w["W1"], accE=w["E"], inW=w["W2"],
+                          accCW=ident.copy(), accCE=ident.copy(), inC=None, r=w["r"], sf=0 if curve == 0 else 1, bf=1 if curve == 0 else 0))
+    for _ in range(steps):
+        for sd in sides:
+            w, curve, field, sf, bf = sd["w"], sd["curve"], sd["field"], sd["sf"], sd["bf"]
+            sd["inC"] = O.msm(curve, sd["inW"], sd["bases"][: sd["n"]])
+            ro = OP.PoseidonHash(P.MODULI[bf], 5, 4, 10, 10)
+            for pt in (sd["accCW"], sd["accCE"], sd["inC"]):
+                ro.absorb_point(tuple(ints(bf, pt.reshape(2, 4))))
+            _, T = OE.cross_terms_oracle(O, field, sd["og"], 0, w["num_fixed"], w["num_advice"], [], w["fixed"], sd["accW"], sd["inW"], sd["ch"])
+            Tc = [O.msm(curve, t, sd["bases"][: t.shape[0]]) for t in T]
+            for c in Tc:
+                ro.absorb_point(tuple(ints(bf, c.reshape(2, 4))))
+            r = O.ints_to_mont(sf, [ro.squeeze(128)])[0]
+            sd["accW"] = O.fold_w(field, sd["accW"], sd["inW"], r)
+            sd["accE"] = O.fold_e(field, sd["accE"], T, r)
+            rp = r.copy()
+            for c in Tc:
+                sd["accCE"] = O.point_add(curve, sd["accCE"], O.point_mul(curve, rp, c))
+                rp = O.fe_mul(sf, rp.reshape(1, 4), r.reshape(1, 4))[0]
+            sd["accCW"] = O.point_add(curve, sd["accCW"], O.point_mul(curve, r, sd["inC"]))
+            sd["r"] = r
+    return hashlib.sha256(b"".join(np.ascontiguousarray(x, dtype=np.uint64).tobytes() for sd in sides for x in
+                                   (sd["accCW"], sd["accCE"], sd["inC"], sd["r"]))).hexdigest()

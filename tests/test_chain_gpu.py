@@ -3,6 +3,7 @@
 src/nifs/sangria/mod.rs:162-179,253-277), several steps, against the same chain recomputed on the CPU oracle
 (tests/chain_cases.py).  Bit-exact: the digest covers e, the folded instance commitments of both circuits and the last
 witness commitments, and every step's challenges depend on all of the previous step."""
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -14,6 +15,17 @@ def test_cyclefold_chain_digest_vs_oracle(srs, oracle, k, log_key, ks, steps):
     want = CC.oracle_chain(oracle, srs, k, log_key, ks, steps)
     assert CC.product_chain(srs, k, log_key, ks, steps) == want                           # support trace: srs_sangria_prove_incoming
     assert CC.product_chain(srs, k, log_key, ks, steps, split_support=True) == want       # commit, then srs_sangria_prove
+
+
+@pytest.mark.parametrize("k,log_key,steps", [(10, 14, 2), (12, 16, 3)])
+def test_sangria_chain_digest_vs_oracle(srs, oracle, k, log_key, steps):
+    """BASELINE configs[1]'s two-curve chain (bench.py's secondary.sangria_k17 leg: both orders of the step -- resident traces, and
+    witnesses from the host) against the same chain on the oracle: commitments of both curves, cross-term commitments, the Poseidon-derived
+    challenge of every step, the folded instances."""
+    import chain_cases as CC
+    want = CC.oracle_chain_sangria(oracle, srs, k, log_key, steps)
+    assert CC.product_chain_sangria(srs, k, log_key, steps, from_host=False) == want
+    assert CC.product_chain_sangria(srs, k, log_key, steps, from_host=True) == want
 
 
 def test_cyclefold_chain_true_rows_differs(srs, oracle):
@@ -92,3 +104,25 @@ def test_device_sponge_equals_host_sponge(srs):
     to the reference's known answer through the oracle"""
     from test_emu_logic import POSEIDON_DEVICE_CODE
     exec(compile(POSEIDON_DEVICE_CODE.replace("import sirius_amd as S\n", ""), "<device sponge>", "exec"), {"S": srs})
+
+
+def test_device_sponge_vs_oracle(srs, oracle):
+    """srs_poseidon_squeeze_device against oracle/poseidon.py DIRECTLY (not through the host sponge): both fields, the reference's
+    parameter set (T = 5, RATE = 4, R_F = R_P = 10) and two others, buffers around the rate, 128- and 253-bit squeezes."""
+    import random
+    from oracle import poseidon as OP
+    from oracle import pyref as P
+    from sirius_amd.field import MODULUS, ints_to_mont
+    O = oracle
+    for field in (0, 1):
+        for (t, rf, rp) in ((5, 10, 10), (3, 4, 3)):
+            for n in (0, 1, 4, 5, 29):
+                vals = [random.Random(n * 11 + i).randrange(MODULUS[field]) for i in range(n)]
+                h = srs.PoseidonHash(field, t, t - 1, rf, rp)
+                if n:
+                    h.absorb_field(ints_to_mont(field, vals))
+                for bits, of in ((128, field), (253, 1 - field)):
+                    oh = OP.PoseidonHash(P.MODULI[field], t, t - 1, rf, rp)
+                    oh.absorb_field_iter(vals)
+                    got = O.mont_to_ints(of, np.asarray(h.squeeze_device(bits, of)[0]).reshape(1, 4))
+                    assert got == [oh.squeeze(bits) % P.MODULI[of]], (field, t, n, bits)

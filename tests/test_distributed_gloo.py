@@ -217,7 +217,8 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
     jobs = {"r1": (bench + ["--gpus", "1"] + common, env),
             "r2": (bench + ["--gpus", "2", "--dist-backend", "gloo"] + [a for a in common if a != "--no-extras"], env2),
             "r1t": (bench + ["--gpus", "1", "--leaf-rows", "true"] + common, env),
-            "r2t": (bench + ["--gpus", "2", "--dist-backend", "gloo", "--leaf-rows", "true"] + common, env2)}
+            "r2t": (bench + ["--gpus", "2", "--dist-backend", "gloo", "--leaf-rows", "true"] + common, env2),
+            "r3s": (bench + ["--gpus", "3", "--single-process"] + common, env2)}       # one process, multi-device keys of 3 logical shards
     procs = {k: subprocess.Popen(a, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k, (a, e) in jobs.items()}
     res = {}
     for k, p in procs.items():
@@ -230,6 +231,8 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
     assert one["state_digest"] == two["state_digest"]
     assert one["config"]["leaf_rows"] == "compat" and one["config"]["challenges"] == "poseidon-ro"      # the headline configuration
     assert two["secondary"]["microbench_msm_sharded"]["msm_uniform"]["n_gpus"] == 2
+    multi = last_json(res["r3s"][1])
+    assert multi["n_gpus"] == 3 and multi["config"]["parallelism"].startswith("msm-multi3-single-process") and multi["state_digest"] == one["state_digest"]
     # the intended leaf rows shard the same way
     d1, d2 = last_json(res["r1t"][1])["state_digest"], last_json(res["r2t"][1])["state_digest"]
     assert d1 == d2 and d1 != one["state_digest"]

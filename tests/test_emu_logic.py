@@ -369,6 +369,26 @@ def test_emu_chain_digest_vs_oracle():
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_emu_sangria_chain_digest_vs_oracle():
+    """bench.py's two-curve Sangria chain (secondary.sangria_k17's shapes, 2 steps, both step orders) through the emulator == the same
+    chain on the oracle (tests/chain_cases.py::oracle_chain_sangria); the GPU version is tests/test_chain_gpu.py."""
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from sirius_amd import _lib\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "import sirius_amd as S, oracle as O, chain_cases as CC\n"
+        "b = CC.oracle_chain_sangria(O, S, 4, 8, 2)\n"
+        "a = CC.product_chain_sangria(S, 4, 8, 2, from_host=False, emu=True)\n"
+        "assert a == b, (a, b)\n"
+        "c = CC.product_chain_sangria(S, 4, 8, 2, from_host=True, emu=True)\n"
+        "assert c == b, (c, b)\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_sangria_step_merged_commits():
     """bench.py's k=17-shaped Sangria step with resident traces: a trace's commitment in the same batched MSM as the cross terms of the
     prove that folds it (srs_sangria_prove_incoming, W2 resident) == commit, then srs_sangria_prove; Poseidon-derived challenges."""

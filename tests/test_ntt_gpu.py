@@ -102,6 +102,20 @@ def test_ntt_microbench_size_properties(srs, oracle):
     assert np.array_equal(da.cpu().numpy().view(np.uint64), a)             # round trip
 
 
+def test_ntt_config_2p24_vs_oracle(srs, oracle):
+    """BASELINE configs[4]: the 2^24-point transforms compared DIRECTLY with the oracle's restatement of src/fft.rs:160-198 (three passes of
+    2^8: a digit-reversal slip that only shows with three digits would pass every size-independent property but not this).  The OpenMP
+    oracle takes a few seconds per transform."""
+    import torch
+    O = oracle
+    a = _rand(O, 1 << 24, 24)
+    d = torch.from_numpy(a.view(np.int64)).cuda()
+    for fn in FNS:
+        d.copy_(torch.from_numpy(a.view(np.int64)))
+        getattr(srs.fft, fn)(d)
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), getattr(O, fn)(a)), fn
+
+
 def test_ntt_asserts(srs):
     with pytest.raises(srs.fft.NotPowerOfTwo):     # src/fft.rs:161
         srs.fft.fft(np.zeros((12, 4), np.uint64))

@@ -22,7 +22,7 @@ def _oracle_gates(gate_T):
 
 
 @pytest.mark.parametrize("which,k,gate_T", [("primary", 10, [5, 3]), ("secondary", 10, [5]), ("primary", 6, [2]),
-                                            ("secondary", 7, [3, 2, 2]), ("primary", 13, [5, 3])])
+                                            ("secondary", 7, [3, 2, 2]), ("primary", 13, [5, 3]), ("secondary", 13, [5])])
 def test_commit_cross_terms_vs_oracle(srs, oracle, which, k, gate_T):
     O = oracle
     w = make_structure_inputs(which, k, seed=k * 31 + len(gate_T))
