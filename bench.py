@@ -40,7 +40,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 MSM_BYTES_PER_SCALAR = 96.0    # 64 B base + 32 B scalar, each read once
@@ -324,7 +323,7 @@ class PgPrimary:
     def __init__(self, S, D, k, log_key, compat):
         from sirius_amd import protogalaxy as PG
         from sirius_amd.field import FR, ints_to_mont
-        from workloads import make_structure_inputs, trace_like
+        from sirius_amd.workloads import make_structure_inputs, trace_like
         import random
         self.PG, self.compat = PG, compat
         w = make_structure_inputs("primary", k, seed=0x5349524955530000 + 3)
@@ -479,7 +478,7 @@ def cyclefold_step(S, D, pri, sup, ro=False, count=False):
 def build_cyclefold(S, D, k, log_key, compat, ks=15):
     """The state of a CycleFold chain before its first step: primary ProtoGalaxy accumulator + incoming trace (committed), the
     support circuit's Sangria accumulator + incoming trace (committed).  Shared by main() and tests/chain_cases.py."""
-    from workloads import make_support_inputs
+    from sirius_amd.workloads import make_support_inputs
     pri = PgPrimary(S, D, k, log_key, compat)
     sup = SangriaSide(S, D, make_support_inputs(ks, seed=0x5349524955530000 + 4), ks + 2, "support")
     sup.witness_commit(S, D, False)
@@ -526,7 +525,7 @@ def msm_roofline(S, units_note, nz_madds=None, world=1):
     sec = acc0["total_ms"] * 1e-3
     achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / sec / 1e9
     traffic, src = None, None
-    for name in ("r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
+    for name in ("r04_pmc_accum0.json", "r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if world == 1:
@@ -630,7 +629,7 @@ def cpu_baseline_cyclefold(args, pri, sup, compat):
 def extras_sangria(S, D, args, k=17, log_key=21, steps=20, warmup=3):
     """BASELINE configs[1]: one SangriaIVC::fold_step at k = 17, (a) with every operand resident in HBM (r01's line) and
     (b) with the two incoming witnesses coming up from host memory inside the step (what a shim on the Rust side pays)."""
-    from workloads import make_structure_inputs
+    from sirius_amd.workloads import make_structure_inputs
     pri = SangriaSide(S, D, make_structure_inputs("primary", k, seed=0x5349524955530000 + 2), log_key, "primary")
     sec = SangriaSide(S, D, make_structure_inputs("secondary", k, seed=0x5349524955530000 + 3), log_key, "secondary")
     pri.witness_commit(S, D, False)
@@ -667,7 +666,7 @@ def extras_sangria(S, D, args, k=17, log_key=21, steps=20, warmup=3):
 def extras_microbench(S, D, ck24, log_n=24, reps=3):
     """BASELINE configs[4]: 2^24-point MSM (bn256 G1) and 2^24-point NTT (Fr), device resident."""
     import torch
-    from workloads import rand_fe
+    from sirius_amd.workloads import rand_fe
     n = 1 << log_n
     rng = np.random.default_rng(5)
     out = {"workload": f"2^{log_n}-point MSM (bn256 G1) + 2^{log_n}-point NTT (Fr), device-resident (BASELINE configs[4])"}
@@ -707,7 +706,7 @@ def extras_msm_sharded(S, D, ck, log_n, reps=3):
     """BASELINE configs[4] on N ranks: the 2^log_n-point MSM over the SHARDED key -- every rank adds up its block-cyclic stripes of the
     same device-resident vector, the 64-byte partials are all-gathered and summed (inside the timed call).  scalars_per_s at
     N = 1, 2, 4, 8 is the MSM scaling curve of the north star."""
-    from workloads import rand_fe
+    from sirius_amd.workloads import rand_fe
     n = 1 << log_n
     rng = np.random.default_rng(5)                 # the same vector on every rank
     out = {"workload": f"2^{log_n}-point MSM (bn256 G1), key and work sharded over {D.world} ranks, device-resident"}

@@ -106,17 +106,17 @@ struct CkShard {
         }
     }
     void post(std::function<void()> fn) {
-#if defined(SRS_EMU)
-        // the CPU logic emulator keeps one global execution context (tests/emu/hipemu.h): shard jobs run inline, one by one
-        rc = 0;
-        try {
-            fn();
-        } catch (const DeviceError &de) {
-            rc = de.rc;
-            err = get_error();
+        if constexpr (rt::kEmulated) {
+            // the CPU logic emulator keeps one global execution context (tests/emu/hipemu.h): shard jobs run inline, one by one
+            rc = 0;
+            try {
+                fn();
+            } catch (const DeviceError &de) {
+                rc = de.rc;
+                err = get_error();
+            }
+            return;
         }
-        return;
-#endif
         std::lock_guard<std::mutex> lk(mu);
         job = std::move(fn);
         has_job = true;
@@ -291,24 +291,18 @@ void to_affine_batch(int curve, const xyzz_t *in, affine_t *out, size_t n) {
     if (curve == SRS_CURVE_BN256) to_affine_batch_t<Bn256>(in, out, n); else to_affine_batch_t<Grumpkin>(in, out, n);
 }
 
-#if !defined(SRS_EMU)
 bool g_device_ok = false;
 int g_device = -1;        // the one device of this process (one process per GPU); bound by the first srs_init
-#endif
 
 // HIP's current device is per host thread: a caller's worker thread starts on device 0.  Every entry point rebinds the
 // calling thread to the process's device so that handles created on one thread work from any other.
 int ensure_device() {
-#if defined(SRS_EMU)
-    return SRS_OK;
-#else
     if (!g_device_ok) return srs_init(-1);
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != g_device) {
         if (hipSetDevice(g_device) != hipSuccess) return fail(SRS_ERR_DEVICE, "hipSetDevice failed");
     }
     return SRS_OK;
-#endif
 }
 
 // ---- multi-device keys --------------------------------------------------------------------------------------------
@@ -416,10 +410,7 @@ int create_multi(int curve, size_t len, int n_devices, Fill fill, srs_ck **out) 
     if (phys <= 0) return fail(SRS_ERR_DEVICE, "no HIP device visible: libsirius_amd has no CPU path");
     const uint32_t world = n_devices > 0 ? (uint32_t)n_devices : (uint32_t)phys;
     if (world > 64) return fail(SRS_ERR_INVALID, "srs_ck_create_multi: more than 64 shards");
-    int home = 0;
-#if !defined(SRS_EMU)
-    home = g_device;
-#endif
+    const int home = g_device < 0 ? 0 : g_device;
     srs_ck *ck = new srs_ck();
     ck->key.curve = curve;
     ck->key.global_len = len;
@@ -447,12 +438,12 @@ int create_multi(int curve, size_t len, int n_devices, Fill fill, srs_ck **out) 
             }
         }
         SRS_HIP_CHECK(hipSetDevice(home));
-#if !defined(SRS_EMU)
-        for (auto &sp : ck->shards) {
-            CkShard *sh = sp.get();
-            sh->worker = std::thread([sh] { sh->loop(); });
+        if constexpr (!rt::kEmulated) {
+            for (auto &sp : ck->shards) {
+                CkShard *sh = sp.get();
+                sh->worker = std::thread([sh] { sh->loop(); });
+            }
         }
-#endif
     } catch (...) {
         (void)hipSetDevice(home);
         srs_ck_free(ck);
@@ -470,10 +461,6 @@ const char *srs_last_error(void) { return get_error(); }
 const char *srs_version(void) { return "sirius_amd 0.1.0 (gfx950)"; }
 
 int srs_init(int device_ordinal) {
-#if defined(SRS_EMU)
-    (void)device_ordinal;
-    return SRS_OK;
-#else
     return guarded([&]() -> int {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
@@ -482,15 +469,14 @@ int srs_init(int device_ordinal) {
         if (dev < 0) SRS_HIP_CHECK(hipGetDevice(&dev));
         if (dev >= count) return fail(SRS_ERR_INVALID, "device ordinal out of range");
         SRS_HIP_CHECK(hipSetDevice(dev));
-        hipDeviceProp_t prop;
-        SRS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-            return fail(SRS_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+        std::string arch;
+        if (!rt::device_arch(dev, arch)) return fail(SRS_ERR_DEVICE, "hipGetDeviceProperties failed");
+        if (arch.compare(0, 6, "gfx950") != 0)
+            return fail(SRS_ERR_DEVICE, "device is " + arch + ", kernels are built for gfx950 only");
         g_device = dev;
         g_device_ok = true;
         return SRS_OK;
     });
-#endif
 }
 
 int srs_scalar_field_of(int curve) {
@@ -1581,10 +1567,7 @@ size_t srs_structure_num_cross_terms(const srs_structure *S) { return S ? rowpro
 size_t srs_structure_num_challenges(const srs_structure *S) { return S ? rowprog::num_challenges(S->s) : 0; }
 size_t srs_structure_num_witness_columns(const srs_structure *S) { return S ? rowprog::num_witness_columns(S->s) : 0; }
 int srs_jit_selfcheck(size_t *code_bytes, char *log, size_t log_cap) {
-#if defined(SRS_EMU)
-    (void)code_bytes; (void)log; (void)log_cap;
-    return fail(SRS_ERR_INVALID, "srs_jit_selfcheck: not part of the emulator build");
-#else
+    if constexpr (rt::kEmulated) return fail(SRS_ERR_INVALID, "srs_jit_selfcheck: not part of the emulator build");
     std::string text;
     const bool ok = rowprog::jit_selfcheck(code_bytes, text);
     if (log && log_cap) {
@@ -1593,7 +1576,6 @@ int srs_jit_selfcheck(size_t *code_bytes, char *log, size_t log_cap) {
         log[n] = 0;
     }
     return ok ? SRS_OK : fail(SRS_ERR_INVALID, "srs_jit_selfcheck: hiprtc rejected the emitted form: " + text.substr(0, 400));
-#endif
 }
 
 int srs_structure_kernel_kind(const srs_structure *S, int which) {

@@ -23,6 +23,23 @@
 
 namespace srs {
 
+// The ONE place host code learns that it runs on the CPU logic emulator (tests/emu): callers branch on these with `if constexpr`,
+// not with the preprocessor (r04: capi.hip had seven SRS_EMU blocks).
+namespace rt {
+#if defined(SRS_EMU)
+constexpr bool kEmulated = true;      // one global execution context: no per-shard worker threads, no hiprtc, no device properties
+inline bool device_arch(int, std::string &name) { name = "gfx950 (hipemu)"; return true; }
+#else
+constexpr bool kEmulated = false;
+inline bool device_arch(int dev, std::string &name) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    name = prop.gcnArchName;
+    return true;
+}
+#endif
+}  // namespace rt
+
 // thread-local last-error text, surfaced through srs_last_error()
 void set_error(const std::string &msg);
 const char *get_error();

@@ -238,14 +238,21 @@ __device__ __forceinline__ void for_each_digit(const uint16_t *__restrict__ d, u
     for (uint32_t i = lo + threadIdx.x; i < head; i += blockDim.x) fn(i, (uint32_t)d[i]);
     const uint32_t nvec = (hi - head) / 8;
     const uint4 *v = reinterpret_cast<const uint4 *>(d + head);
-    for (uint32_t q = threadIdx.x; q < nvec; q += blockDim.x) {
-        const uint4 x = v[q];
+    auto eight = [&](uint32_t q, const uint4 &x) {
         const uint32_t i0 = head + q * 8;
         fn(i0 + 0, x.x & 0xFFFFu); fn(i0 + 1, x.x >> 16);
         fn(i0 + 2, x.y & 0xFFFFu); fn(i0 + 3, x.y >> 16);
         fn(i0 + 4, x.z & 0xFFFFu); fn(i0 + 5, x.z >> 16);
         fn(i0 + 6, x.w & 0xFFFFu); fn(i0 + 7, x.w >> 16);
+    };
+    // four 16-byte loads in flight per thread (r04: one load per loop round left a workgroup with 16 loads in flight -- the digit streams
+    // of a large chunk took 25 memory latencies per thread)
+    uint32_t q = threadIdx.x;
+    for (; q + 3 * blockDim.x < nvec; q += 4 * blockDim.x) {
+        const uint4 x0 = v[q], x1 = v[q + blockDim.x], x2 = v[q + 2 * blockDim.x], x3 = v[q + 3 * blockDim.x];
+        eight(q, x0); eight(q + blockDim.x, x1); eight(q + 2 * blockDim.x, x2); eight(q + 3 * blockDim.x, x3);
     }
+    for (; q < nvec; q += blockDim.x) eight(q, v[q]);
     for (uint32_t i = head + nvec * 8 + threadIdx.x; i < hi; i += blockDim.x) fn(i, (uint32_t)d[i]);
 }
 
@@ -1065,7 +1072,17 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     const uint32_t t = threadIdx.x, m = blockIdx.x, role = blockIdx.y;
     const uint32_t *cnt = count + (size_t)m * NBUCKET;
     uint32_t *pl = plan + (size_t)m * plan_stride;
-    for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) tile[i + i / PER] = cnt[i];
+    {   // all 32 loads of a thread in flight at once: issued one per loop round they cost a memory latency EACH (the counters were just
+        // written by another XCD's atomics: every load misses this XCD's L2) -- that, not arithmetic, was the 30+ us of this kernel
+        uint32_t c[PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) c[j] = cnt[t + j * PLAN_THREADS];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t i = t + j * PLAN_THREADS;
+            tile[i + i / PER] = c[j];
+        }
+    }
     __syncthreads();
     const uint32_t base = t * PER + t;
     uint32_t local = 0;
@@ -1114,17 +1131,32 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
         }
         run = block_exclusive_scan(local, lds, &total);
     }
-    const uint8_t *up = used_prev + (size_t)m * NBUCKET;
-    uint8_t *un = used_next + (size_t)m * NBUCKET;
-#pragma unroll 4
+    // slots in use after this set: the thread's 32 bytes travel as two 16-byte words (byte loads in the loop cost a memory latency EACH:
+    // that was 25 of this kernel's 33 us)
+    static_assert(PER == 32, "k_plan_s: used[] travels as 2 x uint4 per thread");
+    uint32_t was_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, now_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (dense && !first) {
+        const uint4 *up = reinterpret_cast<const uint4 *>(used_prev + (size_t)m * NBUCKET + (size_t)t * PER);
+        const uint4 a = up[0], b = up[1];
+        was_w[0] = a.x; was_w[1] = a.y; was_w[2] = a.z; was_w[3] = a.w; was_w[4] = b.x; was_w[5] = b.y; was_w[6] = b.z; was_w[7] = b.w;
+    }
+#pragma unroll
     for (uint32_t j = 0; j < PER; ++j) {
         const uint32_t c = tile[base + j], v = value(c);
         tile[base + j] = run;
         run += v;
-        if (dense) {                                             // slots in use after this set
-            const uint32_t now = v < S - 1 ? v : S - 1, was = first ? 0u : (uint32_t)up[t * PER + j];
-            un[t * PER + j] = (uint8_t)(now > was ? now : was);
+        if (dense) {
+            const uint32_t now = v < S - 1 ? v : S - 1, was = (was_w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            now_w[j >> 2] |= (now > was ? now : was) << (8 * (j & 3));
         }
+    }
+    if (dense) {
+        uint4 *un = reinterpret_cast<uint4 *>(used_next + (size_t)m * NBUCKET + (size_t)t * PER);
+        uint4 lo, hi;
+        lo.x = now_w[0]; lo.y = now_w[1]; lo.z = now_w[2]; lo.w = now_w[3];
+        hi.x = now_w[4]; hi.y = now_w[5]; hi.z = now_w[6]; hi.w = now_w[7];
+        un[0] = lo;
+        un[1] = hi;
     }
     __syncthreads();
     uint32_t *o = pl + (size_t)role * (NBUCKET + 1);

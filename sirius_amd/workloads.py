@@ -1,0 +1,83 @@
+"""Synthetic Poseidon-shaped Sangria / CycleFold workloads: what bench.py folds, shared with the tests (tests/workloads.py
+re-exports this module).
+
+A real halo2 trace cannot be produced without the Rust front-end, so shapes follow the reference
+configs: the primary structure is MainGate<5> (step-folding circuit) + MainGate<3> (Poseidon step
+circuit) = 12 advice / 26 fixed columns, 2 gates (benches/sangria_poseidon.rs:28-36,80-81); the
+secondary structure is MainGate<5> alone = 7 advice / 15 fixed, 1 gate.  Values are seeded.
+Product-side only (no oracle import): usable from bench.py's timed leg."""
+import numpy as np
+
+from . import expression as X
+from .field import MODULUS
+
+
+def rand_fe(rng, n, zero_frac=0.0):
+    """(n,4) uint64 values < 2^253 (canonical residues of either field; used as Montgomery bit patterns)."""
+    raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << 61) - 1)
+    if zero_frac:
+        raw[rng.random(n) < zero_frac] = 0
+    return raw
+
+
+def trace_like(rng, n):
+    """SURVEY.md 8d(ii) mixture on the Montgomery bit pattern: 55 % zero, rest random (the cross-term /
+    fold kernels are value-oblivious; MSM skew is exercised through canonical scalars in the commit tests)."""
+    return rand_fe(rng, n, zero_frac=0.55)
+
+
+def sangria_shape(which):
+    if which == "primary":      # bn256 circuit over Fr
+        return dict(field=0, curve=0, gate_T=[5, 3])
+    return dict(field=1, curve=1, gate_T=[5])   # grumpkin circuit over Fq
+
+
+def support_gate(num_selectors=1, num_fixed=4):
+    """The one gate of the CycleFold support circuit (reference src/ivc/cyclefold/support_circuit/tiny_gate.rs:56-82):
+      s * (state0 * state1 * mul + state0 * sum0 + state1 * sum1 + rc - output)
+    1 selector, fixed = (mul, sum0, sum1, rc), advice = (state0, state1, output); k = 15 (support_circuit/mod.rs:68)."""
+    s = X.Polynomial(0)
+    F = lambda i: X.Polynomial(num_selectors + i)
+    A = lambda i: X.Polynomial(num_selectors + num_fixed + i)
+    mul, sum0, sum1, rc = F(0), F(1), F(2), F(3)
+    s0, s1, out = A(0), A(1), A(2)
+    inner = X.Sum(X.Sum(X.Sum(X.Sum(X.Product(X.Product(s0, s1), mul), X.Product(s0, sum0)), X.Product(s1, sum1)), rc), X.Negated(out))
+    return X.Product(s, inner)
+
+
+def make_support_inputs(k, seed):
+    """Synthetic support-circuit structure (grumpkin circuit over Fq): -> dict like make_structure_inputs, plus `selectors`."""
+    rng = np.random.default_rng(seed)
+    rows = 1 << k
+    sel = (rng.random(rows) < 0.8).astype(np.uint8)
+    fixed = [rand_fe(rng, rows, zero_frac=0.5) for _ in range(4)]
+    return dict(field=1, curve=1, k=k, rows=rows, gates=[support_gate()], selectors=[sel], fixed=fixed, num_fixed=4,
+                num_advice=3, W1=trace_like(rng, 3 * rows), W2=trace_like(rng, 3 * rows), E=rand_fe(rng, rows),
+                u1_challenges=rand_fe(rng, 0), u1_u=rand_fe(rng, 1)[0], u2_challenges=rand_fe(rng, 0), r=rand_fe(rng, 1)[0],
+                modulus=MODULUS[1])
+
+
+def gates_for(gate_T):
+    nfix = sum(2 * T + 5 for T in gate_T)
+    nadv = sum(T + 2 for T in gate_T)
+    gates, fo, ao = [], 0, 0
+    for T in gate_T:
+        gates.append(X.main_gate(T, 0, fo, ao, nfix))
+        fo += 2 * T + 5
+        ao += T + 2
+    return gates, nfix, nadv
+
+
+def make_structure_inputs(which, k, seed):
+    """-> dict(field, curve, k, gates, fixed (list of (rows,4)), num_advice, W1, W2, E, challenges...)."""
+    sh = sangria_shape(which)
+    rng = np.random.default_rng(seed)
+    rows = 1 << k
+    gates, nfix, nadv = gates_for(sh["gate_T"])
+    fixed = [rand_fe(rng, rows, zero_frac=0.9 if i % 2 else 0.3) for i in range(nfix)]
+    nch = 1 if len(gates) > 1 else 0
+    return dict(field=sh["field"], curve=sh["curve"], k=k, rows=rows, gates=gates, fixed=fixed, num_fixed=nfix,
+                num_advice=nadv, W1=trace_like(rng, nadv * rows), W2=trace_like(rng, nadv * rows),
+                E=rand_fe(rng, rows), u1_challenges=rand_fe(rng, nch), u1_u=rand_fe(rng, 1)[0],
+                u2_challenges=rand_fe(rng, nch), r=rand_fe(rng, 1)[0], modulus=MODULUS[sh["field"]])
