@@ -36,16 +36,6 @@ constexpr uint32_t SMALL_LOG = 10; // single-workgroup path up to 2^10 points
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// The butterfly multiplier.  M29 = false: field.cuh's 8 x 32-bit CIOS (405 instructions).  M29 = true: the 9 x 29-bit carry-free
-// multiplier of field29.cuh (225 instructions) between an unpack of both operands and a pack + canonicalisation of the product
-// (26 + 26 + 75): the data stay canonical 8 x 32 in LDS and HBM, the TWIDDLE tables are then stored times 2^5 (the radix of that
-// multiplier is 2^261: x 2^256 * w 2^261 / 2^261 = x w 2^256, the ABI form, bit for bit).  A/B switch SRS_NTT_MUL29 (r03).
-template <bool M29>
-__device__ __forceinline__ fe_t tw_mul(const fe_t &x, const fe_t &w) {
-    if constexpr (M29) return Fr29::to_canonical_fe(Fr29::mul(Fr29::unpack(x), Fr29::unpack(w)));
-    else return Fr::mul(x, w);
-}
-
 // T[i] = scale * base^(e(i)),  e(i) = (i >> lo_bits) * (i & (2^lo_bits - 1)) mod 2^m   (m = log2 of table)
 // lo_bits == 0 : plain powers base^i.
 __global__ void k_fill_table(fe_t *__restrict__ T, uint32_t log_entries, uint32_t lo_bits, fe_t base, fe_t scale) {
@@ -80,7 +70,7 @@ __device__ __forceinline__ fe_t apply_scale3(const Scale3 &s, fe_t v, size_t idx
 }
 
 // one DIT butterfly stage over an LDS tile laid out [row][col], rows = 2^rbits
-template <uint32_t NCOLS, bool M29>
+template <uint32_t NCOLS>
 __device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rbits, uint32_t s) {
     const uint32_t half = 1u << s;
     const uint32_t pairs = (1u << (rbits - 1)) * NCOLS;
@@ -91,7 +81,7 @@ __device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rb
         uint32_t hi = lo + half;
         fe_t a = tile[lo * NCOLS + c];
         fe_t b = tile[hi * NCOLS + c];
-        if (j) b = tw_mul<M29>(b, W[j << (rbits - 1 - s)]);
+        if (j) b = Fr::mul(b, W[j << (rbits - 1 - s)]);
         tile[lo * NCOLS + c] = Fr::add(a, b);
         tile[hi * NCOLS + c] = Fr::sub(a, b);
     }
@@ -99,7 +89,7 @@ __device__ __forceinline__ void lds_stage(fe_t *tile, const fe_t *W, uint32_t rb
 
 // two DIT stages (s, s + 1) in one LDS round trip: a thread owns the 4 elements base + {0, 1, 2, 3} * 2^s of a radix-4
 // group -- the same 4 twiddle multiplications as two radix-2 stages, half the LDS traffic and half the barriers
-template <uint32_t NCOLS, bool M29>
+template <uint32_t NCOLS>
 __device__ __forceinline__ void lds_stage2(fe_t *tile, const fe_t *W, uint32_t rbits, uint32_t s) {
     const uint32_t h = 1u << s;
     const uint32_t groups = (1u << (rbits - 2)) * NCOLS;
@@ -111,12 +101,12 @@ __device__ __forceinline__ void lds_stage2(fe_t *tile, const fe_t *W, uint32_t r
         fe_t e2 = tile[(base + 2 * h) * NCOLS + c], e3 = tile[(base + 3 * h) * NCOLS + c];
         if (j) {                                                   // stage s: pairs (0,1) and (2,3), twiddle w^(j 2^(r-1-s))
             const fe_t t1 = W[j << (rbits - 1 - s)];
-            e1 = tw_mul<M29>(e1, t1);
-            e3 = tw_mul<M29>(e3, t1);
+            e1 = Fr::mul(e1, t1);
+            e3 = Fr::mul(e3, t1);
         }
         fe_t a0 = Fr::add(e0, e1), a1 = Fr::sub(e0, e1), a2 = Fr::add(e2, e3), a3 = Fr::sub(e2, e3);
-        if (j) a2 = tw_mul<M29>(a2, W[j << (rbits - 2 - s)]);      // stage s + 1: pairs (0,2) and (1,3)
-        a3 = tw_mul<M29>(a3, W[(j + h) << (rbits - 2 - s)]);
+        if (j) a2 = Fr::mul(a2, W[j << (rbits - 2 - s)]);      // stage s + 1: pairs (0,2) and (1,3)
+        a3 = Fr::mul(a3, W[(j + h) << (rbits - 2 - s)]);
         tile[base * NCOLS + c] = Fr::add(a0, a2);
         tile[(base + 2 * h) * NCOLS + c] = Fr::sub(a0, a2);
         tile[(base + h) * NCOLS + c] = Fr::add(a1, a3);
@@ -125,15 +115,15 @@ __device__ __forceinline__ void lds_stage2(fe_t *tile, const fe_t *W, uint32_t r
 }
 
 // all `rbits` stages of a tile
-template <uint32_t NCOLS, bool M29 = false>
+template <uint32_t NCOLS>
 __device__ __forceinline__ void lds_stages(fe_t *tile, const fe_t *W, uint32_t rbits) {
     uint32_t s = 0;
     for (; s + 1 < rbits; s += 2) {
-        lds_stage2<NCOLS, M29>(tile, W, rbits, s);
+        lds_stage2<NCOLS>(tile, W, rbits, s);
         __syncthreads();
     }
     if (s < rbits) {
-        lds_stage<NCOLS, M29>(tile, W, rbits, s);
+        lds_stage<NCOLS>(tile, W, rbits, s);
         __syncthreads();
     }
 }
@@ -172,7 +162,7 @@ struct PassArgs {
 };
 
 // non-final pass: tile = (hi, 16 consecutive `rest`), in place, times inter-digit twiddle T
-template <uint32_t RBITS, bool M29>
+template <uint32_t RBITS>
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_ntt_pass(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg,
                const fe_t *__restrict__ T, Scale3 pre) {
@@ -192,18 +182,18 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     }
     for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
     __syncthreads();
-    lds_stages<COLS, M29>(tile, W, RBITS);
+    lds_stages<COLS>(tile, W, RBITS);
     for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
         uint32_t kd = e / COLS, c = e % COLS;
         size_t tidx = ((size_t)kd << pa.lbits) + rest0 + c;      // T[k_j][rest]
-        fe_t x = tw_mul<M29>(tile[e], T[tidx]);
+        fe_t x = Fr::mul(tile[e], T[tidx]);
         dst[base + ((size_t)kd << pa.lbits) + c] = x;
     }
 }
 
 // final pass: tile = 16 consecutive k1 (most significant memory digit) x one contiguous run;
 // output index = digit reversal  k1 + N1*(k2 + N2*(...)) + (N1..N_{p-1}) * k_p
-template <uint32_t RBITS, bool M29>
+template <uint32_t RBITS>
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_ntt_last(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg, Scale3 fin) {
     __shared__ fe_t tile[(1u << RBITS) * COLS];
@@ -241,13 +231,194 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     }
     for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
     __syncthreads();
-    lds_stages<COLS, M29>(tile, W, RBITS);
+    lds_stages<COLS>(tile, W, RBITS);
     for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
         uint32_t kp = e / COLS, c = e % COLS;
         size_t oidx = (size_t)(k1_0 + c) + ((size_t)out_mid << r1) + ((size_t)kp << (pa.log_n - RBITS));
         fe_t x = tile[e];
         if (fin.on) x = apply_scale3(fin, x, oidx);
         dst[oidx] = x;
+    }
+}
+
+// ---- the multi-pass kernels with the TILE ITSELF in the lazy 9 x 29-bit form (r04) --------------------------------------------------------
+// r03 measured the 29-bit multiplier with canonical 8 x 32 data in LDS: every product paid an unpack of both operands and a pack +
+// canonicalisation of the result (26 + 26 + 75 instructions for the 180 it saves) -- no gain.  Here an element is unpacked ONCE when the
+// tile is loaded, lives in LDS as 9 words, goes through all stages with LAZY additions (no modular reduction: limbs are carry-normalised
+// once per radix-4 group, values grow as bounded multiples of p) and is packed once, after its closing product -- the inter-digit
+// twiddle, or a product with the radix' one in the last pass (which also carries ifft's / the coset's scaling when there is one).
+// Twiddle tables are stored times 2^5 (plan.mul29), so x 2^256 * w 2^261 / 2^261 = x w 2^256: the ABI form, bit for bit.
+//
+// Bounds (P = modulus; the multiplier takes one operand with limbs < 2^31 and value A with A * B < 2^261 P ~ 169 P^2, and returns
+// < A B / 2^261 + P; a twiddle is < P with limbs < 2^29).  V_k = bound of a tile value, in units of P, entering radix-4 group k:
+//   V_0 = 1 (canonical input), V_1 = 7, V_{k+1} = 4 V_k + 1  ->  29, 117, 469 after the 4th group;  a single trailing stage: 2 V + 1.
+//   Inside a group every subtraction a - b adds (bound of b, + 1) * P, so nothing goes negative; products see A <= 2 V + 1 <= 235 and
+//   return < 2.4 P.  The closing product sees A <= 469: result < 469 / 169 P + P < 3.8 P, which to_canonical_fe (< 4 P) takes.
+//   Limbs: normalised (< 2^29, top limb < 2^31) at group boundaries; inside a group <= 2^29 + 2^30 + 2^30 < 2^32.
+struct lazy {
+    static constexpr uint32_t bound(uint32_t k) { return k == 0 ? 1u : (k == 1 ? 7u : 4u * bound(k - 1) + 1u); }
+    SRS_D static f29_t get(const uint32_t *tile, uint32_t e) {
+        f29_t x;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) x.v[l] = tile[e * 9 + l];
+        return x;
+    }
+    SRS_D static void put(uint32_t *tile, uint32_t e, const f29_t &x) {
+#pragma unroll
+        for (int l = 0; l < 9; ++l) tile[e * 9 + l] = x.v[l];
+    }
+};
+
+// radix-4 group number K of a tile (stages 2 K and 2 K + 1), one group per thread and round
+template <uint32_t NCOLS, uint32_t K>
+__device__ __forceinline__ void lazy_stage2(uint32_t *tile, const uint32_t *W, uint32_t rbits) {
+    using F = Fr29;
+    constexpr uint32_t V = lazy::bound(K);
+    const uint32_t s = 2 * K, h = 1u << s;
+    const uint32_t groups = (1u << (rbits - 2)) * NCOLS;
+    for (uint32_t p = threadIdx.x; p < groups; p += blockDim.x) {
+        const uint32_t c = p % NCOLS, g = p / NCOLS;
+        const uint32_t j = g & (h - 1);
+        const uint32_t base = ((g >> s) << (s + 2)) | j;
+        const uint32_t i0 = base * NCOLS + c, i1 = (base + h) * NCOLS + c, i2 = (base + 2 * h) * NCOLS + c, i3 = (base + 3 * h) * NCOLS + c;
+        f29_t e0 = lazy::get(tile, i0), e1 = lazy::get(tile, i1), e2 = lazy::get(tile, i2), e3 = lazy::get(tile, i3);     // < V, normalised
+        if (K > 0 && j) {                                          // stage s: pairs (0,1) and (2,3), twiddle w^(j 2^(r-1-s))
+            const f29_t t1 = lazy::get(W, j << (rbits - 1 - s));
+            e1 = F::mul(e1, t1);                                   // < 2.4
+            e3 = F::mul(e3, t1);
+        }
+        // subtrahends < max(V, 2.4): + (V + 1) P for K > 0, + 2 P for K = 0 (V = 1, no product)
+        constexpr uint32_t CA = K == 0 ? 2u : V + 1u;
+        const f29_t a0 = F::add_lazy(e0, e1), a1 = F::template sub_lazy<CA, 0>(e0, e1);          // < 2 V, < 2 V + 1; limbs < 2^30, < 2^30.6
+        f29_t a2 = F::add_lazy(e2, e3), a3 = F::template sub_lazy<CA, 0>(e2, e3);
+        // stage s + 1: pairs (0,2) and (1,3)
+        a3 = F::mul(a3, lazy::get(W, (j + h) << (rbits - 2 - s)));                               // < 2.4, normalised
+        f29_t o0, o1, o2, o3;
+        if (K > 0 && j) {
+            a2 = F::mul(a2, lazy::get(W, j << (rbits - 2 - s)));                                 // < 2.4
+            o0 = F::add_lazy(a0, a2);
+            o2 = F::template sub_lazy<3, 0>(a0, a2);
+        } else {                                                   // a2 < 2 V, limbs < 2^30
+            o0 = F::add_lazy(a0, a2);
+            o2 = F::template sub_lazy<2 * V + 1, 1>(a0, a2);       // < 4 V + 1
+        }
+        o1 = F::add_lazy(a1, a3);
+        o3 = F::template sub_lazy<3, 0>(a1, a3);                   // < 2 V + 4
+        lazy::put(tile, i0, F::normalize(o0));
+        lazy::put(tile, i2, F::normalize(o2));
+        lazy::put(tile, i1, F::normalize(o1));
+        lazy::put(tile, i3, F::normalize(o3));
+    }
+}
+// a single trailing stage s (odd digit widths), input bound V = lazy::bound(K)
+template <uint32_t NCOLS, uint32_t K>
+__device__ __forceinline__ void lazy_stage1(uint32_t *tile, const uint32_t *W, uint32_t rbits) {
+    using F = Fr29;
+    constexpr uint32_t V = lazy::bound(K);
+    const uint32_t s = 2 * K, half = 1u << s;
+    const uint32_t pairs = (1u << (rbits - 1)) * NCOLS;
+    for (uint32_t p = threadIdx.x; p < pairs; p += blockDim.x) {
+        const uint32_t c = p % NCOLS, q = p / NCOLS;
+        const uint32_t j = q & (half - 1);
+        const uint32_t lo = ((q >> s) << (s + 1)) | j, hi = lo + half;
+        const f29_t a = lazy::get(tile, lo * NCOLS + c);
+        f29_t b = lazy::get(tile, hi * NCOLS + c);
+        if (j) b = F::mul(b, lazy::get(W, j << (rbits - 1 - s)));
+        lazy::put(tile, lo * NCOLS + c, F::normalize(F::add_lazy(a, b)));
+        lazy::put(tile, hi * NCOLS + c, F::normalize(F::template sub_lazy<V + 1, 0>(a, b)));
+    }
+}
+template <uint32_t NCOLS, uint32_t RBITS>
+__device__ __forceinline__ void lazy_stages(uint32_t *tile, const uint32_t *W) {
+    static_assert(RBITS >= 4 && RBITS <= 8, "digit widths");
+    lazy_stage2<NCOLS, 0>(tile, W, RBITS);
+    __syncthreads();
+    lazy_stage2<NCOLS, 1>(tile, W, RBITS);
+    __syncthreads();
+    if constexpr (RBITS >= 6) {
+        lazy_stage2<NCOLS, 2>(tile, W, RBITS);
+        __syncthreads();
+    }
+    if constexpr (RBITS >= 8) {
+        lazy_stage2<NCOLS, 3>(tile, W, RBITS);
+        __syncthreads();
+    }
+    if constexpr (RBITS & 1) {
+        lazy_stage1<NCOLS, RBITS / 2>(tile, W, RBITS);
+        __syncthreads();
+    }
+}
+
+template <uint32_t RBITS>
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_ntt_pass_lazy(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg,
+                    const fe_t *__restrict__ T, Scale3 pre) {
+    __shared__ uint32_t tile[(1u << RBITS) * COLS * 9];
+    __shared__ uint32_t W[(1u << (RBITS - 1)) * 9];
+    const uint32_t rows = 1u << RBITS;
+    const uint32_t tiles_per_hi = 1u << (pa.lbits - COLS_LOG);
+    const size_t hi = blockIdx.x / tiles_per_hi;
+    const uint32_t rest0 = (blockIdx.x % tiles_per_hi) * COLS;
+    const size_t base = (hi << (RBITS + pa.lbits)) + rest0;
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t d = e / COLS, c = e % COLS;
+        size_t idx = base + ((size_t)d << pa.lbits) + c;
+        fe_t x = src[idx];
+        if (pre.on) x = apply_scale3(pre, x, idx);
+        lazy::put(tile, bitrev(d, RBITS) * COLS + c, Fr29::unpack(x));
+    }
+    for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) lazy::put(W, i, Fr29::unpack(Wg[i]));
+    __syncthreads();
+    lazy_stages<COLS, RBITS>(tile, W);
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t kd = e / COLS, c = e % COLS;
+        size_t tidx = ((size_t)kd << pa.lbits) + rest0 + c;      // T[k_j][rest]
+        dst[base + ((size_t)kd << pa.lbits) + c] = Fr29::to_canonical_fe(Fr29::mul(lazy::get(tile, e), Fr29::unpack(T[tidx])));
+    }
+}
+
+template <uint32_t RBITS>
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_ntt_last_lazy(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg, Scale3 fin, fe_t one29) {
+    __shared__ uint32_t tile[(1u << RBITS) * COLS * 9];
+    __shared__ uint32_t W[(1u << (RBITS - 1)) * 9];
+    const uint32_t rows = 1u << RBITS;
+    const uint32_t r1 = pa.radix_bits[0];
+    const uint32_t mid_bits = pa.log_n - r1 - RBITS;              // digits 2..p-1
+    const uint32_t mid = blockIdx.x & ((1u << mid_bits) - 1);
+    const uint32_t k1_0 = (blockIdx.x >> mid_bits) * COLS;
+    uint32_t out_mid = 0;                                         // digit-reverse `mid` (see k_ntt_last)
+    {
+        uint32_t m = mid;
+        uint32_t widths[2], nd = 0, off_of[2];
+        for (uint32_t j = pa.npass - 1; j >= 2; --j) widths[nd++] = pa.radix_bits[j - 1];
+        for (uint32_t t = 0; t < nd; ++t) {
+            uint32_t j = pa.npass - 1 - t, off = 0;
+            for (uint32_t q = 2; q < j; ++q) off += pa.radix_bits[q - 1];
+            off_of[t] = off;
+        }
+        for (uint32_t t = 0; t < nd; ++t) {
+            uint32_t dg = m & ((1u << widths[t]) - 1);
+            m >>= widths[t];
+            out_mid |= dg << off_of[t];
+        }
+    }
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t c = e / rows, i = e % rows;
+        size_t idx = ((size_t)(k1_0 + c) << (pa.log_n - r1)) + ((size_t)mid << RBITS) + i;
+        lazy::put(tile, bitrev(i, RBITS) * COLS + c, Fr29::unpack(src[idx]));
+    }
+    for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) lazy::put(W, i, Fr29::unpack(Wg[i]));
+    __syncthreads();
+    lazy_stages<COLS, RBITS>(tile, W);
+    // the closing product: with the radix' one (2^261 mod p: x 2^256 * 2^261 / 2^261 = x 2^256), or -- coset_ifft -- with zeta^-(i mod 3) * 2^5
+    const f29_t one = Fr29::unpack(one29), z1 = Fr29::unpack(fin.z1), z2 = Fr29::unpack(fin.z2);
+    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
+        uint32_t kp = e / COLS, c = e % COLS;
+        size_t oidx = (size_t)(k1_0 + c) + ((size_t)out_mid << r1) + ((size_t)kp << (pa.log_n - RBITS));
+        const uint32_t r3 = fin.on ? (uint32_t)(oidx % 3) : 0u;
+        const f29_t m = r3 == 1 ? z1 : (r3 == 2 ? z2 : one);
+        dst[oidx] = Fr29::to_canonical_fe(Fr29::mul(lazy::get(tile, e), m));
     }
 }
 
@@ -300,13 +471,16 @@ struct Plan {
     fe_t scale;                                          // n^-1 for ifft (small path only)
     fe_t *scratch = nullptr;                             // n elements (multi-pass ping buffer)
     hipEvent_t done = nullptr;                           // recorded behind the last transform that used `scratch` (see run)
+    fe_t unit;                                           // the tables' common factor in Montgomery form: 1, or 2^5 (mul29)
 };
 
 static std::mutex g_mu;
 static uint32_t g_max_radix = 8;   // tuning knob (4..8): digits per pass; never changes results
 static std::map<std::pair<uint32_t, bool>, Plan> g_plans;
+// r04: multi-pass transforms run on the lazy 9 x 29-bit tile (k_ntt_pass_lazy / k_ntt_last_lazy) -- 2^24: fft 2.33 vs 2.65 ms, ifft 2.21 vs
+// 2.47, coset_ifft 2.12 vs 2.62; 2^20: 0.167 vs 0.201 (profiles/r04_ab_ntt_lazy_tile.txt).  SRS_NTT_MUL29=0: the canonical 8 x 32 tile.
 static bool use_mul29() {
-    static const bool on = [] { const char *e = std::getenv("SRS_NTT_MUL29"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char *e = std::getenv("SRS_NTT_MUL29"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -345,9 +519,10 @@ static Plan &get_plan(uint32_t log_n, bool inverse, hipStream_t st) {
             if (r < 4) { set_error("ntt: digit narrower than 4 bits (raise max radix)"); throw DeviceError{4}; }
         }
         p.mul29 = use_mul29();
-        fe_t unit = Fr::one();              // the tables' common factor: 1, or 2^5 for the 2^261-radix multiplier (tw_mul)
+        fe_t unit = Fr::one();              // the tables' common factor: 1, or 2^5 for the 2^261-radix multiplier (lazy tile)
         if (p.mul29)
             for (int d = 0; d < 5; ++d) unit = Fr::add(unit, unit);
+        p.unit = unit;
         uint32_t below = log_n;
         for (uint32_t j = 0; j < p.npass; ++j) {
             uint32_t r = p.radix_bits[j];
@@ -404,16 +579,25 @@ static void launch_pass(const fe_t *src, fe_t *dst, const PassArgs &pa, const Pl
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = pass_threads((1u << R) * COLS);
-    if (p.mul29) SRS_LAUNCH((k_ntt_pass<R, true>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
-    else SRS_LAUNCH((k_ntt_pass<R, false>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
+    if (p.mul29) SRS_LAUNCH((k_ntt_pass_lazy<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
+    else SRS_LAUNCH((k_ntt_pass<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
 }
 template <uint32_t R>
 static void launch_last(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &fin,
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = pass_threads((1u << R) * COLS);
-    if (p.mul29) SRS_LAUNCH((k_ntt_last<R, true>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
-    else SRS_LAUNCH((k_ntt_last<R, false>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
+    if (p.mul29) {
+        // the closing product's constants in the multiplier's radix: one = 2^261 mod p, the coset factors times 2^5
+        Scale3 f29 = fin;
+        if (fin.on) {
+            f29.z1 = Fr::mul(fin.z1, p.unit);
+            f29.z2 = Fr::mul(fin.z2, p.unit);
+        }
+        SRS_LAUNCH((k_ntt_last_lazy<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], f29, p.unit);
+    } else {
+        SRS_LAUNCH((k_ntt_last<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
+    }
 }
 #define DISPATCH_R(fn, r, ...)                          \
     switch (r) {                                        \

@@ -55,6 +55,29 @@ def test_emu_ntt(emu, oracle):
             assert np.array_equal(getattr(emu.fft, fn)(a.copy()), getattr(O, fn)(a)), (k, fn)
 
 
+def test_emu_ntt_lazy_tile_extremes(emu, oracle):
+    """The multi-pass kernels on the lazy 9 x 29-bit tile (the default since r04): every digit split the plans produce up to 2^16 (widths
+    4..8, odd widths take the single trailing stage), with inputs that drive the lazy bounds -- every element the largest canonical bit
+    pattern p - 1, and alternating -- against the oracle, all four transforms."""
+    O = oracle
+    from oracle import pyref as P
+    rng = np.random.default_rng(2)
+    pm1 = np.array([[((P.MODULI[0] - 1) >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]], dtype=np.uint64)
+    for k in (11, 12, 14, 15, 16):
+        raw = rng.integers(0, 1 << 63, size=(1 << k, 4), dtype=np.uint64)
+        raw[:, 3] &= np.uint64((1 << 60) - 1)
+        a = O.to_mont(O.FR, raw)
+        cases = [a]
+        if k in (12, 16):
+            cases.append(np.repeat(pm1, 1 << k, axis=0))
+            z = a.copy()
+            z[::2] = pm1
+            cases.append(z)
+        for ci, x in enumerate(cases):
+            for fn in ("fft", "ifft", "coset_fft", "coset_ifft"):
+                assert np.array_equal(getattr(emu.fft, fn)(x.copy()), getattr(O, fn)(x)), (k, ci, fn)
+
+
 def test_emu_cross_terms(emu, oracle):
     O = oracle
     from oracle import expr as OE
