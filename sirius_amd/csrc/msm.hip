@@ -1243,16 +1243,18 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     xyzz29_t acc = E29::identity();
     if (s < e) {
         uint32_t v = src[s];
+        uint32_t vn = s + 1 < e ? src[s + 1] : 0u;
         affine_t p = table[v & 0x7FFFFFFFu];
         for (uint32_t j = s; j < e; ++j) {
-            uint32_t vn = 0;
+            uint32_t vnn = 0;             // the next point and the index after it travel behind the addition (see k_accum0s)
             affine_t pn = p;
-            if (j + 1 < e) {              // prefetch the next gathered point behind the add
-                vn = src[j + 1];
+            if (j + 1 < e) {
                 pn = table[vn & 0x7FFFFFFFu];
+                if (j + 2 < e) vnn = src[j + 2];
             }
             acc = E29::madd_signed(acc, E29::load_raw(p), (v >> 31) != 0);
             v = vn;
+            vn = vnn;
             p = pn;
         }
     }
@@ -1406,17 +1408,21 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     xyzz_t *slot = regular ? slots + ((size_t)m * NBUCKET + b) * S + part : ovf + (size_t)m * ovf_stride + tpo[b] + (part - (S - 1));
     xyzz29_t acc = E29::identity();
     uint32_t v = src[s];                                   // a part is never empty: s < e
+    uint32_t vn = s + 1 < e ? src[s + 1] : 0u;
     affine_t p = table[v & 0x7FFFFFFFu];
     if (regular && !first && part < (uint32_t)used_prev[(size_t)m * NBUCKET + b]) acc = E29::unpack(*slot);
     for (uint32_t j = s; j < e; ++j) {
-        uint32_t vn = 0;
+        // behind the addition: the NEXT gathered point (its index arrived an addition ago) and the index after it.  r04: with the index
+        // loaded in the same round as the gather it addresses, every round parked the wave for a memory latency (SQ_WAIT_ANY 23 %)
+        uint32_t vnn = 0;
         affine_t pn = p;
-        if (j + 1 < e) {                  // prefetch the next gathered point behind the add
-            vn = src[j + 1];
+        if (j + 1 < e) {
             pn = table[vn & 0x7FFFFFFFu];
+            if (j + 2 < e) vnn = src[j + 2];
         }
         acc = E29::madd_signed(acc, E29::load_raw(p), (v >> 31) != 0);
         v = vn;
+        vn = vnn;
         p = pn;
     }
     *slot = E29::pack(acc);

@@ -142,6 +142,11 @@ struct PgArgs {
     fe_t *partial;            // [n_gates * tiles_per_gate][P]
     uint32_t shard_rank, shard_world;   // process-per-GPU runs (set_shard): a 1024-leaf tile IS a key stripe (ROW_STRIPE_LOG), this rank
                               //   evaluates the tiles t % world == rank and leaves zeros for the others: its result is a PARTIAL sum
+    // reference leaf rows (compat): every leaf of a gate is that gate AT ROW 0 -- one value per (gate, point) for the whole launch.  r03 shared it
+    // among the 8 leaves of a thread; r04 hoists it out of the leaf pass: a one-workgroup launch (hoist_mode 1) evaluates the gates and leaves
+    // hoist[gate * P + p], the leaf launch (hoist_mode 2) reads it -- every leaf still enters the tree with its own weight.  0: evaluate per thread.
+    fe_t *hoist;
+    int hoist_mode;
 };
 __device__ __forceinline__ bool pg_tile_is_mine(const PgArgs &A, uint32_t tile) {
     return A.shard_world <= 1 || tile % A.shard_world == A.shard_rank;
@@ -249,7 +254,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     SRS_SWEEP_ACC(acc_all);                                 // sweep_smem_bytes(P) of dynamic LDS
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    if (!pg_tile_is_mine(A, tile)) { pg_zero_partial(A, gate, tile); return; }
+    if (!(COMPAT && A.hoist_mode == 1) && !pg_tile_is_mine(A, tile)) { pg_zero_partial(A, gate, tile); return; }
     const GateProg G = A.gates[gate];
     const uint32_t TL = A.tile_log - LPT_LOG;
     const uint32_t row0 = (tile << A.tile_log) + tid;
@@ -259,7 +264,22 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 2) k_pg_leaves_sweep(PgArgs A) {
     if constexpr (COMPAT) {
         // the reference's leaf rows (`index & 2^k`, src/plonk/mod.rs:714): the LPT leaves of a thread all sit at row 0 of this gate,
         // so they share ONE gate evaluation f(X_p); sum_l w_l f = (sum_l w_l) f exactly -- table LPT holds the term coefficients
-        // times the sum of the thread's leaf weights (pg_sum)
+        // times the sum of the thread's leaf weights (pg_sum).  The value is the same for every thread of every tile: hoisted (PgArgs::hoist)
+        if (A.hoist_mode == 2) {                                // the leaf launch: the hoisted values, then the trees
+            for (uint32_t p = 0; p < A.P; ++p) {
+                weighted_tree<F>(red, A.hoist[(size_t)gate * A.P + p], A.weights, A.wpts, TL);
+                if (tid == 0) A.partial[((size_t)gate * gridDim.x + tile) * A.P + p] = red[0];
+                __syncthreads();
+            }
+            return;
+        }
+        if (A.hoist_mode == 1) {                                // the hoisting launch, grid = (P, gates): workgroup p evaluates point p alone
+            RowCtx c = A.ctx;                                   // (the points are independent: P short chains side by side instead of one long one)
+            c.pt0 += tile;
+            PgSpecCall<F, ID>::sweep(gate, c, 0u, 1u, U0 + ((size_t)LPT * A.P + tile) * G.n_uniform, G.n_uniform, acc, false);
+            if (tid == 0) A.hoist[(size_t)gate * A.P + tile] = sw_finish<F>(acc, 0, one261);
+            return;
+        }
         PgSpecCall<F, ID>::sweep(gate, A.ctx, 0u, A.P, U0 + (size_t)LPT * A.P * G.n_uniform, G.n_uniform, acc, false);
     } else {
         for (uint32_t l = 0; l < LPT; ++l) {
@@ -290,7 +310,7 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
     __shared__ fe_t slots[NSLOT * RP_THREADS];
     constexpr uint32_t LPT = 8, LPT_LOG = 3;
     const uint32_t gate = blockIdx.y, tile = blockIdx.x;
-    if (!pg_tile_is_mine(A, tile)) {                       // another rank's tile: zero cubic
+    if (!(A.compat && A.hoist_mode == 1) && !pg_tile_is_mine(A, tile)) {          // another rank's tile: zero cubic
         const uint32_t node = (gate * gridDim.x + tile) * blockDim.x + threadIdx.x;
         for (uint32_t m = 0; m < 4; ++m) nodes[(size_t)m * n_nodes + node] = F::zero();
         return;
@@ -305,6 +325,10 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
             v[l] = v[0];
             continue;
         }
+        if (A.compat && A.hoist_mode == 2) {               // ... evaluated once per launch (PgArgs::hoist)
+            v[0] = A.hoist[gate];
+            continue;
+        }
         const uint32_t row = A.compat ? 0u : row0 + (l << TL);
         if constexpr (ID >= 0) {                           // sweep form with one point: the 9 x 29-bit multiplier
             using PC = PgSpecCall<F, (ID >= 0 ? ID : 0)>;
@@ -313,6 +337,10 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_F_leaves(PgArgs A, PgFLeve
             v[l] = sw_finish<F>(acc, 0, (A.utab + G.utab_off)[PC::one(gate)]);
         } else {
             v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, row, 0, A.utab + G.utab_off);
+        }
+        if (A.compat && A.hoist_mode == 1) {               // the one-workgroup launch: the gate at row 0, nothing else
+            if (threadIdx.x == 0) A.hoist[gate] = v[0];
+            return;
         }
     }
     fe_t c0[4], c1[4];                                     // bit TL: (v0 + v1 (beta + X delta))
@@ -2248,6 +2276,12 @@ static void launch_pg_leaves(const PgArgs &A, uint32_t tiles, uint32_t gates, ui
 // mode 0: compute_F, 1: compute_G, 2: evaluate_e.  W_dev: J device witness pointers (J = 1 for F / e).
 // challenges_host: J arrays of n_ch challenges.  weights_in: betas (F, e) / betas_stroke (G), betas_count values.
 // out_host: points_F / points_G coefficients (after ifft) or the single value e.
+// SRS_PG_NO_HOIST=1: the reference's leaf rows evaluated per thread again (r03), for A/B and the equality test
+static bool pg_hoist_on() {
+    static const bool on = [] { const char *e = std::getenv("SRS_PG_NO_HOIST"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
            const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
            size_t *n_out, std::string &err, const fe_t *g_at_one) {
@@ -2363,11 +2397,12 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         const size_t n0 = n_tiles_padded * T;
         Arena &A = S->arena;
         A.reserve(2 * Arena::pad((4 * n0 + 64) * sizeof(fe_t)) + Arena::pad((utab.size() + 1) * sizeof(fe_t)) +
-                  Arena::pad(gp.size() * sizeof(GateProg)) + 4096);
+                  Arena::pad(gp.size() * sizeof(GateProg)) + Arena::pad((n_gates + 1) * sizeof(fe_t)) + 4096);
         A.reset();
         fe_t *d_utab = A.take<fe_t>(utab.size() + 1);
         GateProg *d_gp = A.take<GateProg>(gp.size());
         fe_t *cur = A.take<fe_t>(4 * n0 + 64), *nxt = A.take<fe_t>(4 * n0 + 64);
+        fe_t *d_hoist = A.take<fe_t>(n_gates + 1);
         SRS_HIP_CHECK(hipMemcpyAsync(d_utab, utab.data(), utab.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
         SRS_HIP_CHECK(hipMemcpyAsync(d_gp, gp.data(), gp.size() * sizeof(GateProg), hipMemcpyHostToDevice, st));
         std::vector<fe_t> deltas(levels);
@@ -2400,14 +2435,24 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         a.partial = nullptr;
         a.shard_rank = S->shard_rank;                      // lpt == 8 here: tile_log == ROW_STRIPE_LOG
         a.shard_world = S->shard_world;
+        a.hoist = d_hoist;
+        a.hoist_mode = 0;
         PgFLevels lv;
         for (uint32_t j = 0; j < 3; ++j) { lv.beta[j] = weights_in[TL + j]; lv.delta[j] = deltas[TL + j]; }
         {
             prof::Scope ps("pg_F_leaves", st, S->rows * n_gates);
-            if (S->pg_spec_id == 0) SRS_LAUNCH((k_pg_F_leaves<Fr, 2, 0>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
-            else if (max_slots <= 8) SRS_LAUNCH((k_pg_F_leaves<Fr, 8, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
-            else if (max_slots <= 16) SRS_LAUNCH((k_pg_F_leaves<Fr, 16, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
-            else SRS_LAUNCH((k_pg_F_leaves<Fr, 32, -1>), (tiles_per_gate, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+            auto leaves = [&](uint32_t tiles) {
+                if (S->pg_spec_id == 0) SRS_LAUNCH((k_pg_F_leaves<Fr, 2, 0>), (tiles, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+                else if (max_slots <= 8) SRS_LAUNCH((k_pg_F_leaves<Fr, 8, -1>), (tiles, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+                else if (max_slots <= 16) SRS_LAUNCH((k_pg_F_leaves<Fr, 16, -1>), (tiles, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+                else SRS_LAUNCH((k_pg_F_leaves<Fr, 32, -1>), (tiles, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
+            };
+            if (compat && pg_hoist_on()) {                 // the gates at row 0 once, then the leaf pass reads them
+                a.hoist_mode = 1;
+                leaves(1);
+                a.hoist_mode = 2;
+            }
+            leaves(tiles_per_gate);
         }
         // remaining leaf-index bits, in the order adjacent nodes differ: thread bits 0 .. TL-1, then tile / gate bits TL+3 ..
         std::vector<uint32_t> order;
@@ -2454,7 +2499,8 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     Arena &A = S->arena;
     size_t need = Arena::pad(weights.size() * sizeof(fe_t)) + Arena::pad((wcoef.size() + 1) * sizeof(fe_t)) +
                   Arena::pad((utab.size() + 1) * sizeof(fe_t)) + Arena::pad(gp.size() * sizeof(GateProg)) +
-                  2 * Arena::pad((n_tiles_padded + 1) * P * sizeof(fe_t)) + Arena::pad(sizeof(fe_t) * P) + 4096;
+                  2 * Arena::pad((n_tiles_padded + 1) * P * sizeof(fe_t)) + Arena::pad(sizeof(fe_t) * P) +
+                  Arena::pad(((size_t)n_gates * P + 1) * sizeof(fe_t)) + 4096;
     A.reserve(need);
     A.reset();
     fe_t *d_w = A.take<fe_t>(weights.size());
@@ -2463,6 +2509,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     GateProg *d_gp = A.take<GateProg>(gp.size());
     fe_t *buf0 = A.take<fe_t>((n_tiles_padded + 1) * P);
     fe_t *buf1 = A.take<fe_t>((n_tiles_padded + 1) * P);
+    fe_t *d_hoist = A.take<fe_t>((size_t)n_gates * P + 1);
     SRS_HIP_CHECK(hipMemcpyAsync(d_w, weights.data(), weights.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
     if (!wcoef.empty()) SRS_HIP_CHECK(hipMemcpyAsync(d_coef, wcoef.data(), wcoef.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
     SRS_HIP_CHECK(hipMemcpyAsync(d_utab, utab.data(), utab.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
@@ -2496,8 +2543,16 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     else { a.shard_rank = 0; a.shard_world = 1; }
     {
         prof::Scope ps(mode == 0 ? "pg_F_leaves" : (mode == 1 ? "pg_G_leaves" : "pg_e_leaves"), st, S->rows * n_gates);
-        if (S->pg_spec_id >= 0 && lpt == 8)
+        a.hoist = d_hoist;
+        a.hoist_mode = 0;
+        if (S->pg_spec_id >= 0 && lpt == 8) {
+            if (sweep_leaves && compat && pg_hoist_on()) {     // k_pg_leaves_sweep<.., COMPAT>: the gates at row 0 once, then the leaf pass
+                a.hoist_mode = 1;
+                launch_pg_spec(S->pg_spec_id, a, P, n_gates, tile, st, sweep_leaves);      // one workgroup per (point, gate)
+                a.hoist_mode = 2;
+            }
             launch_pg_spec(S->pg_spec_id, a, tiles_per_gate, n_gates, tile, st, sweep_leaves);
+        }
         else if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, lpt, st);
         else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, lpt, st);
