@@ -439,6 +439,44 @@ def test_emu_sangria_step_merged_commits():
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+SLOT_MODE_CODE = (
+    "import os, sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+    "from sirius_amd import _lib\n"
+    f"_lib.load({EMU_LIB!r})\n"
+    "import sirius_amd as S, oracle as O\n"
+    "from conftest import seeded_scalars\n"
+    "n = int(os.environ['N'])\n"
+    "for cid in (0, 1):\n"
+    "    bases = O.make_bases(cid, 7 + cid, n); ck = S.CommitmentKey(cid, bases)\n"
+    "    # regimes in turn: no hot buckets -> hot (unexpected: redo) -> hot (expected: overflow kernels) -> none (kernels launched for nothing) -> none\n"
+    "    for rep, kind in enumerate(('uniform', 'trace', 'trace', 'uniform', 'uniform')):\n"
+    "        sc = seeded_scalars(O, cid, n, 20 + rep, kind)\n"
+    "        assert np.array_equal(ck.commit_upload(sc), O.msm(cid, sc, bases[:n])), (cid, rep, kind)\n"
+    "    st = ck.msm_stats(); assert st['slot_sets'] >= 5 and st['hot_sets'] >= 2 and st['redo'] == 1, st\n"
+    "    sc = seeded_scalars(O, cid, n, 31, 'trace'); assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases[:n]))      # a whole MSM (SRS_MSM_SLOTS=2: slot mode too)\n"
+    "    vs = [seeded_scalars(O, cid, m, 40 + i, k) for i, (m, k) in enumerate(((n, 'trace'), (n // 2, 'uniform'), (7, 'trace')))]\n"
+    "    for g, v in zip(ck.commit_batch(vs), vs): assert np.array_equal(g, O.msm(cid, v, bases[:len(v)]))\n"
+    "    for x in (1, 5):      # every scalar the same small value: ONE bucket holds everything\n"
+    "        v = O.ints_to_mont(O.SCALAR_FIELD[cid], [x] * n); assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases[:n])), x\n"
+    "    ck.close()\n"
+    "print('ok')\n")
+
+
+def test_emu_slot_mode_commits():
+    """msm.hip slot mode (r04): persistent per-bucket partial sums across the chunks of a streamed commit, the part length chosen on the
+    device, parts beyond the slots through the level kernels into the last slot, the per-key prediction with its redo -- forced onto
+    small inputs: 4 and 8 slots per bucket (so that hot buckets overflow), three chunks, both sort paths, whole MSMs and batches in slot mode
+    (SRS_MSM_SLOTS=2), against the oracle; msm_stats must show the hot sets and exactly one redo per key."""
+    import sys
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    jobs = []
+    for tag, slot_log, sort, n in (("s2", "2", "1", "5000"), ("s3", "3", "2", "4000"), ("s6", "6", "2", "9000")):
+        env = dict(os.environ, SRS_MSM_SLOTS="2", SRS_MSM_SLOT_LOG=slot_log, SRS_MSM_SORT=sort, SRS_COMMIT_CHUNKS="3", N=n)
+        jobs.append((tag, [sys.executable, "-c", SLOT_MODE_CODE], env))
+    for tag, r in _run_all(jobs).items():
+        assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_long_level0_parts():
     """msm.hip l0_log_for: 64 gathered additions per level-0 thread (the setting of large MSMs), forced on a small one."""
     import sys
