@@ -446,7 +446,7 @@ SLOT_MODE_CODE = (
     "import sirius_amd as S, oracle as O\n"
     "from conftest import seeded_scalars\n"
     "n = int(os.environ['N'])\n"
-    "for cid in (0, 1):\n"
+    "for cid in [int(c) for c in os.environ['CURVES']]:\n"
     "    bases = O.make_bases(cid, 7 + cid, n); ck = S.CommitmentKey(cid, bases)\n"
     "    # regimes in turn: no hot buckets -> hot (unexpected: redo) -> hot (expected: overflow kernels) -> none (kernels launched for nothing) -> none\n"
     "    for rep, kind in enumerate(('uniform', 'trace', 'trace', 'uniform', 'uniform')):\n"
@@ -465,13 +465,14 @@ SLOT_MODE_CODE = (
 def test_emu_slot_mode_commits():
     """msm.hip slot mode (r04): persistent per-bucket partial sums across the chunks of a streamed commit, the part length chosen on the
     device, parts beyond the slots through the level kernels into the last slot, the per-key prediction with its redo -- forced onto
-    small inputs: 4 and 8 slots per bucket (so that hot buckets overflow), three chunks, both sort paths, whole MSMs and batches in slot mode
+    small inputs: 4, 8 and 32 slots per bucket (so that hot buckets overflow), three chunks, both sort paths, whole MSMs and batches in slot mode
     (SRS_MSM_SLOTS=2), against the oracle; msm_stats must show the hot sets and exactly one redo per key."""
     import sys
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
     jobs = []
-    for tag, slot_log, sort, n in (("s2", "2", "1", "5000"), ("s3", "3", "2", "4000"), ("s6", "6", "2", "9000")):
-        env = dict(os.environ, SRS_MSM_SLOTS="2", SRS_MSM_SLOT_LOG=slot_log, SRS_MSM_SORT=sort, SRS_COMMIT_CHUNKS="3", N=n)
+    for tag, slot_log, sort, n, curves in (("s2", "2", "1", "5000", "0"), ("s2g", "2", "2", "3000", "1"), ("s3", "3", "2", "4000", "1"),
+                                           ("s5", "5", "2", "4200", "0")):
+        env = dict(os.environ, SRS_MSM_SLOTS="2", SRS_MSM_SLOT_LOG=slot_log, SRS_MSM_SORT=sort, SRS_COMMIT_CHUNKS="3", N=n, CURVES=curves)
         jobs.append((tag, [sys.executable, "-c", SLOT_MODE_CODE], env))
     for tag, r in _run_all(jobs).items():
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stdout[-500:], r.stderr[-1500:])
