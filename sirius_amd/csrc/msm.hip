@@ -25,6 +25,12 @@
 //     quad_perm moves), 3.9 us instead of 9.8 us per addition.
 // Batched entry: the d-1 cross-term commitments share one base prefix and run
 // as one set of launches (grid.y / grid.z = batch index).
+// r04: the sets of a STREAMED commit (the witness comes up from host memory in chunks, capi.hip: commit_streamed) run in SLOT MODE:
+// every bucket owns 2^6 persistent partial sums in HBM, a level-0 part adds its entries into "its" slot (k_accum0s), so the accumulation
+// levels / wave pass / bucket fold that every chunk used to run are ONE reduction of the slots per commit (k_slot_reduce); the plan of a
+// set (k_plan_s) picks the part length on the device; parts beyond the slots (hot buckets) go through the level kernels into the
+// bucket's last slot, launched only when the key expects them (msm.h: overflow_missed / note_commit).  Whole MSMs of >= 2^23 scalars
+// take the 13 x 20-bit "wide" windows over a second table (16 virtual MSMs of 2^15 buckets each).
 // The 29-bit products of THIS translation unit chain every column's multiply-accumulates from the previous column's carry (inline
 // v_mad_u64_u32, field29.cuh): no 64-bit join per column, 127 instead of 132 VGPRs in k_accum0 / k_accum0s (4 waves per SIMD instead of
 // 3): 13.85 -> 14.4 G mixed additions/s, profiles/r04_ab_slots_cuts.txt.  Device code only; host and emulator builds keep the C form.
