@@ -755,7 +755,7 @@ def main():
         scalars_per_step = pri.w["num_advice"] * pri.rows + (3 + 2) * sup.rows
         if D.rank == 0:
             nz = sum(nonzero_rows(torch.from_numpy(hb.array.view(np.int64))) for hb in pri.host_W) / 2.0 + nonzero_rows(sup.inW) + sup.nz_terms
-            roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 9 chunks + the support circuit's 5*2^15 per step",
+            roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 10 chunks + the support circuit's 5*2^15 per step",
                                 16.0 * nz * args.steps / D.world, D.world)
             prof = {}
             for name in ("pg_F_leaves", "pg_G_leaves", "rowprog_cross_terms"):
@@ -780,7 +780,7 @@ def main():
                                          "poly_F / poly_K, 255 bits (:424-448); the support circuit's r as generate_challenge (sangria/mod.rs:162-179), 128 bits",
                            "witness": "55 % zero scalars, 45 % uniform 254-bit: 7.2 non-zero 16-bit digits (= bucket additions) per scalar, no hot buckets; "
                                       "SURVEY.md 8d(ii)'s mixture with bits and small values costs ~2.4 per scalar (tests/conftest.py seeded_scalars 'trace')",
-                           "msm": "16 x 16-bit windows, streamed commit in 9 chunks, slot mode (per-bucket persistent partial sums, one reduction per commit)",
+                           "msm": "16 x 16-bit windows, streamed commit in 10 chunks, slot mode (per-bucket persistent partial sums, one reduction per commit)",
                            "parallelism": (f"msm+leaf-shard{D.world}" if getattr(pri, "sharded", False) else f"msm-shard{D.world}") if D.world > 1
                                           else (f"msm-multi{D.multi}-single-process ({pri.ck.num_shards} shards on {torch.cuda.device_count() if not D.emu else 0} device(s))"
                                                 if D.multi else "single-gpu")},

@@ -1046,8 +1046,10 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
         // byte has arrived: seven chunks, the last one 26 % -- was {0.045, 0.15, 0.32, 0.53, 0.77}, then {0.024, 0.089, 0.208, 0.399, 0.677}
         // r04 (slot mode: no accumulation levels per chunk, ~0.15 ms of fixed cost per chunk): the chip now WAITED for the uploads of the
         // steeply growing middle chunks (~0.9 ms per commit in the kernel trace) -- nine chunks, each upload no longer than the chunk before
-        // it takes to accumulate: 12.0 -> 11.6 ms per step (profiles/r04_ab_slots_cuts.txt)
-        std::vector<double> frac = {0.02, 0.063, 0.129, 0.219, 0.336, 0.479, 0.652, 0.856};
+        // it takes to accumulate: 12.0 -> 11.6 ms per step (profiles/r04_ab_slots_cuts.txt).  Later in r04, with the per-chunk cost down to
+        // ~0.14 ms and accumulation about as fast per byte as the upload, the no-wait condition  upload(j + 1) <= cost(j)  means chunks
+        // growing LINEARLY: ten of them, 11.2 -> 11.0 ms (same file, last section)
+        std::vector<double> frac = {0.02, 0.058, 0.115, 0.19, 0.285, 0.40, 0.535, 0.69, 0.86};
         if (const char *e = std::getenv("SRS_COMMIT_CUTS")) {      // tuning: cumulative fractions, e.g. "0.1,0.4"
             frac.clear();
             for (const char *q = e; *q;) {
