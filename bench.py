@@ -376,13 +376,15 @@ class PgPrimary:
             ro = self.ro.reset()
             ro.absorb_field(np.concatenate([self.accC.reshape(2, 4), self.inC.reshape(2, 4)]))
             ro.absorb_field(self.betas)
-            delta = PGint(ro.squeeze(255, 0))          # MAX_BITS (src/constants.rs:4), as Challenges::generate_one squeezes it
+            delta_m = ro.squeeze(255, 0)               # MAX_BITS (src/constants.rs:4), as Challenges::generate_one squeezes it
+        else:
+            delta_m = m([delta])[0]
         if self.sharded:
-            return self.prove_sharded(S, D, ro, m([delta])[0], alpha, gamma)
+            return self.prove_sharded(S, D, ro, delta_m, alpha, gamma)
         # one library call (srs_pg_prove): F -> alpha -> betas' -> G -> K -> gamma -> L(gamma), e, fold_witness
         defer = self.inW_next is not None
         self.fold_done()
-        pr = PG.prove(ctx, self.betas, m([delta])[0], [self.accW, self.inW], ro=ro, alpha=None if ro else m([alpha])[0],
+        pr = PG.prove(ctx, self.betas, delta_m, [self.accW, self.inW], ro=ro, alpha=None if ro else m([alpha])[0],
                       gamma=None if ro else m([gamma])[0], reference_compat=self.compat, fold=not defer)
         self.e, self.betas = pr["e"], pr["betas_stroke"]
         if defer:

@@ -88,7 +88,8 @@ struct Key {
     uint32_t slot_s = 0;              // S of the running commit
     uint32_t seq = 0;                 // sets enqueued in the running commit
     bool commit_ovf = false;          // the running commit launches the overflow kernels
-    bool expect_ovf = false;          // prediction for the next commit (= the last one had parts beyond the slots)
+    bool expect_ovf = false;          // prediction for the next commit: hot buckets seen in one of the last few commits (note_commit)
+    uint32_t cold_streak = 0;         // commits in a row without hot buckets while they were expected
     bool slot_mode[LANDING_SLOTS] = {};     // landing slot -> the set ran in slot mode ...
     bool slot_ovf_on[LANDING_SLOTS] = {};   // ... with its overflow kernels launched
     uint32_t slot_batch[LANDING_SLOTS] = {};
@@ -136,7 +137,8 @@ void reserve(Key &k, uint32_t n_max, uint32_t batch);
 // Slot mode predicts per key whether a commit has parts beyond the slots (hot buckets: 0 / 1 / small witnesses) and launches the
 // overflow kernels only then.  After the stream has been synchronised: overflow_missed(slot) says that the set in `slot` HAD such parts
 // while its overflow kernels were not launched -- its result is incomplete and the caller must run the MSM again (the prediction has
-// been switched, so the second run is complete); note_commit() records what the finished commit saw for the next prediction.
+// been switched, so the second run is complete); note_commit() records what the finished commit saw for the next prediction (on at
+// once, off after four commits in a row without hot buckets).
 bool overflow_missed(const Key &k, uint32_t slot);
 void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots);
 

@@ -2187,7 +2187,17 @@ void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots) {
         if (hot) ++k.stat_hot_sets;
         any = any || hot;
     }
-    if (slot_sets) k.expect_ovf = any;
+    // hot buckets are expected at once, and un-expected only after COLD_COMMITS commits in a row without them: launching the overflow kernels
+    // for nothing costs ~0.3 ms of empty launches per commit, missing them costs the commit run a second time
+    constexpr uint32_t COLD_COMMITS = 4;
+    if (!slot_sets) return;
+    if (any) {
+        k.expect_ovf = true;
+        k.cold_streak = 0;
+    } else if (k.expect_ovf && ++k.cold_streak >= COLD_COMMITS) {
+        k.expect_ovf = false;
+        k.cold_streak = 0;
+    }
 }
 
 // ---- the wide-window pipeline: ONE MSM of n >= 2^WIDE_MIN_N_LOG scalars over table_w -------------------------------------
