@@ -1,0 +1,62 @@
+"""Randomised soak of the STREAMED commit in slot mode on the GPU (not part of the test suite): random lengths around the chunking
+thresholds, random value mixtures (no hot buckets / bits and small values / every scalar equal / one scalar hot), pinned and pageable
+sources, two keys on two host threads -- every commitment against the oracle; prints the slot-mode counters at the end.
+usage: python tools/soak_stream.py [seed] [seconds]"""
+import os, sys, threading, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as O
+import sirius_amd as S
+from conftest import seeded_scalars
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+NMAX = 3 << 20
+errs, stats = [], {}
+
+
+def worker(cid, wseed):
+    rng = np.random.default_rng(wseed)
+    ck = S.CommitmentKey.setup_synthetic(cid, NMAX, seed=100 + cid)
+    bases = ck.bases()
+    sf = O.SCALAR_FIELD[cid]
+    t0, done = time.time(), 0
+    try:
+        while time.time() - t0 < budget:
+            n = int(rng.choice([(1 << 19) - 1, (1 << 19) + 1, 1 << 20, (1 << 20) + 7, (1 << 21) + 12345, NMAX, int(rng.integers(1 << 19, NMAX))]))
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                v = seeded_scalars(O, cid, n, int(rng.integers(0, 1 << 30)), "uniform")
+            elif kind == 1:
+                v = seeded_scalars(O, cid, n, int(rng.integers(0, 1 << 30)), "trace")
+            elif kind == 2:
+                v = np.repeat(seeded_scalars(O, cid, 1, int(rng.integers(0, 1 << 30)), "uniform"), n, axis=0)          # one bucket per window holds everything
+            elif kind == 3:
+                v = seeded_scalars(O, cid, n, int(rng.integers(0, 1 << 30)), "uniform")
+                v[:: int(rng.integers(2, 9))] = O.ints_to_mont(sf, [int(rng.integers(1, 4))])[0]                          # a hot bucket among uniform ones
+            else:
+                v = np.zeros((n, 4), np.uint64)
+                v[int(rng.integers(0, n))] = O.ints_to_mont(sf, [5])[0]                                                   # (almost) empty
+            src = v
+            hb = None
+            if rng.random() < 0.5:
+                hb = S.HostBuffer(n)
+                hb.array[:] = v
+                src = hb.array
+            got = ck.commit_upload(src)
+            assert np.array_equal(got, O.msm(cid, v, bases[:n])), ("commit_upload", cid, n, kind)
+            if hb is not None:
+                hb.close()
+            done += 1
+        stats[cid] = (done, ck.msm_stats())
+    except Exception as e:      # surfaced in the main thread
+        errs.append(repr(e))
+    ck.close()
+
+
+th = [threading.Thread(target=worker, args=(c, seed * 7 + c)) for c in (0, 1)]
+[t.start() for t in th]
+[t.join() for t in th]
+assert not errs, errs
+print("soak_stream OK", stats, "seed", seed)
