@@ -123,138 +123,11 @@ struct Fp29 {
     }
 
 #if defined(SRS_F29_CHAIN) && defined(__HIP_DEVICE_COMPILE__)
-    // A/B build (r04, tools/build_variant.py): the same three products with every column's multiply-accumulate chain STARTED FROM the
-    // carry of the column before (the addend operand of v_mad_u64_u32) -- hipcc builds the next column's sum on the side and joins the two
-    // with a v_lshl_add_u64 per column (16 per product, 144 per mixed addition, 4.2 cycles each).  Same values, same bounds.
-    __device__ static __forceinline__ uint64_t mad_vv(uint32_t a, uint32_t b, uint64_t c) {
-        uint64_t d;
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
-        return d;
-    }
-    __device__ static __forceinline__ uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) {      // b: a limb of the modulus (uniform)
-        uint64_t d;
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc");
-        return d;
-    }
-    __device__ static f29_t mul(const f29_t &a, const f29_t &b) {
-        uint64_t acc = 0;
-        uint32_t m[9];
-        f29_t o;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int i = 0; i <= k; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
-#pragma unroll
-            for (int i = 0; i < k; ++i) acc = mad_vs(m[i], p(k - i), acc);
-            m[k] = ((uint32_t)acc * INV) & MASK;
-            acc = mad_vs(m[k], p(0), acc);
-            acc >>= B;
-        }
-#pragma unroll
-        for (int k = 9; k < 17; ++k) {
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc = mad_vs(m[i], p(k - i), acc);
-            o.v[k - 9] = (uint32_t)acc & MASK;
-            acc >>= B;
-        }
-        o.v[8] = (uint32_t)acc;
-        return o;
-    }
-#if SRS_F29_CHAIN == 2
-    __device__ static f29_t mul2(const f29_t &a, const f29_t &b, const f29_t &c, const f29_t &d) {        // hipcc's schedule (as below)
-        uint64_t acc = 0;
-        uint32_t m[9];
-        f29_t o;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int i = 0; i <= k; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
-#pragma unroll
-            for (int i = 0; i <= k; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
-#pragma unroll
-            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * p(k - i);
-            m[k] = ((uint32_t)acc * INV) & MASK;
-            acc += (uint64_t)m[k] * p(0);
-            acc >>= B;
-        }
-#pragma unroll
-        for (int k = 9; k < 17; ++k) {
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.v[i] * b.v[k - i];
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)c.v[i] * d.v[k - i];
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * p(k - i);
-            o.v[k - 9] = (uint32_t)acc & MASK;
-            acc >>= B;
-        }
-        o.v[8] = (uint32_t)acc;
-        return o;
-    }
-#else
-    __device__ static f29_t mul2(const f29_t &a, const f29_t &b, const f29_t &c, const f29_t &d) {
-        uint64_t acc = 0;
-        uint32_t m[9];
-        f29_t o;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int i = 0; i <= k; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
-#pragma unroll
-            for (int i = 0; i <= k; ++i) acc = mad_vv(c.v[i], d.v[k - i], acc);
-#pragma unroll
-            for (int i = 0; i < k; ++i) acc = mad_vs(m[i], p(k - i), acc);
-            m[k] = ((uint32_t)acc * INV) & MASK;
-            acc = mad_vs(m[k], p(0), acc);
-            acc >>= B;
-        }
-#pragma unroll
-        for (int k = 9; k < 17; ++k) {
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc = mad_vv(a.v[i], b.v[k - i], acc);
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc = mad_vv(c.v[i], d.v[k - i], acc);
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc = mad_vs(m[i], p(k - i), acc);
-            o.v[k - 9] = (uint32_t)acc & MASK;
-            acc >>= B;
-        }
-        o.v[8] = (uint32_t)acc;
-        return o;
-    }
-#endif
-    __device__ static f29_t sqr(const f29_t &a) {
-        uint64_t acc = 0;
-        uint32_t m[9], a2[9];
-        f29_t o;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) a2[i] = a.v[i] << 1;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int i = 0; 2 * i < k; ++i) acc = mad_vv(a2[i], a.v[k - i], acc);
-            if ((k & 1) == 0) acc = mad_vv(a.v[k / 2], a.v[k / 2], acc);
-#pragma unroll
-            for (int i = 0; i < k; ++i) acc = mad_vs(m[i], p(k - i), acc);
-            m[k] = ((uint32_t)acc * INV) & MASK;
-            acc = mad_vs(m[k], p(0), acc);
-            acc >>= B;
-        }
-#pragma unroll
-        for (int k = 9; k < 17; ++k) {
-#pragma unroll
-            for (int i = k - 8; 2 * i < k; ++i) acc = mad_vv(a2[i], a.v[k - i], acc);
-            if ((k & 1) == 0) acc = mad_vv(a.v[k / 2], a.v[k / 2], acc);
-#pragma unroll
-            for (int i = k - 8; i < 9; ++i) acc = mad_vs(m[i], p(k - i), acc);
-            o.v[k - 9] = (uint32_t)acc & MASK;
-            acc >>= B;
-        }
-        o.v[8] = (uint32_t)acc;
-        return o;
-    }
+    // r04: the same three products with every column's multiply-accumulate chain STARTED FROM the carry of the column before (the addend
+    // operand of v_mad_u64_u32) -- hipcc builds the next column's sum on the side and joins the two with a v_lshl_add_u64 per column (16
+    // per product, 144 per mixed addition, 4.2 cycles each).  Same values, same bounds.  Generated (tools/gen_field29_chain.py): one asm
+    // statement per run of multiply-accumulates, because every statement costs an s_nop.
+#include "field29_chain.inc"
 #else
     // Montgomery product a * b / 2^261 mod p -- see the bounds in the header comment
     SRS_HD static f29_t mul(const f29_t &a, const f29_t &b) {

@@ -33,7 +33,9 @@
 // take the 13 x 20-bit "wide" windows over a second table (16 virtual MSMs of 2^15 buckets each).
 // The 29-bit products of THIS translation unit chain every column's multiply-accumulates from the previous column's carry (inline
 // v_mad_u64_u32, field29.cuh): no 64-bit join per column, 127 instead of 132 VGPRs in k_accum0 / k_accum0s (4 waves per SIMD instead of
-// 3): 13.85 -> 14.4 G mixed additions/s, profiles/r04_ab_slots_cuts.txt.  Device code only; host and emulator builds keep the C form.
+// 3): 13.85 -> 14.4 G mixed additions/s, profiles/r04_ab_slots_cuts.txt; one asm statement per RUN of multiply-accumulates, not per
+// instruction (hipcc pads each statement with an s_nop, ~1 cycle each): + 2.7 % more, profiles/r04_ab_chain_blocks.txt.  Device code only;
+// host and emulator builds keep the C form.
 #define SRS_F29_CHAIN 1
 #include "msm.h"
 #include "curve29.cuh"

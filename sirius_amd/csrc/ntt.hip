@@ -17,6 +17,7 @@
 //     reversal so the result lands in natural order; ifft's n^-1 is folded into the first table.
 //     Physical traffic = P x 64 B/element (+32 B for the first-pass table), P = number of passes.
 #include "ntt.h"
+#define SRS_F29_CHAIN 1      // chained 9 x 29 products (field29_chain.inc): 2^24 fft 2.38 -> 2.31 ms, profiles/r04_ab_chain_blocks.txt
 #include "field29.cuh"
 #include "prof.h"
 
