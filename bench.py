@@ -536,7 +536,7 @@ def msm_roofline(S, units_note, nz_madds=None, world=1):
             break
         except Exception:
             continue
-    roof = {"bound": "hbm", "kernel": "msm::k_accum0 (bucket accumulation)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+    roof = {"bound": "hbm", "kernel": "msm::k_accum0s / k_accum0 (bucket accumulation: the chunks of a streamed commit in slot mode / every other MSM)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
             "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
             "scalars_per_launch": round(acc0["units"] / acc0["launches"]), "units_note": units_note,
