@@ -30,7 +30,7 @@ constexpr uint32_t RED_COLS = NBUCKET / RED_ROWS;
 constexpr uint32_t RED_THREADS = 4 * RED_COLS;   // k_reduce_final: one quad per element, 128 elements
 constexpr uint32_t ACC1_TREE_MAX = 0;            // tree mode (4 lanes per output, each on a quarter of the parts) above the quad mode: measured no gain
                                                  // (the level is VALU-bound, not latency-bound: profiles/r03_sq_counters_msm.txt); SRS_MSM_TREE_MAX=<log2> enables it
-constexpr uint32_t ACC1_QUAD_MAX = 1u << 16;     // k_accum1 runs one quad per output when a level has at most this many outputs (x batch)
+constexpr uint32_t ACC1_QUAD_MAX = 1u << 17;     // k_accum1 runs one quad per output when a level has at most this many outputs (x batch); r04: 2^16 -> 2^17 (the support circuit's 3 x 2^15 outputs: 138 -> 109 us)
 constexpr uint32_t BATCH_ARGS = 16;    // MSMs per set of launches (batch descriptor = kernel argument); larger batches are chunked
 constexpr uint32_t LANDING_SLOTS = 16;  // sets of launches whose results may be in flight at once (chunked commits)
 constexpr uint32_t NORM_G = 16;           // points per inversion in the key-expansion normalise
