@@ -346,11 +346,24 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
 constexpr uint32_t GRP_PER = 16, GRP_SUB = SORT_THREADS * GRP_PER;      // digit slots per thread / per sub-tile of k_group
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     k_group(const uint16_t *__restrict__ dig, size_t dig_stride, BatchDesc bd, const uint32_t *__restrict__ tile_hist,
-            uint16_t *__restrict__ gkey, uint32_t *__restrict__ gpay, size_t g_stride, uint32_t table_stride, uint32_t SORT_TILE) {
+            uint16_t *__restrict__ gkey, uint32_t *__restrict__ gpay, size_t g_stride, uint32_t table_stride, uint32_t SORT_TILE,
+            const uint32_t *__restrict__ plan, size_t plan_stride, uint16_t *__restrict__ tb, size_t tb_stride, uint32_t arr) {
     __shared__ uint32_t cur[SEG], cnt[SEG], lb[SEG], sc[64];
     __shared__ uint32_t spay[GRP_SUB];
     __shared__ uint16_t skey[GRP_SUB];
     const uint32_t m = blockIdx.z, w = blockIdx.y, tid = threadIdx.x;
+    if (tb) {
+        // slot mode: k_expand's work (the thread -> bucket map of level 0, from the plan array `arr`) rides on this launch, a bucket per
+        // wavefront and round -- one dependent launch less per set of a chunked commit (r04)
+        const uint32_t *tp = plan + (size_t)m * plan_stride + (size_t)arr * (NBUCKET + 1);
+        uint16_t *map = tb + (size_t)m * tb_stride;
+        const uint32_t waves = gridDim.x * gridDim.y * (blockDim.x >> 6);
+        const uint32_t wv = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (tid >> 6), lane = tid & 63u;
+        for (uint32_t b = wv; b < NBUCKET; b += waves) {
+            const uint32_t s = tp[b], e = tp[b + 1];
+            for (uint32_t t = s + lane; t < e; t += 64) map[t] = (uint16_t)b;
+        }
+    }
     const uint32_t n = bd.n[m];
     const uint32_t lo = blockIdx.x * SORT_TILE;
     if (lo >= n) return;
@@ -1910,7 +1923,8 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
         const uint32_t T1 = tiles * NWIN;
         SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, plan_stride);
         SRS_LAUNCH(k_group, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M, bd,
-                   (const uint32_t *)tile_hist, gkey, gpay, (size_t)M, (uint32_t)k.len, tile);
+                   (const uint32_t *)tile_hist, gkey, gpay, (size_t)M, (uint32_t)k.len, tile, (const uint32_t *)nullptr, (size_t)0,
+                   (uint16_t *)nullptr, (size_t)0, 0u);
         // 8 x ceil(tiles / 8) workgroups: the XCD-aware mapping of k_scatter2 needs every (XCD, slot) pair to exist
         SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
                    (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, plan_stride, cursor, sorted, (size_t)M,
@@ -2111,7 +2125,8 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
         const uint32_t T1 = tiles * NWIN;
         SRS_LAUNCH(k_scan_seg, (SEG, batch), (1024), 0, stream, tile_hist, T1, (const uint32_t *)plan, h.plan_stride);
         SRS_LAUNCH(k_group, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M, bd,
-                   (const uint32_t *)tile_hist, gkey, gpay, (size_t)M, (uint32_t)k.len, tile);
+                   (const uint32_t *)tile_hist, gkey, gpay, (size_t)M, (uint32_t)k.len, tile, (const uint32_t *)plan, h.plan_stride, tb,
+                   (size_t)h.cap, (uint32_t)h.levels + 1);                 // + the thread -> bucket map (k_expand's work)
         SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
                    (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, h.plan_stride, cursor, sorted, (size_t)M,
                    (uint32_t)SORT_TILE2);
@@ -2123,7 +2138,7 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
     const Link *no_link = nullptr;
     const uint32_t arr = (uint32_t)h.levels + 1;
-    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, h.plan_stride, tb, (size_t)h.cap, no_link, arr);
+    if (!two_pass) SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, h.plan_stride, tb, (size_t)h.cap, no_link, arr);
     SRS_LAUNCH_TIMED("msm_accum0", units, (k_accum0s<C>), (ceil_div(h.cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                      (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, h.plan_stride, arr, (const uint16_t *)tb, (size_t)h.cap,
                      (const affine_t *)k.table, k.slots, S, used_prev, first ? 1 : 0, ping, (size_t)h.cap);
