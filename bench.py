@@ -56,7 +56,7 @@ MADD_MULT_INSNS = 8 * 171 + 2 * 135 - 90
 # r04 kernel trace of the N = 1 step: per-row / per-scalar work divides by N, the chain's latency-bound part does not).
 PREDICTED_SCALING = {
     "note": "PREDICTION, not a measurement: k = 20 CycleFold step, process per GPU (bench.py --gpus N); strong scaling of ONE sequential chain",
-    "ms_per_step": {"1": 10.8, "2": 7.3, "4": 4.7, "8": 3.7},
+    "ms_per_step": {"1": 10.7, "2": 7.2, "4": 4.7, "8": 3.7},
     "speedup": {"1": 1.0, "2": 1.5, "4": 2.3, "8": 2.9},
     "msm_2p24_uniform_ms": {"1": 19.4, "2": 10.0, "4": 5.3, "8": 3.0},
     "divisible_ms_at_1": 8.2, "replicated_ms": 2.6, "per_rank_overhead_ms_at_n_gt_1": 0.55,
