@@ -13,10 +13,12 @@ at k = 20 with a 2^24 commitment key.  One "step" = the hot-path work of one `ne
   C. the new primary witness arrives FROM THE HOST (halo2 synthesis is CPU work, src/table/circuit_runner.rs:71-107) and is
        committed: 12 * 2^20 scalars -- uploaded inside the timed region, in chunks that overlap the MSM of the
        chunks already in HBM (srs_commit_upload); the device copy is the incoming trace of the next step
-Accumulators, fixed columns and the expanded keys stay resident in HBM; challenges are seeded constants (the Poseidon random
-oracle is host code in the reference; `--ro-challenge` derives them with the library's off-circuit sponge instead).
-`--leaf-rows compat` evaluates every ProtoGalaxy leaf at row 0 as the reference does (src/plonk/mod.rs:714, SURVEY.md Q1: less
-memory traffic); the default `true` reads the leaf's own row -- the heavier, intended computation.
+Accumulators, fixed columns and the expanded keys stay resident in HBM.  Defaults = the reference's computation: every challenge is
+squeezed from the library's off-circuit Poseidon sponge over the transcript (`--challenges poseidon-ro`; `seeded` takes constants), and
+every ProtoGalaxy leaf is evaluated at row 0 as the reference does (`--leaf-rows compat`: src/plonk/mod.rs:714); the
+intended computation -- the leaf's own row, `--leaf-rows true` -- is timed beside it as `secondary.true_leaf_rows`.
+`--witness survey` commits SURVEY.md 8d(ii)'s value mixture instead of the bench witness (hot buckets on every commit; by default
+reported as `secondary.survey_mixture`); `--verify` recomputes the first step on the CPU oracle (oracle/chain.py) and prints both digests.
 
 `--config sangria` runs BASELINE configs[1] (one SangriaIVC::fold_step at k = 17) as the main line instead; by default it is
 reported as a secondary object next to the 2^24 MSM / NTT microbenchmark (configs[4]), each with its own roofline.
@@ -83,6 +85,13 @@ def parse():
                          "reference does (protogalaxy/mod.rs:80-133, sangria/mod.rs:162-179); seeded: constants (no oracle on the critical path)")
     ap.add_argument("--ro-challenge", action="store_true", help="(r02 spelling of --challenges poseidon-ro; now the default)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--witness", default="bench", choices=["bench", "survey"],
+                    help="bench (default): 55 %% zero / 45 %% uniform scalars, 7.2 bucket additions per scalar, no hot bucket; survey: SURVEY.md "
+                         "8d(ii)'s mixture as canonical values (55 %% zero, 20 %% bits, 15 %% < 2^64, 10 %% uniform): ~2.3 additions per scalar, "
+                         "bucket 0 hot in every chunk (slot mode's overflow kernels on every set)")
+    ap.add_argument("--verify", action="store_true",
+                    help="checker, outside the timed region: the chain's FIRST step is recomputed on the CPU oracle (oracle/chain.py) and both "
+                         "digests are printed as `verify` (k = 20: ~10 s of CPU)")
     ap.add_argument("--emu", action="store_true",
                     help="harness self-test without a GPU: loads the CPU logic emulator (tests/emu, test infrastructure) and keeps "
                          "'device' tensors in host memory; use a tiny --k.  The numbers it prints are meaningless")
@@ -349,6 +358,7 @@ class PgPrimary:
             self.side = torch.cuda.Stream()
         rng = np.random.default_rng(77)
         self.host_W = [pinned_copy(S, w["W2"]), pinned_copy(S, trace_like(rng, n))]      # two witnesses, alternating
+        self.witness_kind = "bench"
         rnd = random.Random(3)
         self.m = lambda v: ints_to_mont(0, list(v))
         self.FR = FR
@@ -360,6 +370,21 @@ class PgPrimary:
         self.pending = None
         self.ro = S.PoseidonHash(0, 5, 4, 10, 10)
         self.step_no = 0
+
+    def set_witness(self, kind):
+        """the two host witnesses the steps alternate between: `bench` (as built) or `survey` (SURVEY.md 8d(ii)'s mixture)"""
+        from sirius_amd.workloads import survey_mixture, trace_like
+        if kind == self.witness_kind:
+            return
+        n = self.w["num_advice"] * self.rows
+        if kind == "survey":
+            a = survey_mixture(np.random.default_rng(78), n, 0)
+            self.host_W[0].array[:] = a
+            self.host_W[1].array[:] = np.roll(a, 12345, axis=0)      # a second witness of the same mixture
+        else:
+            self.host_W[0].array[:] = self.w["W2"]
+            self.host_W[1].array[:] = trace_like(np.random.default_rng(77), n)
+        self.witness_kind = kind
 
     def settle(self):
         if self.pending is not None:
@@ -527,7 +552,7 @@ def msm_roofline(S, units_note, nz_madds=None, world=1):
     sec = acc0["total_ms"] * 1e-3
     achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / sec / 1e9
     traffic, src = None, None
-    for name in ("r04_pmc_accum0.json", "r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
+    for name in ("r05_pmc_accum0.json", "r04_pmc_accum0.json", "r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if world == 1:
@@ -540,7 +565,9 @@ def msm_roofline(S, units_note, nz_madds=None, world=1):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
             "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
             "scalars_per_launch": round(acc0["units"] / acc0["launches"]), "units_note": units_note,
-            "note": "integer-multiplier bound (256-bit modular products), not HBM bound: see DESIGN.md and the `alu` object"}
+            "binding": "alu",
+            "note": "`bound` / `frac` are the mandated HBM figures; the roof that BINDS this kernel is integer-multiplier issue (256-bit modular "
+                    "products: v_mad_u64_u32), see the `alu` object and DESIGN.md 2"}
     if nz_madds:
         rate = nz_madds / sec
         peak = MAD_ISSUE_PER_S / MADD_MULT_INSNS
@@ -683,13 +710,33 @@ def extras_microbench(S, D, ck24, log_n=24, reps=3):
         return (time.perf_counter() - t) / reps
     a = up(D, rand_fe(rng, n))
     S.fft.fft(a)
+    pmc = None
+    try:   # HBM bytes per transform of the kernels that ship, from the committed PMC passes (profiles/r05_pmc_ntt.json)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_ntt.json")))
+    except Exception:
+        pass
     for name, fn in (("fft", S.fft.fft), ("ifft", S.fft.ifft)):
         S.profile_reset()
         dt = timeit(lambda: fn(a))
+        # modular products of one transform: (n / 2) log2 n butterflies + one inter-pass twiddle per element and non-final pass (3 passes
+        # at 2^24); the chip issues 31.2 T v_mad_u64_u32/s and a 9 x 29-bit product takes 171 of them
+        passes = 1 if log_n <= 10 else -(-log_n // 8)          # digits of <= 8 bits (csrc/ntt.hip)
+        modmul = (n // 2) * log_n + (passes - 1) * n      # (ifft's 2^-k is folded into the first inter-pass table)
+        alu_peak = MAD_ISSUE_PER_S / 171.0
+        traffic = None
+        if pmc and log_n == 24 and name in pmc.get("per_transform", {}):
+            traffic = round(pmc["per_transform"][name]["hbm_bytes"])
         out[f"ntt_{name}"] = {"ms": round(dt * 1e3, 3), "elements_per_s": round(n / dt),
-                              "roofline": {"bound": "hbm", "achieved": round(NTT_BYTES_PER_ELEMENT * n / dt / 1e9, 2), "peak": HBM_PEAK_GBS,
+                              "roofline": {"bound": "hbm", "binding": "alu", "achieved": round(NTT_BYTES_PER_ELEMENT * n / dt / 1e9, 2), "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": round(NTT_BYTES_PER_ELEMENT * n / dt / 1e9 / HBM_PEAK_GBS, 5),
-                                           "traffic": None, "note": "whole transform (3 passes), wall clock around the call"}}
+                                           "traffic": traffic, "traffic_source": "profiles/r05_pmc_ntt.json" if traffic else None, "passes": passes,
+                                           "alu": {"unit": "G modmul/s", "achieved": round(modmul / dt / 1e9, 2), "peak": round(alu_peak / 1e9, 1),
+                                                   "frac": round(modmul / dt / alu_peak, 4), "modmul_per_transform": modmul,
+                                                   "peak_source": "31.2 T v_mad_u64_u32/s (profiles/r02_ubench29_gfx950.txt) / 171 multiplier instructions per 9 x 29-bit product"},
+                                           "hbm_frac_ceiling": round(NTT_BYTES_PER_ELEMENT * n / (modmul / alu_peak) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "note": "whole transform, wall clock around the call.  `hbm_frac_ceiling` = the HBM fraction this transform would "
+                                                   "show if its modular products ran at the multiplier's issue peak with everything else free: the north "
+                                                   "star's >= 0.6 of HBM is not reachable for a 256-bit field on this chip (SURVEY.md H1), the binding roof is `alu`"}}
     del a
     if not D.emu:
         torch.cuda.empty_cache()
@@ -747,7 +794,20 @@ def main():
         log_key = args.log_key or 24
         compat = args.leaf_rows == "compat"
         pri, sup, ks = build_cyclefold(S, D, k, log_key, compat, 15 if not args.emu else min(k, 5))
+        pri.set_witness(args.witness)
         cyclefold_step(S, D, pri, sup, args.ro_challenge, count=True)           # untimed: also counts the non-zero cross-term rows
+        verify = None
+        if args.verify and D.rank == 0:
+            # CHECKER (never timed, never on the product path): the same first step on the CPU oracle
+            assert args.witness == "bench" and args.ro_challenge, "--verify: the oracle chain folds the bench witness with Poseidon-derived challenges"
+            import oracle as O
+            from oracle.chain import oracle_chain
+            first = chain_digest(pri, sup)
+            t0 = time.perf_counter()
+            want = oracle_chain(O, S, k, log_key, ks, 1, compat, fast=True, threads=args.cpu_threads or min(2 * host_cpus(), os.cpu_count() or 1))
+            verify = {"first_step_digest": first, "oracle_first_step_digest": want, "match": first == want,
+                      "oracle_seconds": round(time.perf_counter() - t0, 2),
+                      "note": "state_digest after ONE step of this chain vs oracle/chain.py::oracle_chain(steps=1); the timed steps continue the same chain"}
         for _ in range(args.warmup):
             cyclefold_step(S, D, pri, sup, args.ro_challenge)
         S.profile_enable(True)
@@ -758,7 +818,7 @@ def main():
         if D.rank == 0:
             nz = sum(nonzero_rows(torch.from_numpy(hb.array.view(np.int64))) for hb in pri.host_W) / 2.0 + nonzero_rows(sup.inW) + sup.nz_terms
             roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 10 chunks + the support circuit's 5*2^15 per step",
-                                16.0 * nz * args.steps / D.world, D.world)
+                                16.0 * nz * args.steps / D.world if args.witness == "bench" else None, D.world)
             prof = {}
             for name in ("pg_F_leaves", "pg_G_leaves", "rowprog_cross_terms"):
                 st = S.profile_get(name)
@@ -790,6 +850,12 @@ def main():
                 "witness_upload_bytes_per_step": int(pri.w["num_advice"] * pri.rows * 32 + 3 * sup.rows * 32),
                 "roofline": roof, "kernel_ms": prof, "state_digest": digest,
             }
+            if verify is not None:
+                out["verify"] = verify
+            if args.witness != "bench":
+                out["config"]["witness"] = ("SURVEY.md 8d(ii) mixture as canonical values: 55 % zero, 20 % bits, 15 % < 2^64, 10 % uniform (~2.3 bucket "
+                                            "additions per scalar; bucket 0 of window 0 hot in every chunk)")
+                out["msm_stats"] = pri.ck.msm_stats()
             if compat and D.world == 1 and not args.no_extras:
                 # beside the headline: the same step with every leaf at ITS OWN row (what the reference's `index & 2^k` was meant
                 # to be) -- more memory traffic in compute_F / compute_G, everything else identical
@@ -801,6 +867,31 @@ def main():
                 pri.compat = True
                 out["true_leaf_rows"] = {"fold_steps_per_s": round(n_true / dt_true, 4), "ms_per_step": round(dt_true / n_true * 1e3, 4),
                                          "steps": n_true, "note": "--leaf-rows true: leaf i evaluated at row i mod 2^k instead of row 0"}
+            if D.world == 1 and not args.no_extras and args.witness == "bench" and not D.emu:
+                # beside the headline: the same step on SURVEY.md 8d(ii)'s value mixture -- the regime real traces are assumed to live in
+                # (0 / 1 / small values): a third of the bucket additions, and slot mode's hot-bucket path (overflow parts -> k_accum1
+                # levels -> k_ovf_final) on EVERY set of every commit
+                st0 = pri.ck.msm_stats()
+                pri.set_witness("survey")
+                for _ in range(3):                      # the first commit meets the hot buckets unexpectedly (one redo), then they are expected
+                    cyclefold_step(S, D, pri, sup, args.ro_challenge)
+                st1 = pri.ck.msm_stats()
+                n_sv = max(1, min(args.steps, 5))
+                S.profile_reset()
+                dt_sv = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), n_sv, after=lambda: (pri.settle(), sup.settle()))
+                st2 = pri.ck.msm_stats()
+                acc_sv = S.profile_get("msm_accum0") or dict(total_ms=0.0, launches=0)
+                out["survey_mixture"] = {
+                    "fold_steps_per_s": round(n_sv / dt_sv, 4), "ms_per_step": round(dt_sv / n_sv * 1e3, 4), "steps": n_sv,
+                    "witness": "SURVEY.md 8d(ii): 55 % zero, 20 % bits, 15 % < 2^64, 10 % uniform, as canonical values (an ASSUMED mixture: no trace "
+                               "histogram is published); ~2.3 bucket additions per scalar",
+                    "msm_stats_warmup": {k2: st1[k2] - st0[k2] for k2 in st0}, "msm_stats_timed": {k2: st2[k2] - st1[k2] for k2 in st1},
+                    "accum0_ms_per_step": round(acc_sv["total_ms"] / n_sv, 4),
+                    "upload_floor_ms": round(pri.w["num_advice"] * pri.rows * 32 / 56e9 * 1e3, 3),
+                    "note": "hot_sets == slot_sets in the timed steps: every chunk's bucket 0 overflows its 63 slots and goes through the overflow "
+                            "kernels; redo == 0 once the key expects them.  Kernel times: profiles/r05_kernel_stats_survey_mixture.csv "
+                            "(`bench.py --witness survey`)"}
+                pri.set_witness("bench")
             if D.world == 1 and not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline_cyclefold(args, pri, sup, compat)
@@ -821,7 +912,8 @@ def main():
             micro = extras_microbench(S, D, ck24) if ck24 is not None else (extras_microbench(S, D, pri.ck, log_key, 1) if D.emu else None)
             S.profile_enable(False)
             if D.rank == 0:
-                out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "sangria_k17": sec_obj, "microbench_2p24": micro,
+                out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "survey_mixture": out.pop("survey_mixture", None),
+                                    "sangria_k17": sec_obj, "microbench_2p24": micro,
                                     "predicted_scaling": PREDICTED_SCALING}
                 out["host_path_ms_per_step"] = sec_obj["host_path_ms_per_step"]
         if not args.no_extras and D.world > 1 and (log_key == 24 or D.emu):

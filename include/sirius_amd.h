@@ -171,6 +171,10 @@ int srs_ck_num_shards(const srs_ck *ck);      /* 1 for an ordinary key */
  * out[2] = commits that were run a second time because such parts had not been expected, out[3] = sets on the other flows.
  * Multi-device keys report the sum over their shards. */
 int srs_ck_msm_stats(const srs_ck *ck, uint64_t *out4);
+/* 1 when the key also holds the second, 13-window table of the 20-bit pipeline (keys of >= 2^23 bases: + 81 % key memory; whole
+ * device-resident MSMs of >= 2^23 scalars use it), 0 when it does not -- by size, by SRS_MSM_WIDE=0, or because the device could not hold
+ * it (the key then works on the 16-bit windows alone).  Multi-device keys: 1 when every shard holds it. */
+int srs_ck_has_wide_table(const srs_ck *ck);
 
 /* out = sum of `n` affine points (host); combines per-rank partial commitments. */
 int srs_point_sum(int curve, const srs_affine *points, size_t n, srs_affine *out);

@@ -117,6 +117,10 @@ class CommitmentKey:
         L.check(L.lib().srs_ck_msm_stats(self._h, out))
         return dict(slot_sets=int(out[0]), hot_sets=int(out[1]), redo=int(out[2]), other_sets=int(out[3]))
 
+    def has_wide_table(self):
+        """True when the key holds the second (20-bit-window) table (srs_ck_has_wide_table)."""
+        return bool(L.lib().srs_ck_has_wide_table(self._h))
+
     @classmethod
     def load_from_file(cls, curve, file_path, k, rank=0, world=1):
         """`CommitmentKey::load_from_file` + the on-curve validation of `load_or_setup_cache`

@@ -793,6 +793,14 @@ int srs_ck_msm_stats(const srs_ck *ck, uint64_t *out) {
     return SRS_OK;
 }
 
+int srs_ck_has_wide_table(const srs_ck *ck) {
+    if (!ck) return 0;
+    if (ck->shards.empty()) return ck->key.table_w != nullptr ? 1 : 0;
+    for (const auto &sh : ck->shards)
+        if (sh->key.len && !sh->key.table_w) return 0;
+    return 1;
+}
+
 void srs_ck_free(srs_ck *ck) {
     if (!ck) return;
     if (!ck->shards.empty()) {

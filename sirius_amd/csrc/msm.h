@@ -3,6 +3,8 @@
 #include "curve.cuh"
 #include "devrt.h"
 
+#include <cstdlib>
+
 namespace srs {
 namespace msm {
 
@@ -67,6 +69,12 @@ struct Chunked {
     xyzz_t *ping = nullptr, *pong = nullptr, *buckets = nullptr, *rc = nullptr, *d_out = nullptr;
 };
 
+// a new key's hot-bucket prediction: expected (SRS_MSM_EXPECT_OVF=0: not expected -- the tests of the redo path start cold)
+inline bool expect_ovf_initial() {
+    static const bool v = [] { const char *e = std::getenv("SRS_MSM_EXPECT_OVF"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 // Device-resident commitment key: window-expanded table T[w * len + i] = 2^(16 w) P_i, coordinates in the
 // R' = 2^261 Montgomery form of the 9 x 29-bit multiplier (field29.cuh) once build_table has run.
 struct Key {
@@ -88,7 +96,7 @@ struct Key {
     uint32_t slot_s = 0;              // S of the running commit
     uint32_t seq = 0;                 // sets enqueued in the running commit
     bool commit_ovf = false;          // the running commit launches the overflow kernels
-    bool expect_ovf = false;          // prediction for the next commit: hot buckets seen in one of the last few commits (note_commit)
+    bool expect_ovf = expect_ovf_initial();   // prediction for the next commit: hot buckets seen in one of the last few commits (note_commit); a new key expects them
     uint32_t cold_streak = 0;         // commits in a row without hot buckets while they were expected
     bool slot_mode[LANDING_SLOTS] = {};     // landing slot -> the set ran in slot mode ...
     bool slot_ovf_on[LANDING_SLOTS] = {};   // ... with its overflow kernels launched
@@ -138,7 +146,7 @@ void reserve(Key &k, uint32_t n_max, uint32_t batch);
 // overflow kernels only then.  After the stream has been synchronised: overflow_missed(slot) says that the set in `slot` HAD such parts
 // while its overflow kernels were not launched -- its result is incomplete and the caller must run the MSM again (the prediction has
 // been switched, so the second run is complete); note_commit() records what the finished commit saw for the next prediction (on at
-// once, off after four commits in a row without hot buckets).
+// once -- and from a key's first commit --, off after three commits in a row without hot buckets).
 bool overflow_missed(const Key &k, uint32_t slot);
 void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots);
 

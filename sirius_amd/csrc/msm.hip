@@ -1729,8 +1729,13 @@ static void build_table_t(Key &k, hipStream_t stream) {
     if (n == 0) return;
     xyzz_t *tmp = nullptr;
     SRS_HIP_CHECK(hipMalloc((void **)&tmp, (size_t)n * sizeof(xyzz_t)));
-    if (wants_wide_table(n)) {
-        SRS_HIP_CHECK(hipMalloc((void **)&k.table_w, (size_t)n * NWIN_W * sizeof(affine_t)));
+    // the second table is an optimisation (+81 % key memory): a device that cannot hold it keeps the 16-bit windows for everything
+    // (use_wide() is false without table_w; srs_ck_has_wide_table tells)
+    if (wants_wide_table(n) && hipMalloc((void **)&k.table_w, (size_t)n * NWIN_W * sizeof(affine_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        k.table_w = nullptr;
+    }
+    if (k.table_w) {
         SRS_HIP_CHECK(hipMemcpyAsync(k.table_w, k.table, (size_t)n * sizeof(affine_t), hipMemcpyDeviceToDevice, stream));
         expand_windows<C>(k.table_w, n, NWIN_W, WBITS_W, tmp, stream);
         const size_t total_w = (size_t)n * NWIN_W;
@@ -2208,9 +2213,10 @@ void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots) {
         if (hot) ++k.stat_hot_sets;
         any = any || hot;
     }
-    // hot buckets are expected at once, and un-expected only after COLD_COMMITS commits in a row without them: launching the overflow kernels
-    // for nothing costs ~0.3 ms of empty launches per commit, missing them costs the commit run a second time
-    constexpr uint32_t COLD_COMMITS = 4;
+    // hot buckets are expected at once -- and from a key's FIRST commit (r05: Key::expect_ovf starts true; a witness of 0 / 1 / small values is
+    // the common case and its first commit used to run twice) -- and un-expected only after COLD_COMMITS commits in a row without them:
+    // launching the overflow kernels for nothing costs ~0.3 ms of empty launches per commit, missing them costs the commit run a second time
+    constexpr uint32_t COLD_COMMITS = 3;
     if (!slot_sets) return;
     if (any) {
         k.expect_ovf = true;
@@ -2379,6 +2385,7 @@ template <class C>
 static void chunked_front_t(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t s_sort,
                             hipStream_t s_acc, hipEvent_t sorted_ev) {
     Chunked &S = k.chunked;
+    if (j < LANDING_SLOTS) k.slot_mode[j] = false;       // this landing slot's set is not a slot-mode set (a stale flag would read an old overflow report)
     const uint64_t M = S.M;
     uint16_t *dig = S.dig + (size_t)j * M;
     uint32_t *sorted = S.sorted + (size_t)j * M;
@@ -2445,6 +2452,7 @@ static void chunked_tail_t(Key &k, hipStream_t stream, uint32_t slot) {
     Chunked &S = k.chunked;
     const uint32_t sets = S.sets;
     const Link *no_link = nullptr;
+    k.slot_mode[slot] = false;
     if (S.defer_tail) {
         xyzz_t *cur = S.ping, *nxt = S.pong;
         size_t cur_stride = S.parts0_cap, nxt_stride = S.parts1_cap;

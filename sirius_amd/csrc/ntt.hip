@@ -250,14 +250,19 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
 // twiddle, or a product with the radix' one in the last pass (which also carries ifft's / the coset's scaling when there is one).
 // Twiddle tables are stored times 2^5 (plan.mul29), so x 2^256 * w 2^261 / 2^261 = x w 2^256: the ABI form, bit for bit.
 //
-// Bounds (P = modulus; the multiplier takes one operand with limbs < 2^31 and value A with A * B < 2^261 P ~ 169 P^2, and returns
-// < A B / 2^261 + P; a twiddle is < P with limbs < 2^29).  V_k = bound of a tile value, in units of P, entering radix-4 group k:
+// Bounds (P = modulus).  What Fr29::mul REQUIRES (field29.cuh): operand a with limbs < 2^31 (8 low limbs) -- any VALUE A * P it then represents,
+// here A <= 469 --, operand b normalised (limbs < 2^29, value < P: the twiddles), so that every 64-bit column sum of the 9 + 9 products stays
+// below 2^64 (9 * 2^31 * 2^29 + 9 * 2^29 * 2^29 + carry < 2^64); what it RETURNS: a normalised value < A B P / 2^261 + P, i.e. < (A / 169 + 1) P
+// (2^261 / P > 169).  It does NOT need A * B < 169 P: only the output bound grows with A.  V_k = bound of a tile value, in units of P,
+// entering radix-4 group k:
 //   V_0 = 1 (canonical input), V_1 = 7, V_{k+1} = 4 V_k + 1  ->  29, 117, 469 after the 4th group;  a single trailing stage: 2 V + 1.
 //   Inside a group every subtraction a - b adds (bound of b, + 1) * P, so nothing goes negative; products see A <= 2 V + 1 <= 235 and
 //   return < 2.4 P.  The closing product sees A <= 469: result < 469 / 169 P + P < 3.8 P, which to_canonical_fe (< 4 P) takes.
 //   Limbs: normalised (< 2^29, top limb < 2^31) at group boundaries; inside a group <= 2^29 + 2^30 + 2^30 < 2^32.
 struct lazy {
     static constexpr uint32_t bound(uint32_t k) { return k == 0 ? 1u : (k == 1 ? 7u : 4u * bound(k - 1) + 1u); }
+    // the closing product of a tile of up to 4 radix-4 groups (+ a trailing stage) must come back below the 4 P that to_canonical_fe takes
+    static constexpr uint32_t closing_bound_x169(uint32_t a) { return a + 169u; }                  // (A / 169 + 1) P, times 169
     SRS_D static f29_t get(const uint32_t *tile, uint32_t e) {
         f29_t x;
 #pragma unroll
@@ -332,6 +337,10 @@ __device__ __forceinline__ void lazy_stage1(uint32_t *tile, const uint32_t *W, u
 template <uint32_t NCOLS, uint32_t RBITS>
 __device__ __forceinline__ void lazy_stages(uint32_t *tile, const uint32_t *W) {
     static_assert(RBITS >= 4 && RBITS <= 8, "digit widths");
+    // value bound entering the closing product: after RBITS / 2 groups (and a trailing stage for odd widths: 2 V + 1)
+    constexpr uint32_t A_CLOSE = (RBITS & 1) ? 2u * lazy::bound(RBITS / 2) + 1u : lazy::bound(RBITS / 2);
+    static_assert(lazy::closing_bound_x169(A_CLOSE) < 4u * 169u, "closing product must return < 4 P (Fr29::to_canonical_fe)");
+    static_assert(2u * lazy::bound(RBITS / 2) + 1u <= 2u * 469u + 1u, "tile values stay within the limb headroom stated above");
     lazy_stage2<NCOLS, 0>(tile, W, RBITS);
     __syncthreads();
     lazy_stage2<NCOLS, 1>(tile, W, RBITS);
@@ -472,6 +481,7 @@ struct Plan {
     fe_t scale;                                          // n^-1 for ifft (small path only)
     fe_t *scratch = nullptr;                             // n elements (multi-pass ping buffer)
     hipEvent_t done = nullptr;                           // recorded behind the last transform that used `scratch` (see run)
+    std::mutex *mu = nullptr;                            // orders the transforms that share `scratch` (one per plan: other lengths do not wait)
     fe_t unit;                                           // the tables' common factor in Montgomery form: 1, or 2^5 (mul29)
 };
 
@@ -539,6 +549,7 @@ static Plan &get_plan(uint32_t log_n, bool inverse, hipStream_t st) {
         SRS_HIP_CHECK(hipMalloc((void **)&p.scratch, sizeof(fe_t) << log_n));
         SRS_HIP_CHECK(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
         SRS_HIP_CHECK(hipEventRecord(p.done, st));
+        p.mu = new std::mutex();
     }
     SRS_HIP_CHECK(hipStreamSynchronize(st));
     return g_plans.emplace(key, p).first->second;
@@ -559,6 +570,7 @@ void release_plans() {
         }
         if (kv.second.scratch) (void)hipFree(kv.second.scratch);
         if (kv.second.done) (void)hipEventDestroy(kv.second.done);
+        delete kv.second.mu;
     }
     g_plans.clear();
 }
@@ -635,11 +647,12 @@ void run(fe_t *a, uint32_t log_n, size_t stride, uint32_t batch, bool inverse, b
         return;
     }
     // A plan owns ONE ping buffer, and plans are shared by every caller of this length: the transforms that use it are ordered here -- the
-    // launches of one transform are issued under the lock (two host threads on one stream cannot interleave their passes) and a transform
-    // on another stream waits for the event recorded behind the previous one (r04: tests/test_commit_gpu.py::
-    // test_two_host_threads_distinct_handles caught two threads' 2^12 transforms sharing the buffer).
-    static std::mutex scratch_mu;
-    std::lock_guard<std::mutex> scratch_lock(scratch_mu);
+    // launches of one transform are issued under the PLAN's lock (two host threads on one stream cannot interleave their passes) and a
+    // transform on another stream waits for the event recorded behind the previous one of the same length (r04: tests/test_commit_gpu.py::
+    // test_two_host_threads_distinct_handles caught two threads' 2^12 transforms sharing the buffer).  r05: the lock is per plan, so
+    // transforms of different lengths (the primary's and the secondary's circuits on two streams) no longer serialise.
+    // release_plans() / srs_ntt_set_max_radix_bits must not run concurrently with transforms (they destroy the plans).
+    std::lock_guard<std::mutex> scratch_lock(*p.mu);
     SRS_HIP_CHECK(hipStreamWaitEvent(st, p.done, 0));
     for (uint32_t b = 0; b < batch; ++b) {
         fe_t *v = a + (size_t)b * stride;

@@ -28,6 +28,19 @@ def test_sangria_chain_digest_vs_oracle(srs, oracle, k, log_key, steps):
     assert CC.product_chain_sangria(srs, k, log_key, steps, from_host=True) == want
 
 
+def test_cyclefold_chain_digest_k20_vs_oracle(srs, oracle):
+    """The headline chain AT ITS OWN SIZE (BASELINE configs[2]: k = 20, key 2^24, support circuit k = 15,
+    src/ivc/cyclefold/support_circuit/mod.rs:68): one warm-up step + one step -- the 12 * 2^20 streamed commits in slot mode, the
+    3 * 2^15 + 2 x 2^15 grumpkin batch of srs_sangria_prove_incoming, F / G / K / e on 2^21 leaves, every Poseidon-derived challenge --
+    against the same chain on the oracle (oracle/chain.py, the C legs of compute_F / compute_G: ~15 s of CPU).  bench.py folds exactly
+    this chain, so its `state_digest` is tied to an oracle value through this test (and `bench.py --verify` prints both)."""
+    import os
+    import chain_cases as CC
+    threads = min(32, 2 * (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
+    want = CC.oracle_chain(oracle, srs, 20, 24, 15, 2, fast=True, threads=threads)
+    assert CC.product_chain(srs, 20, 24, 15, 2) == want
+
+
 def test_cyclefold_chain_true_rows_differs(srs, oracle):
     """the intended leaf rows (`--leaf-rows true`) fold a DIFFERENT chain: the switch is not a no-op"""
     import chain_cases as CC

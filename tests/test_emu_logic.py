@@ -384,6 +384,7 @@ def test_emu_chain_digest_vs_oracle():
         "import sirius_amd as S, oracle as O, chain_cases as CC\n"
         "a = CC.product_chain(S, 4, 8, 3, 2, emu=True); b = CC.oracle_chain(O, S, 4, 8, 3, 2)\n"
         "assert a == b, (a, b)\n"
+        "assert CC.oracle_chain(O, S, 4, 8, 3, 2, fast=True, threads=2) == b      # the C legs the k = 20 GPU test uses\n"
         "c = CC.product_chain(S, 4, 8, 3, 2, emu=True, split_support=True)\n"
         "assert c == b, (c, b)\n"
         "print('ok')\n")
@@ -452,7 +453,7 @@ SLOT_MODE_CODE = (
     "    for rep, kind in enumerate(('uniform', 'trace', 'trace', 'uniform', 'uniform')):\n"
     "        sc = seeded_scalars(O, cid, n, 20 + rep, kind)\n"
     "        assert np.array_equal(ck.commit_upload(sc), O.msm(cid, sc, bases[:n])), (cid, rep, kind)\n"
-    "    st = ck.msm_stats(); assert st['slot_sets'] >= 5 and st['hot_sets'] >= 2 and st['redo'] == 1, st\n"
+    "    st = ck.msm_stats(); assert st['slot_sets'] >= 5 and st['hot_sets'] >= 2 and st['redo'] == int(os.environ['REDO']), st\n"
     "    sc = seeded_scalars(O, cid, n, 31, 'trace'); assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases[:n]))      # a whole MSM (SRS_MSM_SLOTS=2: slot mode too)\n"
     "    vs = [seeded_scalars(O, cid, m, 40 + i, k) for i, (m, k) in enumerate(((n, 'trace'), (n // 2, 'uniform'), (7, 'trace')))]\n"
     "    for g, v in zip(ck.commit_batch(vs), vs): assert np.array_equal(g, O.msm(cid, v, bases[:len(v)]))\n"
@@ -466,13 +467,16 @@ def test_emu_slot_mode_commits():
     """msm.hip slot mode (r04): persistent per-bucket partial sums across the chunks of a streamed commit, the part length chosen on the
     device, parts beyond the slots through the level kernels into the last slot, the per-key prediction with its redo -- forced onto
     small inputs: 4, 8 and 32 slots per bucket (so that hot buckets overflow), three chunks, both sort paths, whole MSMs and batches in slot mode
-    (SRS_MSM_SLOTS=2), against the oracle; msm_stats must show the hot sets and exactly one redo per key."""
+    (SRS_MSM_SLOTS=2), against the oracle; msm_stats must show the hot sets and exactly one redo per key that starts cold, none for one that
+    starts with the default prediction."""
     import sys
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
     jobs = []
-    for tag, slot_log, sort, n, curves in (("s2", "2", "1", "5000", "0"), ("s2g", "2", "2", "3000", "1"), ("s3", "3", "2", "4000", "1"),
-                                           ("s5", "5", "2", "4200", "0")):
-        env = dict(os.environ, SRS_MSM_SLOTS="2", SRS_MSM_SLOT_LOG=slot_log, SRS_MSM_SORT=sort, SRS_COMMIT_CHUNKS="3", N=n, CURVES=curves)
+    # a new key EXPECTS hot buckets (r05): no commit runs twice; SRS_MSM_EXPECT_OVF=0 starts cold, so that the redo path stays covered
+    for tag, slot_log, sort, n, curves, cold in (("s2", "2", "1", "5000", "0", "0"), ("s2g", "2", "2", "3000", "1", "0"), ("s3", "3", "2", "4000", "1", "0"),
+                                                 ("s5", "5", "2", "4200", "0", "0"), ("s3warm", "3", "2", "3100", "0", "1")):
+        env = dict(os.environ, SRS_MSM_SLOTS="2", SRS_MSM_SLOT_LOG=slot_log, SRS_MSM_SORT=sort, SRS_COMMIT_CHUNKS="3", N=n, CURVES=curves,
+                   SRS_MSM_EXPECT_OVF=cold, REDO="1" if cold == "0" else "0")
         jobs.append((tag, [sys.executable, "-c", SLOT_MODE_CODE], env))
     for tag, r in _run_all(jobs).items():
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stdout[-500:], r.stderr[-1500:])

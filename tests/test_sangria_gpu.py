@@ -140,6 +140,39 @@ def test_fold_step_device_resident_k17_properties(srs, oracle):
     assert np.array_equal(commits[0], O.msm(curve, terms[0].cpu().numpy().view(np.uint64), bases[:rows]))
 
 
+@pytest.mark.parametrize("which,seed", [("primary", 2), ("secondary", 3)])
+def test_sangria_config_k17_vs_oracle(srs, oracle, which, seed):
+    """BASELINE configs[1] at FULL size, directly against the oracle (VanillaFS::commit_cross_terms, src/nifs/sangria/mod.rs:102-158):
+    all 6 (primary, bn256) / 5 (secondary, grumpkin) cross-term vectors of 2^17 rows and their commitments over the bench's own
+    2^21 key == the literal GroupedPoly + GraphEvaluator oracle and best_multiexp; then the witness / error folds."""
+    import os
+    import torch
+    from workloads import sangria_shape
+    O = oracle
+    threads = min(32, 2 * (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
+    k = 17
+    w = make_structure_inputs(which, k, seed=0x5349524955530000 + seed)            # bench.py's extras_sangria inputs
+    field, curve, rows, nadv = w["field"], w["curve"], w["rows"], w["num_advice"]
+    S = srs.PlonkStructure(field, k, [], w["fixed"], nadv, w["gates"])
+    ck = srs.CommitmentKey.setup_synthetic(curve, 1 << 21, seed=42 + curve)
+    bases = ck.bases()
+    dev = lambda a: torch.from_numpy(a.view(np.int64)).cuda()
+    W1, W2, E = dev(w["W1"]), dev(w["W2"]), dev(w["E"])
+    terms, commits = srs.VanillaFS.commit_cross_terms(ck, S, w["u1_challenges"], w["u1_u"], W1, w["u2_challenges"], W2)
+    ch = srs.VanillaFS.cross_term_challenges(w["u1_challenges"], w["u1_u"], w["u2_challenges"], field)
+    cg, exp = OE.cross_terms_oracle(O, field, _oracle_gates(sangria_shape(which)["gate_T"]), 0, w["num_fixed"], nadv, [], w["fixed"],
+                                    w["W1"], w["W2"], ch, threads)
+    assert len(terms) == len(exp) == cg.degree == (6 if which == "primary" else 5)
+    for i, (t, e) in enumerate(zip(terms, exp)):
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), e), f"{which}: cross term {i + 1}"
+        assert np.array_equal(commits[i], O.msm(curve, e, bases[:rows], threads)), f"{which}: commitment of cross term {i + 1}"
+    acc = srs.RelaxedPlonkWitness(field, [W1], E).fold([W2], terms, w["r"])
+    assert np.array_equal(acc.W[0].cpu().numpy().view(np.uint64), O.fold_w(field, w["W1"], w["W2"], w["r"], threads))
+    assert np.array_equal(acc.E.cpu().numpy().view(np.uint64), O.fold_e(field, w["E"], exp, w["r"], threads))
+    assert np.array_equal(ck.commit(W2), O.msm(curve, w["W2"], bases[: nadv * rows], threads))
+    S.close(); ck.close()
+
+
 def _is_sat_case(S, O, field=0, k=6, gate_T=(5, 3)):
     """Deciders' gate check (src/plonk/mod.rs:329-346, src/nifs/sangria/mod.rs:352-376): mismatch counts vs the oracle."""
     from workloads import rand_fe
