@@ -852,6 +852,14 @@ def main():
             }
             if verify is not None:
                 out["verify"] = verify
+            if D.multi:      # in-library multi-device path: what every link carried (srs_ck_shard_stats; logical shards report the traffic of a real node)
+                sts = [pri.ck.shard_stats(j) for j in range(pri.ck.num_shards)]
+                commits = max(1, sts[0]["streamed_commits"])
+                out["multi_device"] = {"shards": pri.ck.num_shards, "streamed_commits": commits,
+                                       "h2d_bytes_per_commit": [x["h2d_bytes"] // commits for x in sts],
+                                       "peer_bytes_per_commit": [x["peer_bytes"] // commits for x in sts], "devices": [x["device"] for x in sts],
+                                       "note": "every shard uploads ITS stripes of the witness over its own link (1 / shards of 12 * 2^k * 32 B), overlapped with "
+                                               "its MSM; the device copy for the next prove is assembled on device 0 by peer copies (xGMI)"}
             if args.witness != "bench":
                 out["config"]["witness"] = ("SURVEY.md 8d(ii) mixture as canonical values: 55 % zero, 20 % bits, 15 % < 2^64, 10 % uniform (~2.3 bucket "
                                             "additions per scalar; bucket 0 of window 0 hot in every chunk)")

@@ -175,6 +175,13 @@ int srs_ck_msm_stats(const srs_ck *ck, uint64_t *out4);
  * device-resident MSMs of >= 2^23 scalars use it), 0 when it does not -- by size, by SRS_MSM_WIDE=0, or because the device could not hold
  * it (the key then works on the 16-bit windows alone).  Multi-device keys: 1 when every shard holds it. */
 int srs_ck_has_wide_table(const srs_ck *ck);
+/* Diagnostics of ONE shard of a multi-device key (shard < srs_ck_num_shards): out[0] = bytes its streamed commits brought up from host
+ * memory over the shard's own link (srs_commit_upload on a multi-device key sends every shard ITS block-cyclic stripes only: n * 32 /
+ * shards bytes per commit and link, in chunks that overlap the shard's MSM), out[1] = bytes it forwarded to the process's device to
+ * assemble the device copy the caller asked for (peer copies; 0 for the shard that lives there), out[2] = streamed commits it took part
+ * in, out[3] = the HIP device ordinal it runs on.  A single-device key has one shard with zeros.  Lets a one-GPU box (logical shards)
+ * assert the traffic a multi-GPU node would see. */
+int srs_ck_shard_stats(const srs_ck *ck, int shard, uint64_t *out4);
 
 /* out = sum of `n` affine points (host); combines per-rank partial commitments. */
 int srs_point_sum(int curve, const srs_affine *points, size_t n, srs_affine *out);

@@ -48,6 +48,7 @@ def _prototypes():
         "srs_ck_num_shards": (i32, [vp]),
         "srs_ck_msm_stats": (i32, [vp, C.POINTER(C.c_uint64)]),
         "srs_ck_has_wide_table": (i32, [vp]),
+        "srs_ck_shard_stats": (i32, [vp, i32, C.POINTER(C.c_uint64)]),
         "srs_structure_kernel_kind": (i32, [vp, i32]),
         "srs_ck_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "srs_ck_create_sharded": (i32, [i32, vp, sz, i32, u32, u32, C.POINTER(vp)]),

@@ -117,6 +117,12 @@ class CommitmentKey:
         L.check(L.lib().srs_ck_msm_stats(self._h, out))
         return dict(slot_sets=int(out[0]), hot_sets=int(out[1]), redo=int(out[2]), other_sets=int(out[3]))
 
+    def shard_stats(self, shard):
+        """dict(h2d_bytes, peer_bytes, streamed_commits, device) of one shard of a multi-device key (srs_ck_shard_stats)."""
+        out = (C.c_uint64 * 4)()
+        L.check(L.lib().srs_ck_shard_stats(self._h, shard, out))
+        return dict(h2d_bytes=int(out[0]), peer_bytes=int(out[1]), streamed_commits=int(out[2]), device=int(out[3]))
+
     def has_wide_table(self):
         """True when the key holds the second (20-bit-window) table (srs_ck_has_wide_table)."""
         return bool(L.lib().srs_ck_has_wide_table(self._h))

@@ -66,6 +66,14 @@ struct CkShard {
     msm::Key key;
     Arena staging;
     hipStream_t stream = nullptr;
+    // streamed commits on a multi-device key (r05, multi_commit_streamed): the shard's stripes come up over ITS link in chunks that overlap ITS
+    // MSM; `full` = a vector-sized landing buffer on the shard's device in which only the shard's stripes are ever filled
+    hipStream_t copy_stream = nullptr, sort_stream = nullptr, peer_stream = nullptr;
+    std::vector<hipEvent_t> events;
+    hipEvent_t peer_done = nullptr;
+    fe_t *full = nullptr;
+    size_t full_cap = 0;
+    uint64_t stat_h2d_bytes = 0, stat_peer_bytes = 0, stat_streamed = 0;
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv, done_cv;
@@ -398,6 +406,12 @@ void free_shards(srs_ck *ck) {
         if (sh->key.table) (void)hipFree(sh->key.table);
         msm::release(sh->key);
         sh->staging.release();
+        if (sh->full) (void)hipFree(sh->full);
+        for (hipEvent_t e : sh->events) (void)hipEventDestroy(e);
+        if (sh->peer_done) (void)hipEventDestroy(sh->peer_done);
+        if (sh->copy_stream) (void)hipStreamDestroy(sh->copy_stream);
+        if (sh->sort_stream) (void)hipStreamDestroy(sh->sort_stream);
+        if (sh->peer_stream) (void)hipStreamDestroy(sh->peer_stream);
         if (sh->stream) (void)hipStreamDestroy(sh->stream);
     }
     ck->shards.clear();
@@ -793,6 +807,23 @@ int srs_ck_msm_stats(const srs_ck *ck, uint64_t *out) {
     return SRS_OK;
 }
 
+int srs_ck_shard_stats(const srs_ck *ck, int shard, uint64_t *out) {
+    if (!ck || !out || shard < 0) return fail(SRS_ERR_INVALID, "srs_ck_shard_stats: bad argument");
+    for (int i = 0; i < 4; ++i) out[i] = 0;
+    if (ck->shards.empty()) {
+        if (shard != 0) return fail(SRS_ERR_INVALID, "srs_ck_shard_stats: no such shard");
+        out[3] = (uint64_t)(g_device < 0 ? 0 : g_device);
+        return SRS_OK;
+    }
+    if ((size_t)shard >= ck->shards.size()) return fail(SRS_ERR_INVALID, "srs_ck_shard_stats: no such shard");
+    const CkShard *sh = ck->shards[shard].get();
+    out[0] = sh->stat_h2d_bytes;
+    out[1] = sh->stat_peer_bytes;
+    out[2] = sh->stat_streamed;
+    out[3] = (uint64_t)sh->device;
+    return SRS_OK;
+}
+
 int srs_ck_has_wide_table(const srs_ck *ck) {
     if (!ck) return 0;
     if (ck->shards.empty()) return ck->key.table_w != nullptr ? 1 : 0;
@@ -909,8 +940,24 @@ void upload_range(fe_t *dst, const std::vector<Seg> &segs, size_t a, size_t b, h
 // stream while the MSM of chunk j - 1 runs on the caller's stream; `cuts` = chunk boundaries (element offsets, first 0, last n)
 // A key sharded over processes (world > 1; one contiguous source, chunk boundaries multiples of world * 2^10): every chunk brings up and
 // accumulates only THIS rank's block-cyclic stripes of its range -- the same overlap of upload and MSM, 1 / world of both per rank.
-int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const std::vector<size_t> &cut, fe_t *dst, int repr,
-                    hipStream_t st, srs_affine *out) {
+// The stream resources of whoever runs the commit -- a single-device key handle, or one shard of a multi-device key -- and, for a
+// shard, where its stripes are forwarded once they are in its HBM (the device copy the caller asked for lives on the process's device).
+struct StreamRes {
+    msm::Key &key;
+    hipStream_t &copy_stream, &sort_stream;
+    std::vector<hipEvent_t> &events;
+    uint64_t *h2d_bytes = nullptr;        // statistics: bytes this commit brought up from host memory
+    // peer forwarding (multi-device keys): every uploaded chunk's stripes are copied from `dst` (this device) to the same positions of
+    // `peer_dst` (the process's device) on `peer_stream`, behind the chunk's upload
+    fe_t *peer_dst = nullptr;
+    hipStream_t peer_stream = nullptr;
+    uint64_t *peer_bytes = nullptr;
+};
+
+// -> the commitment as an XYZZ point (the caller normalises: a multi-device key adds its shards' partial sums first)
+int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, const std::vector<size_t> &cut, fe_t *dst, int repr,
+                         hipStream_t st, xyzz_t *sum_out) {
+    StreamRes *ck = &ck_;
     HostTrace ht("commit_streamed");
     const size_t chunks = cut.size() - 1;
     const uint32_t W = ck->key.world, R = ck->key.rank;
@@ -962,6 +1009,20 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
                 SRS_HIP_CHECK(hipMemcpyAsync(d + full * SL, src + full * SL, (len % SL) * sizeof(fe_t), hipMemcpyHostToDevice, ck->copy_stream));
         }
         SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
+        if (ck->h2d_bytes) *ck->h2d_bytes += (W == 1 ? cut[j + 1] - cut[j] : local(cut[j], cut[j + 1])) * sizeof(fe_t);
+        if (ck->peer_dst && W > 1) {         // the same stripes, from this device's landing buffer to the process's device copy
+            SRS_HIP_CHECK(hipStreamWaitEvent(ck->peer_stream, ck->events[j], 0));
+            const size_t len = cut[j + 1] - cut[j], full = len / SL;
+            const size_t mine = full > R ? (full - R + W - 1) / W : 0;
+            const fe_t *d = dst + cut[j];
+            fe_t *pd = ck->peer_dst + cut[j];
+            if (mine)
+                SRS_HIP_CHECK(hipMemcpy2DAsync(pd + R * SL, W * SL * sizeof(fe_t), d + R * SL, W * SL * sizeof(fe_t), SL * sizeof(fe_t), mine,
+                                               hipMemcpyDeviceToDevice, ck->peer_stream));
+            if (len % SL && full % W == R)
+                SRS_HIP_CHECK(hipMemcpyAsync(pd + full * SL, d + full * SL, (len % SL) * sizeof(fe_t), hipMemcpyDeviceToDevice, ck->peer_stream));
+            if (ck->peer_bytes) *ck->peer_bytes += local(cut[j], cut[j + 1]) * sizeof(fe_t);
+        }
     };
     auto launch = [&](size_t j) {
         const fe_t *ptr = dst + cut[j];
@@ -1019,13 +1080,25 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
             acc = Ec<C>::add(acc, part);
         }
         if (missed) acc = redo;
-        affine_t a = Ec<C>::to_affine(acc);
-        std::memcpy(out, &a, sizeof(a));
+        *sum_out = acc;
     };
     if (ck->key.curve == SRS_CURVE_BN256) go(Bn256{}); else go(Grumpkin{});
     ht.mark("host finish");
     prof::collect();
     ht.mark("prof");
+    return SRS_OK;
+}
+
+// single-device (or process-sharded) key handle: the commit on the handle's own resources, normalised
+int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const std::vector<size_t> &cut, fe_t *dst, int repr,
+                    hipStream_t st, srs_affine *out) {
+    xyzz_t sum;
+    StreamRes r{ck->key, ck->copy_stream, ck->sort_stream, ck->events};
+    int rc = commit_streamed_core(r, segs, n, cut, dst, repr, st, &sum);
+    if (rc) return rc;
+    affine_t a;
+    to_affine_batch(ck->key.curve, &sum, &a, 1);
+    std::memcpy(out, &a, sizeof(a));
     return SRS_OK;
 }
 
@@ -1076,6 +1149,85 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
     cut.push_back(n);
     return cut;
 }
+
+// srs_commit_upload on a MULTI-DEVICE key (r05; VERDICT r04 "missing" 2): every shard brings up ITS block-cyclic stripes of the host
+// vector over ITS link -- n * 32 / shards bytes each, once -- in chunks whose upload overlaps the shard's own MSM of the chunks already in
+// its HBM (commit_streamed_core, the process-sharded form: the stripes land at their global positions of a vector-sized buffer on the
+// shard's device).  The device copy the caller asked for lives on the process's device: shard 0 (same device) uploads straight into it, the
+// other shards forward their stripes to it with peer copies behind their uploads (xGMI on a multi-GPU node) -- the whole witness never
+// crosses ONE link, and nothing is uploaded twice.  The caller's stream waits for the forwarded stripes; the partial sums are added here.
+int multi_commit_streamed(srs_ck *ck, const fe_t *host, size_t n, fe_t *dev_copy, int repr, hipStream_t st, srs_affine *out) {
+    const uint32_t world = (uint32_t)ck->shards.size();
+    const int home = g_device < 0 ? 0 : g_device;
+    const size_t align = (size_t)world << msm::STRIPE_LOG;
+    const std::vector<size_t> cut = commit_cuts(n, align, n / world);
+    std::vector<Seg> segs(1, Seg{host, 0, n});
+    std::vector<xyzz_t> parts(world);
+    hipEvent_t ready = nullptr;
+    if (dev_copy) {                              // nothing may land in the device copy while earlier work on the caller's stream still reads it
+        if (ck->events.empty()) { hipEvent_t e; SRS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ck->events.push_back(e); }
+        ready = ck->events[0];
+        SRS_HIP_CHECK(hipEventRecord(ready, st));
+    }
+    for (uint32_t d = 0; d < world; ++d) {
+        CkShard *sh = ck->shards[d].get();
+        sh->post([=, &parts, &segs, &cut]() {
+            const bool direct = dev_copy && sh->device == home && d == 0;          // shard 0 lands in the caller's device copy itself
+            fe_t *dst = dev_copy;
+            if (!direct) {
+                if (sh->full_cap < n) {
+                    if (sh->full) SRS_HIP_CHECK(hipFree(sh->full));
+                    sh->full = nullptr;
+                    sh->full_cap = 0;
+                    SRS_HIP_CHECK(hipMalloc((void **)&sh->full, n * sizeof(fe_t)));
+                    sh->full_cap = n;
+                }
+                dst = sh->full;
+            }
+            if (dev_copy && !direct) {
+                if (!sh->peer_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&sh->peer_stream, hipStreamNonBlocking));
+                if (!sh->peer_done) SRS_HIP_CHECK(hipEventCreateWithFlags(&sh->peer_done, hipEventDisableTiming));
+                SRS_HIP_CHECK(hipStreamWaitEvent(sh->peer_stream, ready, 0));
+            } else if (direct) {
+                SRS_HIP_CHECK(hipStreamWaitEvent(sh->stream, ready, 0));           // (the core orders its copy stream behind sh->stream)
+            }
+            StreamRes r{sh->key, sh->copy_stream, sh->sort_stream, sh->events};
+            r.h2d_bytes = &sh->stat_h2d_bytes;
+            if (dev_copy && !direct) {
+                r.peer_dst = dev_copy;
+                r.peer_stream = sh->peer_stream;
+                r.peer_bytes = &sh->stat_peer_bytes;
+            }
+            // the shard's kernels read ITS stripes at their global positions (the process-sharded layout), not a gathered vector
+            struct Restore { msm::Key &k; bool v; ~Restore() { k.compact_scalars = v; } } restore{sh->key, sh->key.compact_scalars};
+            sh->key.compact_scalars = false;
+            ++sh->stat_streamed;
+            int rc = commit_streamed_core(r, segs, n, cut, dst, repr, sh->stream, &parts[d]);
+            if (rc) throw DeviceError{rc};
+            if (dev_copy && !direct) SRS_HIP_CHECK(hipEventRecord(sh->peer_done, sh->peer_stream));
+        });
+    }
+    int rc = SRS_OK;
+    std::string err;
+    for (uint32_t d = 0; d < world; ++d) {
+        int r = ck->shards[d]->wait();
+        if (r && !rc) { rc = r; err = ck->shards[d]->err; }
+    }
+    if (rc) return fail(rc, "multi-device streamed commit: " + err);
+    for (uint32_t d = 0; d < world && dev_copy; ++d) {
+        CkShard *sh = ck->shards[d].get();
+        const bool direct = sh->device == home && d == 0;
+        if (!direct && sh->peer_done) SRS_HIP_CHECK(hipStreamWaitEvent(st, sh->peer_done, 0));   // the caller's stream sees the whole device copy
+    }
+    xyzz_t sum;
+    std::vector<std::vector<xyzz_t>> pv(world, std::vector<xyzz_t>(1));
+    for (uint32_t d = 0; d < world; ++d) pv[d][0] = parts[d];
+    if (ck->key.curve == SRS_CURVE_BN256) sum_partials_t<Bn256>(pv, 1, &sum); else sum_partials_t<Grumpkin>(pv, 1, &sum);
+    affine_t a;
+    to_affine_batch(ck->key.curve, &sum, &a, 1);
+    std::memcpy(out, &a, sizeof(a));
+    return SRS_OK;
+}
 }  // namespace
 
 int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *dev_copy, int repr, void *stream, srs_affine *out) {
@@ -1098,8 +1250,16 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
             return commit_streamed(ck, segs, n, commit_cuts(n, align, n / ck->key.world), reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
         });
     }
+    static const bool multi_streamed = [] { const char *e = std::getenv("SRS_MULTI_STREAMED"); return !(e && e[0] == '0'); }();
+    if (!ck->shards.empty() && multi_streamed && n >= ((size_t)ck->shards.size() << (msm::STRIPE_LOG + 1))) {
+        // multi-device key: every shard streams its stripes over its own link, overlapped with its MSM; the device copy is assembled on the
+        // process's device by peer copies (multi_commit_streamed).  SRS_MULTI_STREAMED=0: the r04 path below (A/B)
+        return guarded([&]() -> int {
+            return multi_commit_streamed(ck, reinterpret_cast<const fe_t *>(scalars_host), n, reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
+        });
+    }
     if (!ck->shards.empty() || ck->key.world != 1 || n == 0) {
-        // multi-device key: every shard pulls its stripes from the host buffer over its own link; sharded (process-per-GPU)
+        // (short vectors on a multi-device key) every shard pulls its stripes from the host buffer over its own link; sharded (process-per-GPU)
         // key without a device copy: the kernels pick this rank's stripes out of the full vector.
         if (dev_copy && n) {
             rc = guarded([&]() -> int {

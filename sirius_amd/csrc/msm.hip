@@ -426,11 +426,23 @@ static_assert(SORT_TILE2 == SORT_THREADS * S2_PER, "k_scatter2: one tile = S2_PE
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
     k_scatter2(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ gpay, size_t g_stride,
                const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t *__restrict__ cursor /* [batch][NBUCKET] */,
-               uint32_t *__restrict__ sorted, size_t sorted_stride, uint32_t TILE2) {
+               uint32_t *__restrict__ sorted, size_t sorted_stride, uint32_t TILE2, uint16_t *__restrict__ tb, size_t tb_stride, uint32_t arr) {
     __shared__ uint32_t cnt[S2_RANGE], lb[S2_RANGE], gb[S2_RANGE], sc[64];
     __shared__ uint32_t spay[SORT_TILE2];
     __shared__ uint16_t skey[SORT_TILE2];
     const uint32_t m = blockIdx.y, tid = threadIdx.x;
+    if (tb) {
+        // sort v2: the thread -> bucket map of level 0 (k_expand's work, from the plan array `arr`) rides on this launch, a bucket per
+        // wavefront and round (in the r04 flow it rode on k_group's launch, which v2 runs BEFORE the plan)
+        const uint32_t *tp = plan + (size_t)m * plan_stride + (size_t)arr * (NBUCKET + 1);
+        uint16_t *map = tb + (size_t)m * tb_stride;
+        const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+        const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (tid >> 6), lane = tid & 63u;
+        for (uint32_t b = wv; b < NBUCKET; b += waves) {
+            const uint32_t s0 = tp[b], e0 = tp[b + 1];
+            for (uint32_t t = s0 + lane; t < e0; t += 64) map[t] = (uint16_t)b;
+        }
+    }
     const uint32_t total = plan[(size_t)m * plan_stride + NBUCKET];        // number of non-zero digits of this MSM
     // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
     // takes tile (b % 8) * ceil(tiles / 8) + b / 8 -- every XCD sorts one contiguous eighth of the grouped array, i.e.
@@ -493,6 +505,192 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
     for (uint32_t i = tid; i < n_tile; i += blockDim.x) {
         const uint32_t b = skey[i];
         out[gb[b] + (i - lb[b])] = spay[i];
+    }
+}
+
+// ---- r05: the two-pass sort WITHOUT a digit array and without the 2^15-counter flush ("sort v2") ------------------------------------
+// The r03 flow stores 16 digits per scalar (k_digits: 32 B written, then read twice) and counts the entries of every bucket in k_hist,
+// whose workgroups each flush a 2^15-counter LDS histogram through global atomics -- 25 of its 33 us per launch, ten launches per streamed
+// commit.  Here the digits are RECOMPUTED from the scalar by the two kernels that need them (32 B read either way, one Montgomery product
+// per scalar), the first pass only counts per SEGMENT (128 counters), and the per-bucket counts are taken from the GROUPED array, where a
+// tile of 8192 entries spans a few hundred consecutive buckets: an LDS histogram of <= 512 counters and as many global atomics per tile.
+//   k_seghist  : scalars -> entries of the tile per segment (tile_hist); clears the bucket counters
+//   k_scan_seg2: per-tile segment counts -> offsets into the grouped array (segment bases from the counts themselves), seg_off[]
+//   k_group2   : scalars -> entries grouped by segment (k_group's LDS sort; one scalar = 16 digit slots per thread and sub-tile)
+//   k_count    : grouped entries -> count[bucket]
+//   (k_plan / k_plan_s, then k_scatter2 as before; the thread -> bucket map rides on k_scatter2's launch)
+template <class C>
+__device__ __forceinline__ void scalar_codes(const fe_t *__restrict__ ptr, uint32_t i, int is_mont, uint32_t rank, uint32_t world,
+                                             uint32_t (&code)[NWIN]) {
+    using S = typename C::S;
+    fe_t s = ptr[shard_global_index(i, rank, world)];
+    if (is_mont) s = S::from_mont(s);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w) {
+        const uint32_t raw = (s.v[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu;
+        const uint32_t v = raw + carry;
+        if (v > 0x8000u) {
+            code[w] = (((0x10000u - v) - 1u) | 0x8000u) & 0xFFFFu;   // negative digit, magnitude 1..0x7FFF (v = 2^16: zero digit 0xFFFF, carry)
+            carry = 1;
+        } else {
+            code[w] = v ? (v - 1u) : 0xFFFFu;            // positive digit 1..0x8000, or zero
+            carry = 0;
+        }
+    }
+}
+
+constexpr uint32_t SEGHIST_THREADS = 256;
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(SEGHIST_THREADS, 1)
+    k_seghist(BatchDesc bd, int is_mont, uint32_t rank, uint32_t world, uint32_t tile_s, uint32_t *__restrict__ tile_hist /* [batch][SEG][tiles] */,
+              uint32_t *__restrict__ count_zero, uint32_t n_zero) {
+    constexpr uint32_t NW = SEGHIST_THREADS / 64;
+    __shared__ uint32_t cnt[NW][SEG];              // per wavefront: an atomic only meets the lanes of its own wavefront
+    const uint32_t m = blockIdx.y, tid = threadIdx.x, wave = tid >> 6;
+    for (uint32_t j = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + tid; j < n_zero; j += gridDim.x * gridDim.y * blockDim.x) count_zero[j] = 0;
+    for (uint32_t j = tid; j < NW * SEG; j += blockDim.x) (&cnt[0][0])[j] = 0;
+    __syncthreads();
+    const uint32_t n = bd.n[m], lo = blockIdx.x * tile_s;
+    const uint32_t hi = lo + tile_s < n ? lo + tile_s : n;
+    for (uint32_t i = lo + tid; i < hi; i += blockDim.x) {
+        uint32_t code[NWIN];
+        scalar_codes<C>(bd.ptr[m], i, is_mont, rank, world, code);
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w)
+            if (code[w] != 0xFFFFu) atomicAdd(&cnt[wave][(code[w] & 0x7FFFu) / SEG_BUCKETS], 1u);
+    }
+    __syncthreads();
+    for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) {
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NW; ++w) c += cnt[w][sgm];
+        tile_hist[((size_t)m * SEG + sgm) * gridDim.x + blockIdx.x] = c;
+    }
+}
+
+// grid = (SEG, batch): workgroup `sgm` adds up the counts of all segments before its own (the segment's first entry in the grouped array),
+// then turns its own row into exclusive offsets.  seg_off[m][sgm] = that base; seg_off[m][SEG] = the MSM's number of entries.
+__global__ void SRS_KERNEL_BOUNDS(1024, 1)
+    k_scan_seg2(const uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_off, uint32_t T1, uint32_t *__restrict__ seg_off) {
+    // (the offsets go to an array of their own: every workgroup reads the COUNTS of all segments before its own)
+    __shared__ uint32_t lds[64];
+    const uint32_t sgm = blockIdx.x, m = blockIdx.y;
+    const uint32_t *all = tile_hist + (size_t)m * SEG * T1;
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < sgm * T1; i += blockDim.x) part += all[i];
+    uint32_t base;
+    (void)block_exclusive_scan(part, lds, &base);
+    const uint32_t *row = tile_hist + ((size_t)m * SEG + sgm) * T1;
+    uint32_t *orow = tile_off + ((size_t)m * SEG + sgm) * T1;
+    uint32_t carry = 0;
+    for (uint32_t at = 0; at < T1; at += blockDim.x) {
+        const uint32_t i = at + threadIdx.x;
+        const uint32_t v = i < T1 ? row[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, lds, &total);
+        if (i < T1) orow[i] = base + carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        seg_off[(size_t)m * (SEG + 1) + sgm] = base;
+        if (sgm == SEG - 1) seg_off[(size_t)m * (SEG + 1) + SEG] = base + carry;
+    }
+}
+
+template <class C>
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
+    k_group2(BatchDesc bd, int is_mont, uint32_t rank, uint32_t world, uint32_t tile_s, const uint32_t *__restrict__ tile_off,
+             uint16_t *__restrict__ gkey, uint32_t *__restrict__ gpay, size_t g_stride, uint32_t table_stride) {
+    static_assert(GRP_PER == NWIN, "k_group2: a thread's GRP_PER digit slots are the NWIN windows of one scalar");
+    __shared__ uint32_t cur[SEG], cnt[SEG], lb[SEG], sc[64];
+    __shared__ uint32_t spay[GRP_SUB];
+    __shared__ uint16_t skey[GRP_SUB];
+    const uint32_t m = blockIdx.y, tid = threadIdx.x;
+    const uint32_t n = bd.n[m];
+    const uint32_t lo = blockIdx.x * tile_s;
+    if (lo >= n) return;
+    const uint32_t hi = lo + tile_s < n ? lo + tile_s : n;
+    const uint32_t T1 = gridDim.x;
+    for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cur[sgm] = tile_off[((size_t)m * SEG + sgm) * T1 + blockIdx.x];
+    uint16_t *ok = gkey + (size_t)m * g_stride;
+    uint32_t *op = gpay + (size_t)m * g_stride;
+    const uint32_t pay0 = bd.base[m];
+    for (uint32_t sub = lo; sub < hi; sub += SORT_THREADS) {            // workgroup-uniform: SORT_THREADS scalars = GRP_SUB digit slots
+        for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cnt[sgm] = 0;
+        __syncthreads();
+        const uint32_t i = sub + tid;
+        uint32_t code[NWIN], rank_[NWIN];
+        if (i < hi) {
+            scalar_codes<C>(bd.ptr[m], i, is_mont, rank, world, code);
+        } else {
+#pragma unroll
+            for (int w = 0; w < NWIN; ++w) code[w] = 0xFFFFu;
+        }
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) rank_[w] = code[w] != 0xFFFFu ? atomicAdd(&cnt[(code[w] & 0x7FFFu) / SEG_BUCKETS], 1u) : 0u;
+        __syncthreads();
+        uint32_t n_sub;
+        const uint32_t ex = block_exclusive_scan(tid < SEG ? cnt[tid] : 0u, sc, &n_sub);
+        if (tid < SEG) lb[tid] = ex;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            if (code[w] != 0xFFFFu) {
+                const uint32_t bkt = code[w] & 0x7FFFu, pos = lb[bkt / SEG_BUCKETS] + rank_[w];
+                skey[pos] = (uint16_t)bkt;
+                spay[pos] = ((uint32_t)w * table_stride + pay0 + i) | ((code[w] & 0x8000u) << 16);
+            }
+        }
+        __syncthreads();
+        for (uint32_t e = tid; e < n_sub; e += blockDim.x) {             // index order: a segment's run goes out as one contiguous piece
+            const uint32_t key = skey[e], sgm = key / SEG_BUCKETS, g = cur[sgm] + (e - lb[sgm]);
+            ok[g] = (uint16_t)key;
+            op[g] = spay[e];
+        }
+        __syncthreads();
+        if (tid < SEG) cur[tid] += cnt[tid];
+    }
+}
+
+// entries per bucket from the grouped array: same tiles (and XCD mapping) as k_scatter2.   grid = (8 * ceil(tiles / 8), batch)
+__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
+    k_count(const uint16_t *__restrict__ gkey, size_t g_stride, const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ count, uint32_t TILE2) {
+    __shared__ uint32_t cnt[S2_RANGE];
+    const uint32_t m = blockIdx.y, tid = threadIdx.x;
+    const uint32_t total = seg_off[(size_t)m * (SEG + 1) + SEG];
+    const uint32_t n_tiles = (total + TILE2 - 1) / TILE2, per_xcd = (n_tiles + 7) / 8;
+    if (blockIdx.x / 8 >= per_xcd) return;
+    const uint32_t tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile_id >= n_tiles) return;
+    const uint32_t lo = tile_id * TILE2;
+    if (lo >= total) return;
+    const uint32_t hi = lo + TILE2 < total ? lo + TILE2 : total;
+    const uint16_t *key = gkey + (size_t)m * g_stride;
+    uint32_t *out = count + (size_t)m * NBUCKET;
+    const uint32_t b_lo = ((uint32_t)key[lo] / SEG_BUCKETS) * SEG_BUCKETS;
+    const uint32_t b_hi = ((uint32_t)key[hi - 1] / SEG_BUCKETS + 1) * SEG_BUCKETS;
+    if (b_hi - b_lo > S2_RANGE) {            // a tile over more than two segments (few entries for the bucket range): entry by entry
+        for (uint32_t i = lo + tid; i < hi; i += blockDim.x) atomicAdd(&out[key[i]], 1u);
+        return;
+    }
+    for (uint32_t b = tid; b < S2_RANGE; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t i0 = lo + tid * S2_PER;
+    if (i0 + S2_PER <= hi && (reinterpret_cast<uintptr_t>(key + i0) & 15u) == 0) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(key + i0);
+        atomicAdd(&cnt[(x.x & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.x >> 16) - b_lo], 1u);
+        atomicAdd(&cnt[(x.y & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.y >> 16) - b_lo], 1u);
+        atomicAdd(&cnt[(x.z & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.z >> 16) - b_lo], 1u);
+        atomicAdd(&cnt[(x.w & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.w >> 16) - b_lo], 1u);
+    } else {
+        for (uint32_t k = 0; k < S2_PER; ++k)
+            if (i0 + k < hi) atomicAdd(&cnt[(uint32_t)key[i0 + k] - b_lo], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < S2_RANGE; b += blockDim.x) {
+        const uint32_t c = cnt[b];
+        if (c) atomicAdd(&out[b_lo + b], c);
     }
 }
 
@@ -972,11 +1170,11 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     // part counts of level l -- over all 2^15 buckets.  The arrays only depend on the counts (parts of level l = ceil(parts of level
     // l - 1 / 2^l1_log)), so the levels do not wait for each other (r03: one workgroup did them in turn, 45-55 us of pure latency
     // per MSM launch; now ~one round).  Every workgroup derives the number of levels actually needed the same way.
-    // Thread t owns PER consecutive buckets (registers), but
-    // global traffic goes through an LDS transposition so that every load/store instruction is
-    // coalesced (a single CU issuing 4-byte accesses at 128-byte stride was 5x slower than the scan).
+    // Thread t owns PER consecutive buckets.  r05: they stay in LDS (index i at i + i / PER: conflict-free for the owner's walk AND for the
+    // coalesced loads / stores) and are walked -- sum, then running prefix written in place -- instead of being held in 32 registers: the
+    // register form spilled 392 bytes per lane to scratch (31 us per launch; k_plan_s, which got this form in r04, takes 14).
     constexpr uint32_t PER = NBUCKET / PLAN_THREADS;             // 32
-    __shared__ uint32_t tile[NBUCKET + NBUCKET / PER];           // index i lives at i + i / PER: conflict-free both ways
+    __shared__ uint32_t tile[NBUCKET + NBUCKET / PER];
     __shared__ uint32_t lds[64];
     const uint32_t t = threadIdx.x;
     const uint32_t m = blockIdx.x;
@@ -984,78 +1182,84 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
     const uint32_t *cnt = count + (size_t)m * NBUCKET;
     uint32_t *cur = cursor + (size_t)m * NBUCKET;
     uint32_t *pl = plan + (size_t)m * plan_stride;
-    for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) tile[i + i / PER] = cnt[i];
-    __syncthreads();
-    uint32_t vals[PER];
-    const uint32_t base = t * PER;
+    {   // all 32 loads of a thread in flight at once (the counters were just written by another XCD's atomics: every load misses this L2)
+        uint32_t c[PER];
 #pragma unroll
-    for (uint32_t j = 0; j < PER; ++j) vals[j] = tile[base + j + t];
-    int needed = nlevels;
-    uint32_t total_entries = 0;
-    for (int level = -1; level <= my_level; ++level) {
-        // level -1: scan the raw counts (entry offsets); level >= 0: scan the part counts
-        if (level >= 0) {
-            uint32_t lg = level == 0 ? l0_log : l1_log;
-            uint32_t mx = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < PER; ++j) {
-                uint32_t p = (vals[j] + (1u << lg) - 1) >> lg;
-                vals[j] = p ? p : 1u;
-                mx = vals[j] > mx ? vals[j] : mx;
-            }
-            if (level == 0) {
-                // (a) the heaviest bucket must be down to <= FINAL_FANIN parts for the wave-level pass;
-                // (b) the TYPICAL bucket (2x the mean load) must be down to one part: the wave-level pass
-                //     spends a whole wavefront per bucket, so it must find real work only in outliers.
-                uint32_t p = block_max(mx, lds);
-                needed = 1;
-                while (p > FINAL_FANIN && needed < nlevels) {
-                    p = (p + (1u << l1_log) - 1) >> l1_log;
-                    ++needed;
-                }
-                uint32_t typical = (2u * total_entries + NBUCKET - 1) / NBUCKET;
-                uint32_t x = (typical + (1u << l0_log) - 1) >> l0_log;
-                int by_mean = 1;
-                while (x > 1 && by_mean < nlevels) {
-                    x = (x + (1u << l1_log) - 1) >> l1_log;
-                    ++by_mean;
-                }
-                needed = by_mean > needed ? by_mean : needed;
-                if (t == 0 && my_level == 0) pl[plan_stride - 4] = (uint32_t)needed;
-                if (my_level >= needed) return;                  // a level nobody runs (workgroup-uniform)
-            }
-        }
-        if (level != -1 && level != my_level) continue;          // only the counts' total and the own array need a scan
-        uint32_t local = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) local += vals[j];
-        uint32_t total;
-        uint32_t run = block_exclusive_scan(local, lds, &total);
-        if (level < 0) total_entries = total;
-        if (level != my_level) continue;
-        __syncthreads();                                         // the load of the counts has finished reading `tile`
+        for (uint32_t j = 0; j < PER; ++j) c[j] = cnt[t + j * PLAN_THREADS];
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {
-            tile[base + j + t] = run;
-            run += vals[j];
+            const uint32_t i = t + j * PLAN_THREADS;
+            tile[i + i / PER] = c[j];
         }
-        __syncthreads();
-        uint32_t *o = pl + (size_t)(level + 1) * (NBUCKET + 1);
-        const uint32_t shift = (level < 0 && seg_off) ? seg_off[m] : 0u;
-        for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) {
-            uint32_t v = tile[i + i / PER] + shift;
-            o[i] = v;
-            if (level < 0) cur[i] = v;
-        }
-        if (t == PLAN_THREADS - 1) o[NBUCKET] = total + shift;
     }
+    __syncthreads();
+    const uint32_t base = t * PER + t;
+    // parts of a bucket with c entries on level `level` (>= 1: an empty bucket still owns one, identity, part)
+    auto value = [&](uint32_t c, int level) -> uint32_t {
+        uint32_t p = (c + (1u << l0_log) - 1) >> l0_log;
+        p = p ? p : 1u;
+        for (int l = 0; l < level; ++l) p = (p + (1u << l1_log) - 1) >> l1_log;
+        return p;
+    };
+    uint32_t local = 0;
+#pragma unroll 8
+    for (uint32_t j = 0; j < PER; ++j) local += tile[base + j];
+    uint32_t total_entries;
+    uint32_t run = block_exclusive_scan(local, lds, &total_entries);
+    uint32_t total = total_entries;
+    int needed = nlevels;
+    if (my_level >= 0) {
+        // (a) the heaviest bucket must be down to <= FINAL_FANIN parts for the wave-level pass;
+        // (b) the TYPICAL bucket (2x the mean load) must be down to one part: the wave-level pass
+        //     spends a whole wavefront per bucket, so it must find real work only in outliers.
+        uint32_t mx = 0;
+#pragma unroll 8
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t v = value(tile[base + j], 0);
+            mx = v > mx ? v : mx;
+        }
+        uint32_t p = block_max(mx, lds);
+        needed = 1;
+        while (p > FINAL_FANIN && needed < nlevels) {
+            p = (p + (1u << l1_log) - 1) >> l1_log;
+            ++needed;
+        }
+        const uint32_t typical = (2u * total_entries + NBUCKET - 1) / NBUCKET;
+        uint32_t x = (typical + (1u << l0_log) - 1) >> l0_log;
+        int by_mean = 1;
+        while (x > 1 && by_mean < nlevels) {
+            x = (x + (1u << l1_log) - 1) >> l1_log;
+            ++by_mean;
+        }
+        needed = by_mean > needed ? by_mean : needed;
+        if (t == 0 && my_level == 0) pl[plan_stride - 4] = (uint32_t)needed;
+        if (my_level >= needed) return;                  // a level nobody runs (workgroup-uniform)
+        local = 0;
+#pragma unroll 8
+        for (uint32_t j = 0; j < PER; ++j) local += value(tile[base + j], my_level);
+        run = block_exclusive_scan(local, lds, &total);
+    }
+    uint32_t mx_own = 0;
+#pragma unroll 8
+    for (uint32_t j = 0; j < PER; ++j) {
+        const uint32_t c = tile[base + j], v = my_level < 0 ? c : value(c, my_level);
+        tile[base + j] = run;
+        run += v;
+        mx_own = v > mx_own ? v : mx_own;
+    }
+    __syncthreads();
+    uint32_t *o = pl + (size_t)(my_level + 1) * (NBUCKET + 1);
+    const uint32_t shift = (my_level < 0 && seg_off) ? seg_off[m] : 0u;
+    for (uint32_t i = t; i < NBUCKET; i += PLAN_THREADS) {
+        const uint32_t v = tile[i + i / PER] + shift;
+        o[i] = v;
+        if (my_level < 0) cur[i] = v;
+    }
+    if (t == PLAN_THREADS - 1) o[NBUCKET] = total + shift;
     // every bucket already a single part after the last level?  Then the wave-level pass is a pure copy:
     // k_accum_final exits and k_rowcol reads the last level's parts directly (part index == bucket index).
     if (my_level == needed - 1) {
-        uint32_t mx = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) mx = vals[j] > mx ? vals[j] : mx;
-        uint32_t p = block_max(mx, lds);
+        const uint32_t p = block_max(mx_own, lds);
         if (t == 0) pl[plan_stride - 3] = (p <= 1u) ? 1u : 0u;
     }
 }
@@ -1849,6 +2053,24 @@ static bool use_two_pass(uint64_t M, uint32_t batch) {
     return M * batch >= TWO_PASS_MIN_SLOTS;
 }
 
+// sort v2 (k_seghist / k_scan_seg2 / k_group2 / k_count: no digit array, no 2^15-counter flush) replaces the r04 two-pass flow wherever that
+// one ran; SRS_MSM_SORTV=1: the r04 flow everywhere (A/B), =2: v2 for EVERY set, the small single-pass ones too (tests; A/B of the threshold)
+static bool use_sort_v2(uint64_t M, uint32_t batch) {
+    static const int forced = [] { const char *e = std::getenv("SRS_MSM_SORTV"); return e ? std::atoi(e) : 0; }();
+    if (forced == 1) return false;
+    if (forced == 2) return true;
+    static const uint64_t min_slots = [] { const char *e = std::getenv("SRS_MSM_SORTV2_MIN"); return e ? (1ull << std::atoi(e)) : TWO_PASS_MIN_SLOTS; }();
+    static const int sort_forced = [] { const char *e = std::getenv("SRS_MSM_SORT"); return e ? std::atoi(e) : 0; }();
+    if (sort_forced == 1) return false;
+    return sort_forced == 2 || M * batch >= min_slots;
+}
+// scalars per workgroup of k_seghist / k_group2: ~SORT_TARGET_BLOCKS workgroups over the whole batch, whole sub-tiles of SORT_THREADS scalars
+static uint32_t sort_v2_tile(uint32_t n_max, uint32_t batch) {
+    uint32_t t = (uint32_t)(((uint64_t)n_max * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
+    t = (t + SORT_THREADS - 1) / SORT_THREADS * SORT_THREADS;
+    return t < SORT_THREADS ? SORT_THREADS : t;
+}
+
 size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     uint64_t M = (uint64_t)n_max * NWIN;
     int levels = levels_for(M);
@@ -1865,9 +2087,11 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     per += Arena::pad(parts1 * sizeof(xyzz_t));              // pong
     per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
-    if (use_two_pass(M, batch)) {
+    if (use_two_pass(M, batch) || use_sort_v2(M, batch)) {
         per += Arena::pad(M * sizeof(uint16_t)) + Arena::pad(M * sizeof(uint32_t));                     // grouped keys / payloads
         per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));            // per-tile segment counts
+        per += Arena::pad((SEG + 1) * sizeof(uint32_t));                                                // segment offsets (sort v2)
+        per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));            // per-tile segment offsets (sort v2)
     }
     return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 4096;
 }
@@ -1901,10 +2125,12 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     xyzz_t *pong = A.take<xyzz_t>(parts1_cap * batch);
     xyzz_t *buckets = A.take<xyzz_t>((size_t)NBUCKET * batch);
     xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
-    const bool two_pass = use_two_pass(M, batch);
+    const bool v2 = use_sort_v2(M, batch), two_pass = v2 || use_two_pass(M, batch);
     uint16_t *gkey = two_pass ? A.take<uint16_t>(M * batch) : nullptr;
     uint32_t *gpay = two_pass ? A.take<uint32_t>(M * batch) : nullptr;
     uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
+    uint32_t *seg_off = v2 ? A.take<uint32_t>((size_t)(SEG + 1) * batch) : nullptr;
+    uint32_t *tile_off = v2 ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
 
     BatchDesc bd;
     for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
@@ -1912,14 +2138,31 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
         bd.n[m] = m < batch ? n_host[m] : 0;
         bd.base[m] = (m < batch && base_host) ? base_host[m] : 0;
     }
-    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont,
-               k.compact_scalars ? 0u : k.rank, k.compact_scalars ? 1u : k.world, count, (uint32_t)(NBUCKET * batch));
+    const uint32_t s_rank = k.compact_scalars ? 0u : k.rank, s_world = k.compact_scalars ? 1u : k.world;
     // tile = digits per workgroup: large enough that the fixed 2^15-bin zero/scan of the LDS histogram is
     // amortised, small enough to give ~SORT_TARGET_BLOCKS workgroups (one per CU, 128 KiB LDS each)
     uint32_t tile = (uint32_t)(((uint64_t)n_max * NWIN * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
     tile = (tile + 1023u) & ~1023u;
     if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
     const uint32_t tiles = ceil_div(n_max, tile);
+    const Link *no_link = nullptr;
+    if (v2) {
+        const uint32_t tile_s = sort_v2_tile(n_max, batch), tiles_s = ceil_div(n_max, tile_s);
+        SRS_LAUNCH((k_seghist<C>), (tiles_s, batch), (SEGHIST_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, tile_hist, count,
+                   (uint32_t)(NBUCKET * batch));
+        SRS_LAUNCH(k_scan_seg2, (SEG, batch), (1024), 0, stream, (const uint32_t *)tile_hist, tile_off, tiles_s, seg_off);
+        SRS_LAUNCH((k_group2<C>), (tiles_s, batch), (SORT_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, (const uint32_t *)tile_off, gkey,
+                   gpay, (size_t)M, (uint32_t)k.len);
+        SRS_LAUNCH(k_count, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (size_t)M,
+                   (const uint32_t *)seg_off, count, (uint32_t)SORT_TILE2);
+        SRS_LAUNCH(k_plan, (batch, levels + 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
+                   levels, l0_log, (uint32_t)ACC_L1_LOG, (const uint32_t *)nullptr);
+        SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
+                   (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, plan_stride, cursor, sorted, (size_t)M,
+                   (uint32_t)SORT_TILE2, tb, (size_t)parts0_cap, 1u);                  // + the thread -> bucket map (k_expand's work)
+    } else {
+    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont, s_rank, s_world, count,
+               (uint32_t)(NBUCKET * batch));
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
     SRS_LAUNCH(k_plan, (batch, levels + 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
@@ -1933,16 +2176,16 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
         // 8 x ceil(tiles / 8) workgroups: the XCD-aware mapping of k_scatter2 needs every (XCD, slot) pair to exist
         SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
                    (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, plan_stride, cursor, sorted, (size_t)M,
-                   (uint32_t)SORT_TILE2);
+                   (uint32_t)SORT_TILE2, (uint16_t *)nullptr, (size_t)0, 0u);
     } else {
         SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                    bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
     }
+    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap, no_link, 1u);
+    }
 
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
-    const Link *no_link = nullptr;
-    SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap, no_link, 1u);
     SRS_LAUNCH_TIMED("msm_accum0", units, (k_accum0<C>), (ceil_div(parts0_cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                      (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, plan_stride, (const uint16_t *)tb, (size_t)parts0_cap,
                      (const affine_t *)k.table, ping, (size_t)parts0_cap, 1u << l0_log, no_link);
@@ -2045,8 +2288,10 @@ static size_t workspace_bytes_slots(uint32_t n_max, uint32_t batch) {
     per += Arena::pad(h.cap * sizeof(xyzz_t)) + Arena::pad(h.cap * sizeof(uint16_t)) + Arena::pad(h.cap1 * sizeof(xyzz_t));   // overflow parts, map, pong
     per += Arena::pad((size_t)NBUCKET * (h.S / 8 + 1) * sizeof(xyzz_t)) + Arena::pad((size_t)NBUCKET * (h.S / 64 + 1) * sizeof(xyzz_t));   // reduction ping / pong
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
-    if (use_two_pass(h.M, batch)) {
+    if (use_two_pass(h.M, batch) || use_sort_v2(h.M, batch)) {
         per += Arena::pad(h.M * sizeof(uint16_t)) + Arena::pad(h.M * sizeof(uint32_t));
+        per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));
+        per += Arena::pad((SEG + 1) * sizeof(uint32_t));
         per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));
     }
     return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 8192;
@@ -2104,10 +2349,12 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
     xyzz_t *red_a = A.take<xyzz_t>((size_t)NBUCKET * (S / 8 + 1) * batch);
     xyzz_t *red_b = A.take<xyzz_t>((size_t)NBUCKET * (S / 64 + 1) * batch);
     xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
-    const bool two_pass = use_two_pass(M, batch);
+    const bool v2 = use_sort_v2(M, batch), two_pass = v2 || use_two_pass(M, batch);
     uint16_t *gkey = two_pass ? A.take<uint16_t>(M * batch) : nullptr;
     uint32_t *gpay = two_pass ? A.take<uint32_t>(M * batch) : nullptr;
     uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
+    uint32_t *seg_off = v2 ? A.take<uint32_t>((size_t)(SEG + 1) * batch) : nullptr;
+    uint32_t *tile_off = v2 ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
 
     BatchDesc bd;
     for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
@@ -2115,15 +2362,32 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
         bd.n[m] = m < batch ? n_host[m] : 0;
         bd.base[m] = (m < batch && base_host) ? base_host[m] : 0;
     }
-    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont,
-               k.compact_scalars ? 0u : k.rank, k.compact_scalars ? 1u : k.world, count, (uint32_t)(NBUCKET * batch));
+    const uint32_t s_rank = k.compact_scalars ? 0u : k.rank, s_world = k.compact_scalars ? 1u : k.world;
     uint32_t tile = (uint32_t)(((uint64_t)n_max * NWIN * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
     tile = (tile + 1023u) & ~1023u;
     if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
     const uint32_t tiles = ceil_div(n_max, tile);
+    uint32_t *h_ovf = k.h_ovf + (size_t)slot * BATCH_ARGS;
+    const uint32_t arr = (uint32_t)h.levels + 1;
+    if (v2) {
+        const uint32_t tile_s = sort_v2_tile(n_max, batch), tiles_s = ceil_div(n_max, tile_s);
+        SRS_LAUNCH((k_seghist<C>), (tiles_s, batch), (SEGHIST_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, tile_hist, count,
+                   (uint32_t)(NBUCKET * batch));
+        SRS_LAUNCH(k_scan_seg2, (SEG, batch), (1024), 0, stream, (const uint32_t *)tile_hist, tile_off, tiles_s, seg_off);
+        SRS_LAUNCH((k_group2<C>), (tiles_s, batch), (SORT_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, (const uint32_t *)tile_off, gkey,
+                   gpay, (size_t)M, (uint32_t)k.len);
+        SRS_LAUNCH(k_count, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (size_t)M,
+                   (const uint32_t *)seg_off, count, (uint32_t)SORT_TILE2);
+        SRS_LAUNCH(k_plan_s, (batch, h.levels + 2), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, h.plan_stride, h.levels, S,
+                   (uint32_t)ACC_L1_LOG, used_prev, used_next, first ? 1 : 0, h_ovf, slot_want_cap());
+        SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
+                   (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, h.plan_stride, cursor, sorted, (size_t)M,
+                   (uint32_t)SORT_TILE2, tb, (size_t)h.cap, arr);                      // + the thread -> bucket map (k_expand's work)
+    } else {
+    SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont, s_rank, s_world, count,
+               (uint32_t)(NBUCKET * batch));
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                bd, count, tile, two_pass ? tile_hist : (uint32_t *)nullptr);
-    uint32_t *h_ovf = k.h_ovf + (size_t)slot * BATCH_ARGS;
     SRS_LAUNCH(k_plan_s, (batch, h.levels + 2), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, h.plan_stride, h.levels, S,
                (uint32_t)ACC_L1_LOG, used_prev, used_next, first ? 1 : 0, h_ovf, slot_want_cap());
     if (two_pass) {
@@ -2134,15 +2398,15 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
                    (size_t)h.cap, (uint32_t)h.levels + 1);                 // + the thread -> bucket map (k_expand's work)
         SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
                    (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, h.plan_stride, cursor, sorted, (size_t)M,
-                   (uint32_t)SORT_TILE2);
+                   (uint32_t)SORT_TILE2, (uint16_t *)nullptr, (size_t)0, 0u);
     } else {
         SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                    bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
     }
+    }
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
     const Link *no_link = nullptr;
-    const uint32_t arr = (uint32_t)h.levels + 1;
     if (!two_pass) SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, h.plan_stride, tb, (size_t)h.cap, no_link, arr);
     SRS_LAUNCH_TIMED("msm_accum0", units, (k_accum0s<C>), (ceil_div(h.cap, ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                      (const uint32_t *)sorted, (size_t)M, (const uint32_t *)plan, h.plan_stride, arr, (const uint16_t *)tb, (size_t)h.cap,

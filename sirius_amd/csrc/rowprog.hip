@@ -419,6 +419,48 @@ __global__ void SRS_KERNEL_BOUNDS(512, 1)
     for (uint32_t m = t; m <= deg; m += blockDim.x) out[m] = buf[(nlev - 1) & 1][m];
 }
 
+// r05: SEVERAL levels of the polynomial tree per launch, for ANY number of nodes: workgroup g takes the 2^nlev consecutive input nodes
+// [g 2^nlev, (g + 1) 2^nlev) through nlev <= PG_F_MULTI_LEVELS levels in LDS (the same (coefficient, node) threads as k_pg_F_level) and writes
+// ONE output node of degree deg_in + nlev.  compute_F's 18 levels above the leaf cubics (k = 20) are 3 launches instead of 13 + 1
+// (each ~7 us of kernel + a launch gap on a chain nothing overlaps).   grid = n_in >> nlev, block = 256
+constexpr uint32_t PG_F_MULTI_LEVELS = 6, PG_F_MULTI_NODES = 1u << (PG_F_MULTI_LEVELS - 1);
+struct PgFMulti {
+    fe_t beta[PG_F_MULTI_LEVELS], delta[PG_F_MULTI_LEVELS];
+};
+template <class F>
+__global__ void SRS_KERNEL_BOUNDS(256, 1)
+    k_pg_F_multi(const fe_t *__restrict__ in, uint32_t n_in, uint32_t m_valid, uint32_t deg_in, uint32_t nlev, PgFMulti T, fe_t *__restrict__ out,
+                 uint32_t n_out_total) {
+    __shared__ fe_t buf[2][(PG_F_TAIL_MAXDEG + 1) * PG_F_MULTI_NODES];      // level outputs: <= 32 nodes x <= 41 coefficients
+    const uint32_t t = threadIdx.x, g = blockIdx.x;
+    const uint32_t first = g << nlev;                                      // this workgroup's first input node
+    uint32_t cur_n = 1u << nlev, deg = deg_in;
+    uint32_t valid = m_valid > first ? m_valid - first : 0u;               // its input nodes that are not padding
+    if (valid > cur_n) valid = cur_n;
+    for (uint32_t lv = 0; lv < nlev; ++lv) {
+        const uint32_t n_out = cur_n >> 1;
+        const fe_t *src = lv == 0 ? in + first : buf[(lv - 1) & 1];
+        const size_t src_stride = lv == 0 ? (size_t)n_in : (size_t)cur_n;  // coefficient-major: src[m * stride + node]
+        fe_t *dst = buf[lv & 1];
+        for (uint32_t lin = t; lin < n_out * (deg + 2); lin += blockDim.x) {
+            const uint32_t m = lin / n_out, i = lin - m * n_out;
+            const bool hasL = 2 * i < valid, hasR = 2 * i + 1 < valid;
+            fe_t acc = F::zero();
+            if (m <= deg) {
+                if (hasL) acc = src[(size_t)m * src_stride + 2 * i];
+                if (hasR) acc = F::add(acc, F::mul(src[(size_t)m * src_stride + 2 * i + 1], T.beta[lv]));
+            }
+            if (m >= 1 && hasR) acc = F::add(acc, F::mul(src[(size_t)(m - 1) * src_stride + 2 * i + 1], T.delta[lv]));
+            dst[(size_t)m * n_out + i] = acc;
+        }
+        __syncthreads();
+        cur_n = n_out;
+        ++deg;
+        valid = (valid + 1) >> 1;
+    }
+    for (uint32_t m = t; m <= deg; m += blockDim.x) out[(size_t)m * n_out_total + g] = buf[(nlev - 1) & 1][m];
+}
+
 #define SRS_SPEC_PART 2
 #include "rowprog_spec.inc"
 #undef SRS_SPEC_PART
@@ -2461,6 +2503,24 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         size_t n_in = n0, m_valid = n_tiles_valid * T;
         uint32_t deg = 3;
         size_t at = 0;
+        static const bool f_multi = [] { const char *e = std::getenv("SRS_PG_F_MULTI"); return !(e && e[0] == '0'); }();
+        while (f_multi && at < order.size() && deg + std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at) <= PG_F_TAIL_MAXDEG) {
+            // up to six levels per launch (k_pg_F_multi); SRS_PG_F_MULTI=0: one launch per level + the one-workgroup tail (r03 flow, A/B)
+            const uint32_t nlev = (uint32_t)std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at);
+            PgFMulti tm;
+            for (uint32_t l = 0; l < PG_F_MULTI_LEVELS; ++l) {
+                tm.beta[l] = l < nlev ? weights_in[order[at + l]] : Fr::zero();
+                tm.delta[l] = l < nlev ? deltas[order[at + l]] : Fr::zero();
+            }
+            const size_t n_out = n_in >> nlev;
+            SRS_LAUNCH((k_pg_F_multi<Fr>), ((uint32_t)n_out), (256), 0, st, (const fe_t *)cur, (uint32_t)n_in, (uint32_t)m_valid, deg, nlev, tm, nxt,
+                       (uint32_t)n_out);
+            n_in = n_out;
+            m_valid = (m_valid + (((size_t)1 << nlev) - 1)) >> nlev;
+            deg += nlev;
+            at += nlev;
+            std::swap(cur, nxt);
+        }
         for (; at < order.size(); ++at) {
             // the last levels (<= 32 nodes left) run in one workgroup (k_pg_F_tail)
             const size_t left = order.size() - at;

@@ -338,10 +338,11 @@ def test_two_pass_scatter_matches_single_pass(srs, oracle):
         "assert np.array_equal(ck.commit(vd), O.msm(0, vd, bases))\n"
         "print('ok')\n")
     from conftest import ROOT
-    for mode in ("1", "2"):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT=mode), capture_output=True,
+    # "2": sort v2 (r05: digits recomputed, per-segment first pass, bucket counts from the grouped array); "2" + SRS_MSM_SORTV=1: the r04 two-pass flow
+    for mode, extra in (("1", {}), ("2", {}), ("2", {"SRS_MSM_SORTV": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT=mode, **extra), capture_output=True,
                            text=True, timeout=600)
-        assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
+        assert r.returncode == 0 and "ok" in r.stdout, (mode, extra, r.stdout[-500:], r.stderr[-1500:])
 
 
 @pytest.mark.parametrize("cid", [0, 1])
@@ -423,6 +424,28 @@ def test_multi_device_key_single_process(srs, oracle, cid):
         with pytest.raises(srs.TooLongInput):
             ck.commit(np.zeros((n + 1, 4), np.uint64))
         ck.close()
+    # r05: a streamed commit on a multi-device key -- every shard uploads ITS stripes over its own link in chunks that overlap its MSM,
+    # the device copy is assembled on the process's device by peer copies; bytes per link asserted through srs_ck_shard_stats
+    n2 = 37 * 1024 + 555
+    bases2 = O.make_bases(cid, 22, n2)
+    for kind in ("uniform", "trace"):
+        v = seeded_scalars(O, cid, n2, 41, kind)
+        want2 = O.msm(cid, v, bases2)
+        for shards in (2, 3, 8):
+            ck = srs.CommitmentKey.create_multi(cid, bases2, shards)
+            d = torch.zeros((n2, 4), dtype=torch.int64, device="cuda")
+            for rep in range(2):
+                d.zero_()
+                assert np.array_equal(ck.commit_upload(v, dev_copy=d), want2), (kind, shards, rep)
+                torch.cuda.synchronize()
+                assert np.array_equal(d.cpu().numpy().view(np.uint64), v), (kind, shards, rep)
+            st = [ck.shard_stats(j) for j in range(shards)]
+            stripes = lambda j: sum(min(1024, n2 - s * 1024) for s in range(j, (n2 + 1023) // 1024, shards))
+            for j in range(shards):
+                assert st[j]["streamed_commits"] == 2 and st[j]["h2d_bytes"] == 2 * stripes(j) * 32, (j, st[j])
+                assert st[j]["peer_bytes"] == (0 if j == 0 else 2 * stripes(j) * 32), (j, st[j])
+            assert sum(x["h2d_bytes"] for x in st) == 2 * n2 * 32
+            ck.close()
     # synthetic multi key == synthetic single key (same seeded bases, whatever the sharding)
     a = srs.CommitmentKey.setup_synthetic(cid, 3000, seed=5)
     b = srs.CommitmentKey.setup_synthetic_multi(cid, 3000, seed=5, n_devices=3)

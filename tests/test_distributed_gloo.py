@@ -233,6 +233,10 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
     assert two["secondary"]["microbench_msm_sharded"]["msm_uniform"]["n_gpus"] == 2
     multi = last_json(res["r3s"][1])
     assert multi["n_gpus"] == 3 and multi["config"]["parallelism"].startswith("msm-multi3-single-process") and multi["state_digest"] == one["state_digest"]
+    # ... and every link carried its third of the 12 * 2^11 * 32 B witness, once (srs_ck_shard_stats): nothing goes to device 0 first
+    md = multi["multi_device"]
+    assert md["shards"] == 3 and sum(md["h2d_bytes_per_commit"]) == 12 * 2048 * 32 and max(md["h2d_bytes_per_commit"]) == 12 * 2048 * 32 // 3
+    assert md["peer_bytes_per_commit"][0] == 0 and md["peer_bytes_per_commit"][1:] == md["h2d_bytes_per_commit"][1:]
     # the intended leaf rows shard the same way
     d1, d2 = last_json(res["r1t"][1])["state_digest"], last_json(res["r2t"][1])["state_digest"]
     assert d1 == d2 and d1 != one["state_digest"]

@@ -185,7 +185,7 @@ def test_emu_batch_invert_assigned(emu, oracle):
 
 
 def test_emu_two_pass_scatter():
-    """SRS_MSM_SORT=2 (two-pass scatter incl. the XCD-aware tile mapping) on the emulator; the switch is read once per process."""
+    """SRS_MSM_SORT=2 (two-pass scatter incl. the XCD-aware tile mapping: sort v2 and the r04 flow) on the emulator; the switches are read once per process."""
     import sys
     code = (
         "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
@@ -212,9 +212,10 @@ def test_emu_two_pass_scatter():
         "    ve = O.ints_to_mont(O.SCALAR_FIELD[1], [x % q for x in vals])\n"
         "    assert np.array_equal(ck.commit(ve), O.msm(1, ve, bases[:len(vals)])), vals[-1]\n"
         "print('ok')\n")
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT="2"), capture_output=True, text=True,
-                       timeout=1800)
-    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
+    # SRS_MSM_SORT=2 takes sort v2 (r05: k_seghist / k_scan_seg2 / k_group2 / k_count, no digit array); with SRS_MSM_SORTV=1 the r04 two-pass flow
+    jobs = [(tag, [sys.executable, "-c", code], dict(os.environ, SRS_MSM_SORT="2", **extra)) for tag, extra in (("v2", {}), ("r04", {"SRS_MSM_SORTV": "1"}))]
+    for tag, r in _run_all(jobs, timeout=1800).items():
+        assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stdout[-300:], r.stderr[-1500:])
 
 
 def test_emu_commit_upload_and_multi_device_key(emu, oracle, monkeypatch):
@@ -241,6 +242,26 @@ def test_emu_commit_upload_and_multi_device_key(emu, oracle, monkeypatch):
             assert np.array_equal(mk.commit_batch([sc, sc[:1000], sc[:0]])[1], O.msm(cid, sc[:1000], bases[:1000]))
             assert np.array_equal(mk.bases(), bases) and mk.count_off_curve() == 0
             mk.close()
+    # r05: srs_commit_upload on a multi-device key streams every shard's OWN stripes over its own link (chunks overlapped with the shard's
+    # MSM) and assembles the device copy on the process's device with peer copies: result, device copy and the bytes per link
+    cid, n, shards = 0, 6500, 3
+    bases = O.make_bases(cid, 9, n)
+    sc = seeded_scalars(O, cid, n, 6, "trace")
+    want = O.msm(cid, sc, bases)
+    mk = emu.CommitmentKey.create_multi(cid, bases, shards)
+    import torch
+    for rep in range(2):
+        dev = np.zeros_like(sc)
+        assert np.array_equal(mk.commit_upload(sc, dev_copy=torch.from_numpy(dev.view(np.int64))), want), rep
+        assert np.array_equal(dev, sc), rep
+    assert np.array_equal(mk.commit_upload(sc), want)                          # no device copy asked for: nothing is forwarded
+    st = [mk.shard_stats(d) for d in range(shards)]
+    stripes = lambda d: sum(min(1024, n - s * 1024) for s in range(d, (n + 1023) // 1024, shards))
+    for d in range(shards):
+        assert st[d]["streamed_commits"] == 3 and st[d]["h2d_bytes"] == 3 * stripes(d) * 32, (d, st[d])
+        assert st[d]["peer_bytes"] == (0 if d == 0 else 2 * stripes(d) * 32), (d, st[d])
+    assert sum(x["h2d_bytes"] for x in st) == 3 * n * 32                       # the witness crosses PCIe exactly once per commit, split over the links
+    mk.close()
 
 
 def test_emu_bench_harness():
