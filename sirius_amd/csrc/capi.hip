@@ -1064,6 +1064,7 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
         missed = missed || msm::overflow_missed(ck->key, (uint32_t)j);
     }
     msm::note_commit(ck->key, used_slots.data(), (uint32_t)used_slots.size());
+    ck->key.last_scalars = local(0, n);                          // with note_commit's entry count: the density the next commit's cuts follow
     xyzz_t redo;
     if (missed) {
         ++ck->key.stat_redo;
@@ -1102,9 +1103,17 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
     return SRS_OK;
 }
 
+// bucket additions per scalar of the key's last streamed commit (0: none yet)
+double key_density(const msm::Key &k) { return k.last_scalars ? (double)k.last_entries / (double)k.last_scalars : 0.0; }
+
 // chunk boundaries of a streamed commit of n elements; `align`: boundaries are multiples of it (columns are never split)
 // `n_eff`: the scalars one device accumulates (n / world on a sharded key): what the number of chunks is chosen from
-std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
+// `density`: bucket additions (non-zero 16-bit digits) per scalar of the key's previous streamed commit, 0 = unknown.  The default cuts are
+// tuned for a commit whose accumulation takes about as long per byte as the upload (>= ~5 additions per scalar: the bench witness has
+// 7.2); a witness of 0 / 1 / small values (~2.3) accumulates 2-3x faster than it uploads -- the device WAITS for every
+// chunk, the commit ends one chunk's work after the last byte, and the schedule that fits is many even chunks with a SMALL last one
+// (r05, profiles/r05_ab_survey_cuts.txt).
+std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0, double density = 0.0) {
     static const size_t want = [] { const char *e = std::getenv("SRS_COMMIT_CHUNKS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
     if (!n_eff) n_eff = n;
     size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n_eff >> 20));
@@ -1131,7 +1140,10 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0) {
         // ~0.14 ms and accumulation about as fast per byte as the upload, the no-wait condition  upload(j + 1) <= cost(j)  means chunks
         // growing LINEARLY: ten of them, 11.2 -> 11.0 ms (same file, last section)
         std::vector<double> frac = {0.02, 0.058, 0.115, 0.19, 0.285, 0.40, 0.535, 0.69, 0.86};
-        if (const char *e = std::getenv("SRS_COMMIT_CUTS")) {      // tuning: cumulative fractions, e.g. "0.1,0.4"
+        static const bool adaptive = [] { const char *e = std::getenv("SRS_COMMIT_ADAPTIVE"); return !(e && e[0] == '0'); }();
+        if (adaptive && density > 0.0 && density < 4.5)            // upload-bound regime: eleven even chunks, the last one 4 %
+            frac = {0.03, 0.12, 0.24, 0.36, 0.48, 0.60, 0.72, 0.82, 0.90, 0.96};
+        if (const char *e = std::getenv(density > 0.0 && density < 4.5 && std::getenv("SRS_COMMIT_CUTS_SPARSE") ? "SRS_COMMIT_CUTS_SPARSE" : "SRS_COMMIT_CUTS")) {      // tuning: cumulative fractions, e.g. "0.1,0.4"
             frac.clear();
             for (const char *q = e; *q;) {
                 char *end = nullptr;
@@ -1160,7 +1172,7 @@ int multi_commit_streamed(srs_ck *ck, const fe_t *host, size_t n, fe_t *dev_copy
     const uint32_t world = (uint32_t)ck->shards.size();
     const int home = g_device < 0 ? 0 : g_device;
     const size_t align = (size_t)world << msm::STRIPE_LOG;
-    const std::vector<size_t> cut = commit_cuts(n, align, n / world);
+    const std::vector<size_t> cut = commit_cuts(n, align, n / world, key_density(ck->shards[0]->key));
     std::vector<Seg> segs(1, Seg{host, 0, n});
     std::vector<xyzz_t> parts(world);
     hipEvent_t ready = nullptr;
@@ -1247,7 +1259,7 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
         return guarded([&]() -> int {
             const size_t align = (size_t)ck->key.world << msm::STRIPE_LOG;
             std::vector<Seg> segs(1, Seg{reinterpret_cast<const fe_t *>(scalars_host), 0, n});
-            return commit_streamed(ck, segs, n, commit_cuts(n, align, n / ck->key.world), reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
+            return commit_streamed(ck, segs, n, commit_cuts(n, align, n / ck->key.world, key_density(ck->key)), reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
         });
     }
     static const bool multi_streamed = [] { const char *e = std::getenv("SRS_MULTI_STREAMED"); return !(e && e[0] == '0'); }();
@@ -1279,7 +1291,7 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
             dst = ck->staging.take<fe_t>(n);
         }
         std::vector<Seg> segs(1, Seg{reinterpret_cast<const fe_t *>(scalars_host), 0, n});
-        return commit_streamed(ck, segs, n, commit_cuts(n, 1024), dst, repr, st, out);
+        return commit_streamed(ck, segs, n, commit_cuts(n, 1024, 0, key_density(ck->key)), dst, repr, st, out);
     });
 }
 
@@ -1342,7 +1354,7 @@ int srs_commit_upload_columns(srs_ck *ck, const srs_fe *const *columns_host, con
             return srs_commit(ck, reinterpret_cast<const srs_fe *>(dst), n, SRS_SPACE_DEVICE, repr, stream, out);
         }
         const size_t align = (uniform && pad_size >= 1024) ? pad_size : 1024;
-        std::vector<size_t> cut = commit_cuts(n, align);
+        std::vector<size_t> cut = commit_cuts(n, align, 0, key_density(ck->key));
         return commit_streamed(ck, segs, n, cut, dst, repr, st, out);
     });
 }

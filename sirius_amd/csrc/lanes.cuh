@@ -23,6 +23,7 @@ SRS_D void quad_bcast_words(const uint32_t *in, uint32_t *out) { __emu_quad_bcas
 template <int N>
 SRS_D void shfl_down_words(const uint32_t *in, uint32_t *out, unsigned delta, int width) { __emu_shfl_down_bulk(in, out, delta, width, N); }
 #define SRS_SWEEP_ACC(name) static thread_local uint32_t name[(DMAX + 1) * SW_WORDS * RP_THREADS]
+#define SRS_DYN_LDS(type, name, max_elems) static thread_local type name[max_elems]
 #else
 template <int K>
 SRS_D uint32_t quad_bcast_u32(uint32_t v) {   // quad_perm:[K,K,K,K]: register crossbar, no LDS
@@ -45,6 +46,8 @@ SRS_D void shfl_down_words(const uint32_t *in, uint32_t *out, unsigned delta, in
 }
 // per-point accumulators of the sweep kernels: dynamic LDS sized by the launch (rowprog_dev.cuh: sweep_smem_bytes)
 #define SRS_SWEEP_ACC(name) extern __shared__ uint32_t name[]
+// dynamic LDS of `type`, sized by the launch (the emulator build reserves max_elems)
+#define SRS_DYN_LDS(type, name, max_elems) extern __shared__ type name[]
 #endif
 
 }  // namespace srs

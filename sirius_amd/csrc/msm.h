@@ -92,7 +92,9 @@ struct Key {
     xyzz_t *slots = nullptr;          // [batch][NBUCKET][S] persistent partial sums of the running commit
     size_t slots_pts = 0;
     uint8_t *used = nullptr;          // [2][BATCH_ARGS][NBUCKET]: slots of a bucket that hold a sum (parity = set index inside the commit)
-    uint32_t *h_ovf = nullptr;        // page-locked [LANDING_SLOTS][BATCH_ARGS]: parts beyond the slots, reported by k_plan_s
+    uint32_t *h_ovf = nullptr;        // page-locked [2][LANDING_SLOTS][BATCH_ARGS]: parts beyond the slots, then non-zero digits, reported by k_plan_s
+    uint64_t last_entries = 0;        // non-zero digits (= bucket additions) of the last commit that ran in slot mode (note_commit) ...
+    uint64_t last_scalars = 0;        // ... and its scalars (set by the caller): the density the next streamed commit's chunk cuts are chosen for
     uint32_t slot_s = 0;              // S of the running commit
     uint32_t seq = 0;                 // sets enqueued in the running commit
     bool commit_ovf = false;          // the running commit launches the overflow kernels

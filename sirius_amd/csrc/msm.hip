@@ -508,7 +508,7 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
     }
 }
 
-// ---- r05: the two-pass sort WITHOUT a digit array and without the 2^15-counter flush ("sort v2") ------------------------------------
+// ---- r05: the two-pass sort WITHOUT a digit array and without the 2^15-counter flush ("sort v2"; measured SLOWER, off: see use_sort_v2) ----
 // The r03 flow stores 16 digits per scalar (k_digits: 32 B written, then read twice) and counts the entries of every bucket in k_hist,
 // whose workgroups each flush a 2^15-counter LDS histogram through global atomics -- 25 of its 33 us per launch, ten launches per streamed
 // commit.  Here the digits are RECOMPUTED from the scalar by the two kernels that need them (32 B read either way, one Montgomery product
@@ -1401,6 +1401,7 @@ __global__ void SRS_KERNEL_BOUNDS(PLAN_THREADS, 1)
             pl[plan_stride - 1] = total;
             h_ovf[m] = total;
         }
+        if (role == 0) h_ovf[(size_t)LANDING_SLOTS * BATCH_ARGS + m] = total;      // the set's non-zero digits (msm::note_commit: the witness's density)
     }
 }
 
@@ -2053,16 +2054,15 @@ static bool use_two_pass(uint64_t M, uint32_t batch) {
     return M * batch >= TWO_PASS_MIN_SLOTS;
 }
 
-// sort v2 (k_seghist / k_scan_seg2 / k_group2 / k_count: no digit array, no 2^15-counter flush) replaces the r04 two-pass flow wherever that
-// one ran; SRS_MSM_SORTV=1: the r04 flow everywhere (A/B), =2: v2 for EVERY set, the small single-pass ones too (tests; A/B of the threshold)
-static bool use_sort_v2(uint64_t M, uint32_t batch) {
+// sort v2 (k_seghist / k_scan_seg2 / k_group2 / k_count: no digit array, no 2^15-counter flush) is OFF by measurement (r05,
+// profiles/r05_ab_sort_v2.txt): per 1.7 M-scalar chunk it takes 244 us against the r04 flow's 185 (k_seghist 85 + k_scan_seg2 12 + k_group2 79 +
+// k_count 14 vs k_digits 32 + k_hist 37 + k_scan_seg 8 + k_group 56; plan and k_scatter2 equal) -- recomputing the digits from the scalars
+// twice (a Montgomery product and sixteen LDS atomics per scalar behind ONE dependent 32-byte load per thread and round) costs more than the
+// digit array's write and two reads, and what k_hist's 2^15-counter flush costs (25 us) k_count + the second pass over the scalars give back.
+// The k = 20 step: 11.00 / 11.03 ms with it, 10.95 / 11.00 without, same box.  SRS_MSM_SORTV=2 turns it on for every set (tests, A/B).
+static bool use_sort_v2(uint64_t, uint32_t) {
     static const int forced = [] { const char *e = std::getenv("SRS_MSM_SORTV"); return e ? std::atoi(e) : 0; }();
-    if (forced == 1) return false;
-    if (forced == 2) return true;
-    static const uint64_t min_slots = [] { const char *e = std::getenv("SRS_MSM_SORTV2_MIN"); return e ? (1ull << std::atoi(e)) : TWO_PASS_MIN_SLOTS; }();
-    static const int sort_forced = [] { const char *e = std::getenv("SRS_MSM_SORT"); return e ? std::atoi(e) : 0; }();
-    if (sort_forced == 1) return false;
-    return sort_forced == 2 || M * batch >= min_slots;
+    return forced == 2;
 }
 // scalars per workgroup of k_seghist / k_group2: ~SORT_TARGET_BLOCKS workgroups over the whole batch, whole sub-tiles of SORT_THREADS scalars
 static uint32_t sort_v2_tile(uint32_t n_max, uint32_t batch) {
@@ -2323,8 +2323,8 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
         }
         if (!k.used) SRS_HIP_CHECK(hipMalloc((void **)&k.used, 2 * (size_t)BATCH_ARGS * NBUCKET));
         if (!k.h_ovf) {
-            SRS_HIP_CHECK(hipHostMalloc((void **)&k.h_ovf, (size_t)LANDING_SLOTS * BATCH_ARGS * sizeof(uint32_t)));
-            for (size_t i = 0; i < (size_t)LANDING_SLOTS * BATCH_ARGS; ++i) k.h_ovf[i] = 0;
+            SRS_HIP_CHECK(hipHostMalloc((void **)&k.h_ovf, 2 * (size_t)LANDING_SLOTS * BATCH_ARGS * sizeof(uint32_t)));
+            for (size_t i = 0; i < 2 * (size_t)LANDING_SLOTS * BATCH_ARGS; ++i) k.h_ovf[i] = 0;
         }
     } else if (k.slot_s != S || batch != 1) {
         set_error("internal: msm slot mode: a commit's sets must share the slot layout");
@@ -2468,10 +2468,12 @@ bool overflow_missed(const Key &k, uint32_t slot) {
 }
 void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots) {
     bool any = false, slot_sets = false;
+    uint64_t entries = 0;
     for (uint32_t i = 0; i < n_slots; ++i) {
         const uint32_t sl = slots_used[i];
         if (sl >= LANDING_SLOTS || !k.slot_mode[sl] || !k.h_ovf) continue;
         slot_sets = true;
+        for (uint32_t m = 0; m < k.slot_batch[sl]; ++m) entries += k.h_ovf[(size_t)(LANDING_SLOTS + sl) * BATCH_ARGS + m];
         bool hot = false;
         for (uint32_t m = 0; m < k.slot_batch[sl]; ++m) hot = hot || k.h_ovf[(size_t)sl * BATCH_ARGS + m] != 0;
         if (hot) ++k.stat_hot_sets;
@@ -2482,6 +2484,7 @@ void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots) {
     // launching the overflow kernels for nothing costs ~0.3 ms of empty launches per commit, missing them costs the commit run a second time
     constexpr uint32_t COLD_COMMITS = 3;
     if (!slot_sets) return;
+    k.last_entries = entries;
     if (any) {
         k.expect_ovf = true;
         k.cold_streak = 0;

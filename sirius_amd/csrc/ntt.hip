@@ -263,15 +263,22 @@ struct lazy {
     static constexpr uint32_t bound(uint32_t k) { return k == 0 ? 1u : (k == 1 ? 7u : 4u * bound(k - 1) + 1u); }
     // the closing product of a tile of up to 4 radix-4 groups (+ a trailing stage) must come back below the 4 P that to_canonical_fe takes
     static constexpr uint32_t closing_bound_x169(uint32_t a) { return a + 169u; }                  // (A / 169 + 1) P, times 169
+    // Element e lives at word 9 e + (e >> 6): ONE padding word per 64 elements.  Without it the bit-reversed tile rows of the load phases sit
+    // 288 x 2^j words apart (= 0 or 32 mod the 64 LDS banks): k_ntt_last_lazy's load put 32 lanes on one bank (SQ_LDS_BANK_CONFLICT 4x
+    // k_ntt_pass_lazy's, profiles/r05_pmc_ntt.json), the pass kernel's 8, the butterfly groups up to 4; with the pad every access pattern of
+    // these kernels is at most 2-way (tools/ntt_lds_banks.py enumerates them).
+    SRS_HD static constexpr uint32_t words(uint32_t elems) { return elems * 9 + (elems >> 6) + 1; }
     SRS_D static f29_t get(const uint32_t *tile, uint32_t e) {
         f29_t x;
+        const uint32_t at = e * 9 + (e >> 6);
 #pragma unroll
-        for (int l = 0; l < 9; ++l) x.v[l] = tile[e * 9 + l];
+        for (int l = 0; l < 9; ++l) x.v[l] = tile[at + l];
         return x;
     }
     SRS_D static void put(uint32_t *tile, uint32_t e, const f29_t &x) {
+        const uint32_t at = e * 9 + (e >> 6);
 #pragma unroll
-        for (int l = 0; l < 9; ++l) tile[e * 9 + l] = x.v[l];
+        for (int l = 0; l < 9; ++l) tile[at + l] = x.v[l];
     }
 };
 
@@ -363,8 +370,8 @@ template <uint32_t RBITS>
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_ntt_pass_lazy(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg,
                     const fe_t *__restrict__ T, Scale3 pre) {
-    __shared__ uint32_t tile[(1u << RBITS) * COLS * 9];
-    __shared__ uint32_t W[(1u << (RBITS - 1)) * 9];
+    __shared__ uint32_t tile[lazy::words((1u << RBITS) * COLS)];
+    __shared__ uint32_t W[lazy::words(1u << (RBITS - 1))];
     const uint32_t rows = 1u << RBITS;
     const uint32_t tiles_per_hi = 1u << (pa.lbits - COLS_LOG);
     const size_t hi = blockIdx.x / tiles_per_hi;
@@ -390,8 +397,8 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
 template <uint32_t RBITS>
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_ntt_last_lazy(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg, Scale3 fin, fe_t one29) {
-    __shared__ uint32_t tile[(1u << RBITS) * COLS * 9];
-    __shared__ uint32_t W[(1u << (RBITS - 1)) * 9];
+    __shared__ uint32_t tile[lazy::words((1u << RBITS) * COLS)];
+    __shared__ uint32_t W[lazy::words(1u << (RBITS - 1))];
     const uint32_t rows = 1u << RBITS;
     const uint32_t r1 = pa.radix_bits[0];
     const uint32_t mid_bits = pa.log_n - r1 - RBITS;              // digits 2..p-1

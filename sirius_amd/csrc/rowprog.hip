@@ -431,7 +431,12 @@ template <class F>
 __global__ void SRS_KERNEL_BOUNDS(256, 1)
     k_pg_F_multi(const fe_t *__restrict__ in, uint32_t n_in, uint32_t m_valid, uint32_t deg_in, uint32_t nlev, PgFMulti T, fe_t *__restrict__ out,
                  uint32_t n_out_total) {
-    __shared__ fe_t buf[2][(PG_F_TAIL_MAXDEG + 1) * PG_F_MULTI_NODES];      // level outputs: <= 32 nodes x <= 41 coefficients
+    // level outputs, two buffers of 32 x (deg_in + nlev + 1) elements each: DYNAMIC LDS sized by the launch -- the first launch of a k = 20
+    // compute_F (4096 workgroups, degree 3 -> 9) needs 20 KB and shares a CU eight ways; with the worst-case 84 KB it ran one workgroup per
+    // CU, 16 rounds: 219 us (profiles/r05_ab_misc.txt)
+    SRS_DYN_LDS(fe_t, dyn, 2 * (PG_F_TAIL_MAXDEG + 1) * PG_F_MULTI_NODES);
+    const uint32_t bstride = PG_F_MULTI_NODES * (deg_in + nlev + 1);
+    fe_t *const buf[2] = {dyn, dyn + bstride};
     const uint32_t t = threadIdx.x, g = blockIdx.x;
     const uint32_t first = g << nlev;                                      // this workgroup's first input node
     uint32_t cur_n = 1u << nlev, deg = deg_in;
@@ -479,6 +484,29 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1)
         if (threadIdx.x == 0) out[(size_t)blockIdx.x * P + p] = red[0];
         __syncthreads();
     }
+}
+
+// r05: the same reduction with the P evaluation points SIDE BY SIDE: thread (p, t) of a workgroup of P * 2^lv <= 1024 threads runs point p's
+// tree (k_pg_reduce walks the points one after the other: P x lv dependent multiply-add-barrier rounds on a chain nothing overlaps --
+// 64 + 26 us per compute_G at P = 5).   grid = number of output nodes, block = (2^lv, P)
+constexpr uint32_t PG_REDUCE_PAR_THREADS = 1024;
+template <class F>
+__global__ void SRS_KERNEL_BOUNDS(PG_REDUCE_PAR_THREADS, 1)
+    k_pg_reduce_par(const fe_t *__restrict__ in, uint32_t m_valid, uint32_t P, const fe_t *__restrict__ weights, uint32_t wpts,
+                    uint32_t level0, uint32_t lv, fe_t *__restrict__ out) {
+    __shared__ fe_t red[PG_REDUCE_PAR_THREADS];
+    const uint32_t t = threadIdx.x, p = threadIdx.y, width = blockDim.x;
+    const uint32_t node = blockIdx.x * width + t;
+    fe_t *r = red + (size_t)p * width;
+    const fe_t *w = weights + (size_t)level0 * wpts + (wpts > 1 ? p : 0);
+    r[t] = node < m_valid ? in[(size_t)node * P + p] : F::zero();
+    __syncthreads();
+    for (uint32_t l = 0; l < lv; ++l) {
+        const uint32_t stride = 1u << l;
+        if ((t & (2 * stride - 1)) == 0) r[t] = F::add(r[t], F::mul(r[t + stride], w[(size_t)l * wpts]));
+        __syncthreads();
+    }
+    if (t == 0) out[(size_t)blockIdx.x * P + p] = r[0];
 }
 
 // K(X) on the coset (compute_K_from_G, poly/mod.rs:475-509): thread i: X = ZETA * w^i,
@@ -2513,7 +2541,8 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
                 tm.delta[l] = l < nlev ? deltas[order[at + l]] : Fr::zero();
             }
             const size_t n_out = n_in >> nlev;
-            SRS_LAUNCH((k_pg_F_multi<Fr>), ((uint32_t)n_out), (256), 0, st, (const fe_t *)cur, (uint32_t)n_in, (uint32_t)m_valid, deg, nlev, tm, nxt,
+            const size_t lds = 2 * (size_t)PG_F_MULTI_NODES * (deg + nlev + 1) * sizeof(fe_t);
+            SRS_LAUNCH((k_pg_F_multi<Fr>), ((uint32_t)n_out), (256), lds, st, (const fe_t *)cur, (uint32_t)n_in, (uint32_t)m_valid, deg, nlev, tm, nxt,
                        (uint32_t)n_out);
             n_in = n_out;
             m_valid = (m_valid + (((size_t)1 << nlev) - 1)) >> nlev;
@@ -2622,9 +2651,14 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     size_t m_valid = n_tiles_valid, m = n_tiles_padded;
     uint32_t level0 = tile_log;
     fe_t *cur = buf0, *nxt = buf1;
+    static const bool reduce_par = [] { const char *e = std::getenv("SRS_PG_REDUCE_PAR"); return !(e && e[0] == '0'); }();
     while (m > 1) {
         uint32_t lv = std::min<uint32_t>(7, ilog2(m));
         uint32_t outs = (uint32_t)(m >> lv);
+        if (reduce_par && ((size_t)P << lv) <= PG_REDUCE_PAR_THREADS && (((size_t)P << lv) % 64 == 0 || outs == 1))
+            SRS_LAUNCH((k_pg_reduce_par<Fr>), (outs), (1u << lv, P), 0, st, (const fe_t *)cur, (uint32_t)m_valid, P, (const fe_t *)d_w, wpts,
+                       level0, lv, nxt);
+        else
         SRS_LAUNCH((k_pg_reduce<Fr>), (outs), (1u << lv), 0, st, (const fe_t *)cur, (uint32_t)m_valid, P, (const fe_t *)d_w, wpts,
                    level0, lv, nxt);
         level0 += lv;

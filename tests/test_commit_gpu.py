@@ -338,8 +338,8 @@ def test_two_pass_scatter_matches_single_pass(srs, oracle):
         "assert np.array_equal(ck.commit(vd), O.msm(0, vd, bases))\n"
         "print('ok')\n")
     from conftest import ROOT
-    # "2": sort v2 (r05: digits recomputed, per-segment first pass, bucket counts from the grouped array); "2" + SRS_MSM_SORTV=1: the r04 two-pass flow
-    for mode, extra in (("1", {}), ("2", {}), ("2", {"SRS_MSM_SORTV": "1"})):
+    # "2" + SRS_MSM_SORTV=2: sort v2 (r05: digits recomputed, per-segment first pass, bucket counts from the grouped array; off by default)
+    for mode, extra in (("1", {}), ("2", {}), ("2", {"SRS_MSM_SORTV": "2"})):
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT=mode, **extra), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (mode, extra, r.stdout[-500:], r.stderr[-1500:])
