@@ -50,20 +50,29 @@ NTT_BYTES_PER_ELEMENT = 64.0   # read once + write once
 # 9 x 29-bit limb form = 8 * 171 + 2 * 135 multiplier instructions (v_mad_u64_u32 / v_mul_lo_u32), minus the 81 + 9 of the one
 # Montgomery reduction that Y3 = t r - Y1 ppp shares since r03 (Fp29::mul2); the chip issues 31.2 T v_mad_u64_u32 per second
 # (profiles/r02_ubench29_gfx950.txt: 50.7 lane-ops/clk/CU x 256 CUs x 2.4 GHz).
+PROF_SAMPLE = int(os.environ.get("SRS_BENCH_PROF_SAMPLE", "4"))      # HIP events on every n-th k_accum0s launch of the headline loop (an event-bracketed launch idles the device ~8 us)
 MAD_ISSUE_PER_S = 31.16e12
 MADD_MULT_INSNS = 8 * 171 + 2 * 135 - 90
 
 
-# No multi-GPU node was available to r01-r04: what the first measured SCALE record can be diffed against (derived from the
-# r04 kernel trace of the N = 1 step: per-row / per-scalar work divides by N, the chain's latency-bound part does not).
+# No multi-GPU node was available to r01-r05: what the first measured SCALE record can be diffed against (derived from the
+# kernel trace of the N = 1 step: per-row / per-scalar work divides by N, the chain's latency-bound part does not).
 PREDICTED_SCALING = {
-    "note": "PREDICTION, not a measurement: k = 20 CycleFold step, process per GPU (bench.py --gpus N); strong scaling of ONE sequential chain",
-    "ms_per_step": {"1": 10.7, "2": 7.2, "4": 4.7, "8": 3.7},
-    "speedup": {"1": 1.0, "2": 1.5, "4": 2.3, "8": 2.9},
-    "msm_2p24_uniform_ms": {"1": 19.4, "2": 10.0, "4": 5.3, "8": 3.0},
-    "divisible_ms_at_1": 8.2, "replicated_ms": 2.6, "per_rank_overhead_ms_at_n_gt_1": 0.55,
-    "replicated": "transcript (Poseidon, host) 0.35, compute_F tree upper levels + K + e 0.35, bucket reductions + host finish 0.3, k_plan_s / "
-                  "k_hist floors 0.07 per chunk (10 chunks at N <= 2, 2 at N >= 4: the cuts follow the scalars per device), support circuit's latency-bound MSM 0.5, step-wise calls + five <= 2 KB all-gathers 0.45",
+    "note": "PREDICTION, not a measurement: k = 20 CycleFold step; strong scaling of ONE sequential chain",
+    "process_per_gpu": {
+        "how": "bench.py --gpus N (torchrun or self-launched): MSMs, leaves, cross terms, folds and the witness upload sharded by key / row stripes; RCCL all-gathers",
+        "ms_per_step": {"1": 10.8, "2": 7.3, "4": 4.7, "8": 3.7}, "speedup": {"1": 1.0, "2": 1.5, "4": 2.3, "8": 2.9},
+        "divisible_ms_at_1": 8.2, "replicated_ms": 2.6, "per_rank_overhead_ms_at_n_gt_1": 0.55,
+        "replicated": "transcript (Poseidon, host) 0.35, compute_F tree upper levels + K + e 0.35, bucket reductions + host finish 0.3, k_plan_s / "
+                      "k_hist floors 0.07 per chunk (10 chunks at N <= 2, 2 at N >= 4), support circuit's latency-bound MSM 0.5, step-wise calls + five <= 2 KB all-gathers 0.45"},
+    "single_process": {
+        "how": "bench.py --gpus N --single-process (srs_ck_create_multi: what a single-process Rust IVC driver calls): every shard streams ITS stripes of the witness "
+               "over its own link, overlapped with its MSM; the device copy is assembled on device 0 by peer copies; prove and support circuit on device 0",
+        "ms_per_step": {"1": 10.8, "2": 7.4, "4": 5.1, "8": 4.0}, "speedup": {"1": 1.0, "2": 1.5, "4": 2.1, "8": 2.7},
+        "divisible_ms_at_1": 8.1, "device0_ms": 2.0, "per_commit_overhead_ms_at_n_gt_1": 0.5,
+        "device0": "srs_pg_prove 1.0 (F / G / K / e + transcript), srs_sangria_prove_incoming 0.65 (the support key is a single-device key), Python 0.1, "
+                   "the deferred witness fold 0.24 under the upload; per commit: slot + bucket reductions per shard 0.3, worker hand-off and the peer-copy tail 0.2"},
+    "msm_2p24_uniform_ms": {"1": 19.3, "2": 10.0, "4": 5.3, "8": 3.0},
 }
 
 
@@ -544,12 +553,16 @@ def timed(D, fn, steps, after=None):
     return D.max_over_ranks(time.perf_counter() - t0)
 
 
-def msm_roofline(S, units_note, nz_madds=None, world=1):
-    """roofline object of the dominant kernel from the library's HIP-event timers (srs_profile_*)."""
+def msm_roofline(S, units_note, nz_madds=None, world=1, total_units=None, sample_every=1):
+    """roofline object of the dominant kernel from the library's HIP-event timers (srs_profile_*).  With event sampling
+    (srs_profile_sampling) the timers cover every n-th launch: total_units = the scalars of ALL launches, so that the mixed additions of
+    the sampled launches are nz_madds x (sampled scalars / all scalars)."""
     acc0 = S.profile_get("msm_accum0") or dict(total_ms=0.0, launches=0, units=0)
     if not acc0["launches"]:
         return None
     sec = acc0["total_ms"] * 1e-3
+    if nz_madds and total_units and sample_every > 1:
+        nz_madds = nz_madds * acc0["units"] / total_units
     achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / sec / 1e9
     traffic, src = None, None
     for name in ("r05_pmc_accum0.json", "r04_pmc_accum0.json", "r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
@@ -565,7 +578,7 @@ def msm_roofline(S, units_note, nz_madds=None, world=1):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
             "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
             "scalars_per_launch": round(acc0["units"] / acc0["launches"]), "units_note": units_note,
-            "binding": "alu",
+            "binding": "alu", "event_sampling": f"1 launch in {sample_every}" if sample_every > 1 else "every launch",
             "note": "`bound` / `frac` are the mandated HBM figures; the roof that BINDS this kernel is integer-multiplier issue (256-bit modular "
                     "products: v_mad_u64_u32), see the `alu` object and DESIGN.md 2"}
     if nz_madds:
@@ -812,14 +825,17 @@ def main():
         for _ in range(args.warmup):
             cyclefold_step(S, D, pri, sup, args.ro_challenge)
         S.profile_enable(True)
+        S.profile_sampling(PROF_SAMPLE)          # events on every 4th bucket-accumulation launch (11 per step: every chunk position is sampled in turn)
         S.profile_reset()
         dt = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), args.steps, after=lambda: (pri.settle(), sup.settle()))
         S.profile_enable(False)
+        S.profile_sampling(1)
         scalars_per_step = pri.w["num_advice"] * pri.rows + (3 + 2) * sup.rows
         if D.rank == 0:
             nz = sum(nonzero_rows(torch.from_numpy(hb.array.view(np.int64))) for hb in pri.host_W) / 2.0 + nonzero_rows(sup.inW) + sup.nz_terms
             roof = msm_roofline(S, f"{pri.w['num_advice']}*2^{k} witness scalars in 10 chunks + the support circuit's 5*2^15 per step",
-                                16.0 * nz * args.steps / D.world if args.witness == "bench" else None, D.world)
+                                16.0 * nz * args.steps / D.world if args.witness == "bench" else None, D.world,
+                                total_units=scalars_per_step * args.steps / D.world, sample_every=PROF_SAMPLE)
             prof = {}
             for name in ("pg_F_leaves", "pg_G_leaves", "rowprog_cross_terms"):
                 st = S.profile_get(name)

@@ -207,6 +207,10 @@ int srs_job_wait(uint64_t job);
  * names: "msm_accum0" (units = scalars), "rowprog_cross_terms" (rows), "rowprog_eval" (rows), "ntt_transform" (elements) */
 void srs_profile_enable(int on);
 void srs_profile_reset(void);
+/* Events on every `every`-th launch of a name only (1 = all, the default): a launch that carries its own event pair costs ~8 us of idle
+ * device, which a per-launch measurement of the dominant kernel adds to every step it measures.  srs_profile_get then reports the SAMPLED
+ * launches (total_ms, launches and units of the same launches, so units / total_ms stays exact). */
+void srs_profile_sampling(unsigned every);
 int srs_profile_get(const char *name, double *total_ms, uint64_t *launches, uint64_t *units);
 
 /* ---- fft (src/fft.rs:160-198) ----

@@ -25,6 +25,11 @@ def profile_reset():
     _lib.lib().srs_profile_reset()
 
 
+def profile_sampling(every=1):
+    """events on every `every`-th timed launch of a name only (srs_profile_sampling)"""
+    _lib.lib().srs_profile_sampling(int(every))
+
+
 def profile_get(name):
     """-> dict(total_ms, launches, units) or None."""
     import ctypes as _C

@@ -64,6 +64,7 @@ def _prototypes():
         "srs_jit_selfcheck": (i32, [C.POINTER(sz), C.c_char_p, sz]),
         "srs_profile_enable": (None, [i32]),
         "srs_profile_reset": (None, []),
+        "srs_profile_sampling": (None, [C.c_uint]),
         "srs_profile_get": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "srs_ck_load_file": (i32, [i32, C.c_char_p, sz, u32, u32, C.POINTER(vp)]),
         "srs_ck_save_file": (i32, [vp, C.c_char_p]),

@@ -1584,6 +1584,7 @@ int srs_job_wait(uint64_t job) {
 
 void srs_profile_enable(int on) { prof::enable(on != 0); }
 void srs_profile_reset(void) { prof::reset(); }
+void srs_profile_sampling(unsigned every) { prof::sampling(every); }
 int srs_profile_get(const char *name, double *total_ms, uint64_t *launches, uint64_t *units) {
     prof::Stat st;
     if (!name || !prof::get(name, st)) return SRS_ERR_INVALID;

@@ -26,6 +26,8 @@ struct Pending {
 };
 struct State {
     bool on = false;
+    uint32_t sample_every = 1;      // SRS_LAUNCH_TIMED binds events to every n-th launch of a name only (sampling(): an event-bracketed launch costs ~8 us of idle device)
+    std::map<std::string, uint64_t> seen;      // launches per name since reset(), sampled or not
     std::mutex mu;
     std::map<std::string, Stat> stats;
     std::vector<Pending> pending;
@@ -81,6 +83,7 @@ struct KernelEvents {
         State &s = state();
         if (!s.on) return;
         std::lock_guard<std::mutex> lk(s.mu);
+        if (s.sample_every > 1 && (s.seen[name]++ % s.sample_every) != 0) return;      // not this launch
         auto take = [&]() {
             hipEvent_t e;
             if (!s.pool.empty()) { e = s.pool.back(); s.pool.pop_back(); return e; }
@@ -123,6 +126,7 @@ struct KernelEvents {
 void collect();
 void reset();
 void enable(bool on);
+void sampling(uint32_t every);      // 1 = every timed launch (default)
 bool get(const char *name, Stat &out);
 
 }  // namespace prof

@@ -32,6 +32,13 @@ void reset() {
     State &s = state();
     std::lock_guard<std::mutex> lk(s.mu);
     s.stats.clear();
+    s.seen.clear();
+}
+
+void sampling(uint32_t every) {
+    State &s = state();
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.sample_every = every ? every : 1;
 }
 
 void enable(bool on) {
