@@ -50,7 +50,9 @@ NTT_BYTES_PER_ELEMENT = 64.0   # read once + write once
 # 9 x 29-bit limb form = 8 * 171 + 2 * 135 multiplier instructions (v_mad_u64_u32 / v_mul_lo_u32), minus the 81 + 9 of the one
 # Montgomery reduction that Y3 = t r - Y1 ppp shares since r03 (Fp29::mul2); the chip issues 31.2 T v_mad_u64_u32 per second
 # (profiles/r02_ubench29_gfx950.txt: 50.7 lane-ops/clk/CU x 256 CUs x 2.4 GHz).
-PROF_SAMPLE = int(os.environ.get("SRS_BENCH_PROF_SAMPLE", "4"))      # HIP events on every n-th k_accum0s launch of the headline loop (an event-bracketed launch idles the device ~8 us)
+# HIP events on every n-th bucket-accumulation launch of the headline loop.  1 = every launch: the rocprofv3 trace shows 6-10 us of idle device in front of an
+# event-bracketed launch, but with 1 launch in 4 sampled the step is the same within noise (10.72 / 10.74 against 10.74 / 10.71 ms, profiles/r05_ab_small_msm.txt)
+PROF_SAMPLE = int(os.environ.get("SRS_BENCH_PROF_SAMPLE", "1"))
 MAD_ISSUE_PER_S = 31.16e12
 MADD_MULT_INSNS = 8 * 171 + 2 * 135 - 90
 
@@ -825,7 +827,7 @@ def main():
         for _ in range(args.warmup):
             cyclefold_step(S, D, pri, sup, args.ro_challenge)
         S.profile_enable(True)
-        S.profile_sampling(PROF_SAMPLE)          # events on every 4th bucket-accumulation launch (11 per step: every chunk position is sampled in turn)
+        S.profile_sampling(PROF_SAMPLE)
         S.profile_reset()
         dt = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), args.steps, after=lambda: (pri.settle(), sup.settle()))
         S.profile_enable(False)

@@ -2006,7 +2006,9 @@ static uint32_t l0_log_for(uint64_t M) {
     // < 2^17 level-0 threads, each a chain of 16 dependent additions on a chip that holds 2^17.6 -- shorter parts, more threads
     // (r03; SRS_MSM_L0_SMALL=0 restores 16 everywhere)
     static const bool small_on = [] { const char *e = std::getenv("SRS_MSM_L0_SMALL"); return !(e && e[0] == '0'); }();
-    if (small_on && M < (1ull << 21)) return 2;
+    // r05: parts of 8 from 2^20 digit slots on (was 2^21): the support circuit's batch (3 * 2^15 + 2 x 2^15 scalars, 1.6 M slots) 589 -> 501 us per call,
+    // profiles/r05_ab_small_msm.txt -- with parts of 4 its first accumulation level has 5 partial sums per bucket to combine, with 8 two or three
+    if (small_on && M < (1ull << 20)) return 2;
     if (small_on && M < (1ull << 22)) return 3;
     uint32_t lg = ACC_L0_LOG;
     while (lg < 7 && (M >> (lg + 1)) >= (5ull << 20)) ++lg;
