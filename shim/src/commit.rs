@@ -85,6 +85,20 @@ impl<C: GpuCurve> GpuKey<C> {
                                                  ptr::null_mut(), out.as_mut_ptr() as *mut srs_affine) })?;
         Ok(unsafe { out.assume_init() })
     }
+
+    /// number of shards of a multi-device key (1 for an ordinary key)
+    pub fn num_shards(&self) -> usize { unsafe { srs_ck_num_shards(self.raw) as usize } }
+
+    /// (bytes uploaded over the shard's own link, bytes forwarded to the process's device, streamed commits, device ordinal) of one shard
+    /// of a multi-device key: `commit_upload` sends every shard ITS stripes of the witness only (diagnostics, no reference counterpart)
+    pub fn shard_stats(&self, shard: usize) -> Result<[u64; 4], ShimError> {
+        let mut out = [0u64; 4];
+        check(unsafe { srs_ck_shard_stats(self.raw, shard as i32, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+
+    /// whether the key holds the optional second (20-bit-window) table; without it every MSM takes the 16-bit windows
+    pub fn has_wide_table(&self) -> bool { unsafe { srs_ck_has_wide_table(self.raw) != 0 } }
 }
 impl<C: GpuCurve> Drop for GpuKey<C> { fn drop(&mut self) { unsafe { srs_ck_free(self.raw) } } }
 

@@ -271,9 +271,10 @@ def test_emu_bench_harness():
     import json
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emu", "--k", "3", "--log-key", "7", "--steps", "1", "--warmup", "0",
-                        "--cpu-threads", "2", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--cpu-threads", "2", "--no-extras", "--verify"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["verify"]["match"] and line["verify"]["first_step_digest"] == line["verify"]["oracle_first_step_digest"]     # --verify: first step == oracle chain
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
