@@ -555,7 +555,7 @@ def timed(D, fn, steps, after=None):
     return D.max_over_ranks(time.perf_counter() - t0)
 
 
-def msm_roofline(S, units_note, nz_madds=None, world=1, total_units=None, sample_every=1):
+def msm_roofline(S, units_note, nz_madds=None, world=1, total_units=None, sample_every=1, gather_peak_g=40.0):
     """roofline object of the dominant kernel from the library's HIP-event timers (srs_profile_*).  With event sampling
     (srs_profile_sampling) the timers cover every n-th launch: total_units = the scalars of ALL launches, so that the mixed additions of
     the sampled launches are nz_madds x (sampled scalars / all scalars)."""
@@ -580,12 +580,20 @@ def msm_roofline(S, units_note, nz_madds=None, world=1, total_units=None, sample
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": src,
             "avg_launch_ms": round(acc0["total_ms"] / acc0["launches"], 4), "launches": acc0["launches"],
             "scalars_per_launch": round(acc0["units"] / acc0["launches"]), "units_note": units_note,
+            "traffic_note": "PMC FETCH_SIZE x 2 (the guide's correction for wide streaming reads) + WRITE_SIZE; FETCH_SIZE counts requests x 64 B and a random 64-byte "
+                            "gather is ONE request of 64 B (profiles/r05_ubench_gather.txt), so the gather share (~80 %) of this figure is counted twice: ~0.7 KB per scalar move",
             "binding": "alu", "event_sampling": f"1 launch in {sample_every}" if sample_every > 1 else "every launch",
             "note": "`bound` / `frac` are the mandated HBM figures; the roof that BINDS this kernel is integer-multiplier issue (256-bit modular "
                     "products: v_mad_u64_u32), see the `alu` object and DESIGN.md 2"}
     if nz_madds:
         rate = nz_madds / sec
         peak = MAD_ISSUE_PER_S / MADD_MULT_INSNS
+        # the other candidate roof: every mixed addition gathers one 64-byte table entry.  tools/ubench_gather (profiles/r05_ubench_gather.txt): random
+        # 64-byte gathers saturate at ~40 G/s while the pages touched stay within ~2 GiB (a chunk of a streamed commit), at 19.7 G/s over a 16 GiB table
+        gp = gather_peak_g * 1e9
+        roof["gather"] = {"unit": "G gathers/s", "achieved": round(rate / 1e9, 3), "peak": gather_peak_g, "frac": round(rate / gp, 4),
+                          "peak_source": "tools/ubench_gather.hip, profiles/r05_ubench_gather.txt: measured random 64-byte gather rate for this table footprint "
+                                         "(a gather moves 64 B, not 128: 128-byte entries saturate at half the rate)"}
         roof["alu"] = {"unit": "G mixed-add/s", "achieved": round(rate / 1e9, 3), "peak": round(peak / 1e9, 3),
                        "frac": round(rate / peak, 4),
                        "peak_source": "instruction issue: 31.2 T v_mad_u64_u32/s (profiles/r02_ubench29_gfx950.txt) / 1548 multiplier "
