@@ -294,7 +294,7 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
     // every workgroup flushes from its own offset: 256 of them walking the counters in the same order met at the same addresses
     // (k_hist 36.8 -> 33.1 us on average, profiles/r04_ab_chain_blocks.txt section 5)
     const uint32_t rot = ((blockIdx.y * gridDim.x + blockIdx.x) * 128u) & (NBUCKET - 1);
-    for (uint32_t i = threadIdx.x; i < NBUCKET; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < NBUCKET; i += blockDim.x) {      // (r05: two counters per 64-bit atomic change nothing: 35.6 us either way, profiles/r05_ab_misc.txt)
         const uint32_t b = (i + rot) & (NBUCKET - 1);
         uint32_t c = h[b];
         if (c) atomicAdd(&cnt[b], c);
