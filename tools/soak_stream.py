@@ -1,6 +1,7 @@
 """Randomised soak of the STREAMED commit in slot mode on the GPU (not part of the test suite): random lengths around the chunking
 thresholds, random value mixtures (no hot buckets / bits and small values / every scalar equal / one scalar hot), pinned and pageable
-sources, two keys on two host threads -- every commitment against the oracle; prints the slot-mode counters at the end.
+sources, two keys on two host threads, plus (r05) a 3-shard multi-device key on a third thread -- every commitment against the oracle; prints the
+slot-mode counters at the end.
 usage: python tools/soak_stream.py [seed] [seconds]"""
 import os, sys, threading, time
 import numpy as np
@@ -55,7 +56,36 @@ def worker(cid, wseed):
     ck.close()
 
 
-th = [threading.Thread(target=worker, args=(c, seed * 7 + c)) for c in (0, 1)]
+def worker_multi(cid, wseed, shards):
+    """r05: the streamed commit on a MULTI-DEVICE key (logical shards on the visible devices): every shard streams its own stripes, the device copy
+    is assembled by peer copies -- commitment against the oracle, device copy against the source, bytes per link against the stripe count"""
+    import torch
+    rng = np.random.default_rng(wseed)
+    n_key = 1 << 20
+    ck = S.CommitmentKey.setup_synthetic_multi(cid, n_key, seed=200 + cid, n_devices=shards)
+    bases = ck.bases()
+    t0, done, h2d = time.time(), 0, 0
+    try:
+        while time.time() - t0 < budget:
+            n = int(rng.choice([n_key, n_key - 1, (1 << 19) + 3, int(rng.integers(shards << 11, n_key))]))
+            v = seeded_scalars(O, cid, n, int(rng.integers(0, 1 << 30)), ("uniform", "trace")[int(rng.integers(0, 2))])
+            d = torch.zeros((n, 4), dtype=torch.int64, device="cuda") if rng.random() < 0.7 else None
+            got = ck.commit_upload(v, dev_copy=d)
+            assert np.array_equal(got, O.msm(cid, v, bases[:n])), ("multi commit_upload", cid, n)
+            if d is not None:
+                torch.cuda.synchronize()
+                assert np.array_equal(d.cpu().numpy().view(np.uint64), v), ("multi device copy", cid, n)
+            h2d += n * 32
+            done += 1
+        st = [ck.shard_stats(j) for j in range(shards)]
+        assert sum(x["h2d_bytes"] for x in st) == h2d, (st, h2d)          # every byte crossed exactly one link, once
+        stats[f"multi{shards}_{cid}"] = (done, ck.msm_stats(), [x["h2d_bytes"] for x in st])
+    except Exception as e:
+        errs.append(repr(e))
+    ck.close()
+
+
+th = [threading.Thread(target=worker, args=(c, seed * 7 + c)) for c in (0, 1)] + [threading.Thread(target=worker_multi, args=(0, seed * 7 + 5, 3))]
 [t.start() for t in th]
 [t.join() for t in th]
 assert not errs, errs
