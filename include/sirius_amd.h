@@ -147,7 +147,9 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
  * src/table/circuit_runner.rs:71-107), the result is device memory: the host never builds the concatenated copy.
  * srs_commit_upload_columns = `ck.commit(&concatenate_with_padding(advice, 2^k))` of run_sps_protocol_* (src/plonk/mod.rs:441-447)
  * in one call: groups of columns go up while the MSM of the previous group runs; dev_copy (srs_concat_len elements, or NULL)
- * receives the assembled witness for the prover calls that follow. */
+ * receives the assembled witness for the prover calls that follow.  Sharded keys (srs_ck_create_multi / srs_ck_create_sharded) stream
+ * per shard: a device is sent only its stripes of the columns and zeroes its stripes of the padding (the sharded form returns the
+ * rank's PARTIAL commitment and fills the rank's stripes of dev_copy, as srs_commit_upload does). */
 size_t srs_concat_len(const size_t *lens, size_t n_columns, size_t pad_size);
 int srs_concat_with_padding(srs_fe *out_dev, const srs_fe *const *columns_host, const size_t *lens, size_t n_columns, size_t pad_size,
                             void *stream);

@@ -936,10 +936,65 @@ void upload_range(fe_t *dst, const std::vector<Seg> &segs, size_t a, size_t b, h
     if (b > at) SRS_HIP_CHECK(hipMemsetAsync(dst + at, 0, (b - at) * sizeof(fe_t), cs));
 }
 
+// The same for ONE RANK of a block-cyclic sharding: uploads rank R's stripes (2^STRIPE_LOG elements; stripe s belongs to rank s % W) of the global
+// range [a, b) of the concatenation -- pieces + zero padding up to the next piece / n -- to their global positions in dst.  Per piece and kind
+// (data / padding) the whole stripes are ONE strided copy (or strided memset), partial stripes at the ends of a piece one small operation
+// each: a dozen operations per chunk whatever its size.  Pieces may start anywhere (stripes are global).  -> data elements copied.
+size_t upload_stripes(fe_t *dst, const std::vector<Seg> &segs, size_t n, size_t a, size_t b, uint32_t R, uint32_t W, hipStream_t cs) {
+    const size_t SL = (size_t)1 << msm::STRIPE_LOG, pitch = (size_t)W * SL * sizeof(fe_t);
+    size_t copied = 0;
+    auto over = [&](size_t lo, size_t hi, const fe_t *src /* element at global offset lo, or nullptr: zeros */) {
+        lo = std::max(lo, a);
+        const size_t lo0 = lo;
+        hi = std::min(hi, b);
+        if (lo >= hi) return;
+        auto op1 = [&](size_t g, size_t len) {
+            if (src) { SRS_HIP_CHECK(hipMemcpyAsync(dst + g, src + (g - lo0), len * sizeof(fe_t), hipMemcpyHostToDevice, cs)); copied += len; }
+            else SRS_HIP_CHECK(hipMemsetAsync(dst + g, 0, len * sizeof(fe_t), cs));
+        };
+        size_t s_lo = lo / SL;
+        const size_t s_last = (hi - 1) / SL;
+        if (s_lo == s_last) {                              // inside one stripe
+            if (s_lo % W == R) op1(lo, hi - lo);
+            return;
+        }
+        if (lo % SL) {                                     // partial first stripe
+            if (s_lo % W == R) op1(lo, (s_lo + 1) * SL - lo);
+            ++s_lo;
+        }
+        const size_t full_end = hi / SL;                   // stripes [s_lo, full_end) are whole
+        if (hi % SL && full_end % W == R) op1(full_end * SL, hi - full_end * SL);          // partial last stripe
+        if (s_lo < full_end) {
+            const size_t s0 = s_lo + ((R + W - s_lo % W) % W);
+            if (s0 < full_end) {
+                const size_t rows = (full_end - s0 + W - 1) / W, g = s0 * SL;
+                if (src) {
+                    SRS_HIP_CHECK(hipMemcpy2DAsync(dst + g, pitch, src + (g - lo0), pitch, SL * sizeof(fe_t), rows, hipMemcpyHostToDevice, cs));
+                    copied += rows * SL;
+                } else {
+                    SRS_HIP_CHECK(hipMemset2DAsync(dst + g, pitch, 0, SL * sizeof(fe_t), rows, cs));
+                }
+            }
+        }
+    };
+    size_t at = 0;                                         // everything before the first piece is padding too
+    for (size_t k = 0; k < segs.size(); ++k) {
+        const Seg &sg = segs[k];
+        if (sg.off > at) over(at, sg.off, nullptr);
+        // (the data pointer handed to `over` must point at the element of global offset max(sg.off, a))
+        const size_t d_lo = std::max(sg.off, a);
+        if (sg.len && d_lo < sg.off + sg.len) over(sg.off, sg.off + sg.len, sg.src + (d_lo - sg.off));
+        at = std::max(at, sg.off + sg.len);
+    }
+    if (n > at) over(at, n, nullptr);
+    return copied;
+}
+
 // the streamed commit of srs_commit_upload / srs_commit_upload_columns (single-device key): chunk j goes up on the key's copy
 // stream while the MSM of chunk j - 1 runs on the caller's stream; `cuts` = chunk boundaries (element offsets, first 0, last n)
-// A key sharded over processes (world > 1; one contiguous source, chunk boundaries multiples of world * 2^10): every chunk brings up and
-// accumulates only THIS rank's block-cyclic stripes of its range -- the same overlap of upload and MSM, 1 / world of both per rank.
+// A key sharded over processes (world > 1; chunk boundaries multiples of world * 2^10): every chunk brings up and accumulates only THIS rank's
+// block-cyclic stripes of its range -- the same overlap of upload and MSM, 1 / world of both per rank (r05: from any list of pieces, so the
+// column form streams too: upload_stripes).
 // The stream resources of whoever runs the commit -- a single-device key handle, or one shard of a multi-device key -- and, for a
 // shard, where its stripes are forwarded once they are in its HBM (the device copy the caller asked for lives on the process's device).
 struct StreamRes {
@@ -997,19 +1052,12 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
     auto upload = [&](size_t j) {
         if (W == 1) {
             upload_range(dst, segs, cut[j], cut[j + 1], ck->copy_stream);
-        } else {                             // one strided copy of the rank's stripes of [cut_j, cut_j+1) + the ragged last stripe
-            const fe_t *src = segs[0].src + cut[j];
-            fe_t *d = dst + cut[j];
-            const size_t len = cut[j + 1] - cut[j], full = len / SL;
-            const size_t mine = full > R ? (full - R + W - 1) / W : 0;
-            if (mine)
-                SRS_HIP_CHECK(hipMemcpy2DAsync(d + R * SL, W * SL * sizeof(fe_t), src + R * SL, W * SL * sizeof(fe_t), SL * sizeof(fe_t), mine,
-                                               hipMemcpyHostToDevice, ck->copy_stream));
-            if (len % SL && full % W == R)
-                SRS_HIP_CHECK(hipMemcpyAsync(d + full * SL, src + full * SL, (len % SL) * sizeof(fe_t), hipMemcpyHostToDevice, ck->copy_stream));
+        } else {                             // the rank's stripes of [cut_j, cut_j+1): strided copies per piece, strided memsets for the padding
+            const size_t up = upload_stripes(dst, segs, n, cut[j], cut[j + 1], R, W, ck->copy_stream);
+            if (ck->h2d_bytes) *ck->h2d_bytes += up * sizeof(fe_t);
         }
         SRS_HIP_CHECK(hipEventRecord(ck->events[j], ck->copy_stream));
-        if (ck->h2d_bytes) *ck->h2d_bytes += (W == 1 ? cut[j + 1] - cut[j] : local(cut[j], cut[j + 1])) * sizeof(fe_t);
+        if (ck->h2d_bytes && W == 1) *ck->h2d_bytes += (cut[j + 1] - cut[j]) * sizeof(fe_t);
         if (ck->peer_dst && W > 1) {         // the same stripes, from this device's landing buffer to the process's device copy
             SRS_HIP_CHECK(hipStreamWaitEvent(ck->peer_stream, ck->events[j], 0));
             const size_t len = cut[j + 1] - cut[j], full = len / SL;
@@ -1168,12 +1216,11 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0, double
 // shard's device).  The device copy the caller asked for lives on the process's device: shard 0 (same device) uploads straight into it, the
 // other shards forward their stripes to it with peer copies behind their uploads (xGMI on a multi-GPU node) -- the whole witness never
 // crosses ONE link, and nothing is uploaded twice.  The caller's stream waits for the forwarded stripes; the partial sums are added here.
-int multi_commit_streamed(srs_ck *ck, const fe_t *host, size_t n, fe_t *dev_copy, int repr, hipStream_t st, srs_affine *out) {
+int multi_commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, fe_t *dev_copy, int repr, hipStream_t st, srs_affine *out) {
     const uint32_t world = (uint32_t)ck->shards.size();
     const int home = g_device < 0 ? 0 : g_device;
     const size_t align = (size_t)world << msm::STRIPE_LOG;
     const std::vector<size_t> cut = commit_cuts(n, align, n / world, key_density(ck->shards[0]->key));
-    std::vector<Seg> segs(1, Seg{host, 0, n});
     std::vector<xyzz_t> parts(world);
     hipEvent_t ready = nullptr;
     if (dev_copy) {                              // nothing may land in the device copy while earlier work on the caller's stream still reads it
@@ -1267,7 +1314,8 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
         // multi-device key: every shard streams its stripes over its own link, overlapped with its MSM; the device copy is assembled on the
         // process's device by peer copies (multi_commit_streamed).  SRS_MULTI_STREAMED=0: the r04 path below (A/B)
         return guarded([&]() -> int {
-            return multi_commit_streamed(ck, reinterpret_cast<const fe_t *>(scalars_host), n, reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
+            std::vector<Seg> segs(1, Seg{reinterpret_cast<const fe_t *>(scalars_host), 0, n});
+            return multi_commit_streamed(ck, segs, n, reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
         });
     }
     if (!ck->shards.empty() || ck->key.world != 1 || n == 0) {
@@ -1343,16 +1391,24 @@ int srs_commit_upload_columns(srs_ck *ck, const srs_fe *const *columns_host, con
             off += std::max(lens[c], pad_size);
         }
         fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
-        const bool streamed = ck->shards.empty() && ck->key.world == 1 && n != 0;
+        static const bool multi_streamed = [] { const char *e = std::getenv("SRS_MULTI_STREAMED"); return !(e && e[0] == '0'); }();
+        if (!ck->shards.empty() && multi_streamed && n >= ((size_t)ck->shards.size() << (msm::STRIPE_LOG + 1)))
+            // multi-device key (r05): every shard streams ITS stripes of the columns (and of their zero padding) over its own link
+            return multi_commit_streamed(ck, segs, n, dst, repr, st, out);
+        const bool sharded_streamed = ck->shards.empty() && ck->key.world > 1 && n >= ((size_t)ck->key.world << (msm::STRIPE_LOG + 1));
+        const bool streamed = ck->shards.empty() && (ck->key.world == 1 || sharded_streamed) && n != 0;
         if (!dst) {
             ck->staging.reserve(Arena::pad((n + 1) * sizeof(fe_t)) + 256);
             ck->staging.reset();
             dst = ck->staging.take<fe_t>(n + 1);
         }
-        if (!streamed) {                     // multi-device / sharded keys: assemble in HBM, then the ordinary commit
+        if (!streamed) {                     // (short vectors on multi-device / sharded keys) assemble in HBM, then the ordinary commit
             upload_range(dst, segs, 0, n, st);
             return srs_commit(ck, reinterpret_cast<const srs_fe *>(dst), n, SRS_SPACE_DEVICE, repr, stream, out);
         }
+        if (sharded_streamed)                // process-sharded key (r05): the rank's stripes of the columns, chunk boundaries on world * 2^10
+            return commit_streamed(ck, segs, n, commit_cuts(n, (size_t)ck->key.world << msm::STRIPE_LOG, n / ck->key.world, key_density(ck->key)), dst,
+                                   repr, st, out);
         const size_t align = (uniform && pad_size >= 1024) ? pad_size : 1024;
         std::vector<size_t> cut = commit_cuts(n, align, 0, key_density(ck->key));
         return commit_streamed(ck, segs, n, cut, dst, repr, st, out);

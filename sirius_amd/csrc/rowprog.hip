@@ -2532,7 +2532,8 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         uint32_t deg = 3;
         size_t at = 0;
         static const bool f_multi = [] { const char *e = std::getenv("SRS_PG_F_MULTI"); return !(e && e[0] == '0'); }();
-        while (f_multi && at < order.size() && deg + std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at) <= PG_F_TAIL_MAXDEG) {
+        // (dynamic LDS of a launch stays below 48 KiB: degree <= 23 after the launch -- every table size an NTT of <= 2^28 allows; beyond, the r03 flow)
+        while (f_multi && at < order.size() && deg + std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at) <= 23) {
             // up to six levels per launch (k_pg_F_multi); SRS_PG_F_MULTI=0: one launch per level + the one-workgroup tail (r03 flow, A/B)
             const uint32_t nlev = (uint32_t)std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at);
             PgFMulti tm;

@@ -371,6 +371,11 @@ inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t
     return hipSuccess;
 }
 
+inline hipError_t hipMemset2DAsync(void *d, size_t pitch, int value, size_t width, size_t height, hipStream_t = nullptr) {
+    for (size_t r = 0; r < height; ++r) std::memset((char *)d + r * pitch, value, width);
+    return hipSuccess;
+}
+
 namespace hipemu {
 // Run kernel(args...) over grid x block: the threads of a block are fibers; the blocks of a large grid are dealt to a few
 // host threads (every piece of emulator state is thread_local), a small grid runs on the calling thread.

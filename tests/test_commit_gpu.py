@@ -600,6 +600,36 @@ def _concat_cases(S, O, cid, make_dev, k=11):
     assert np.array_equal(mk.commit_upload_columns(cols, rows), want)
     mk.close()
     ck.close()
+    # r05: the column form STREAMS on sharded keys too -- every shard / rank uploads its own stripes of the columns and memsets its stripes of the
+    # padding (upload_stripes): (a) a multi-device key with a device copy assembled by peer copies, bytes per link = the data elements of the
+    # shard's stripes; (b) a key sharded over "processes": rank r's call returns its partial commitment and fills ITS stripes of its buffer
+    n, SL = W.shape[0], 1024
+    data = np.zeros(n, dtype=bool)
+    at = 0
+    for c in cols:
+        data[at:at + c.shape[0]] = True
+        at += max(c.shape[0], rows)
+    for shards in (2, 3):
+        mk = S.CommitmentKey.create_multi(cid, bases, shards)
+        d = make_dev(n)
+        assert np.array_equal(mk.commit_upload_columns(cols, rows, dev_copy=d), want), shards
+        assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(-1, 4), W), shards
+        if n >= shards << 11:                # the streamed path (short vectors take the one-copy path and report no traffic)
+            for j in range(shards):
+                mine = sum(int(data[s * SL:(s + 1) * SL].sum()) for s in range(j, (n + SL - 1) // SL, shards))
+                assert mk.shard_stats(j)["h2d_bytes"] == mine * 32, (shards, j, mk.shard_stats(j), mine)
+        mk.close()
+    world = 2
+    parts = []
+    for r in range(world):
+        rk = S.CommitmentKey(cid, bases, rank=r, world=world)
+        d = make_dev(n)
+        parts.append(rk.commit_upload_columns(cols, rows, dev_copy=d))
+        got = d.cpu().numpy().view(np.uint64).reshape(-1, 4)
+        for s_ in range(r, (n + SL - 1) // SL, world):
+            assert np.array_equal(got[s_ * SL:(s_ + 1) * SL], W[s_ * SL:(s_ + 1) * SL]), (r, s_)
+        rk.close()
+    assert np.array_equal(S.point_sum(cid, np.stack(parts)), want)
 
 
 @pytest.mark.parametrize("cid", [0, 1])

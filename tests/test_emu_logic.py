@@ -585,6 +585,7 @@ def test_emu_concatenate_with_padding(emu, oracle):
     import torch
     from test_commit_gpu import _concat_cases
     _concat_cases(emu, oracle, 1, lambda n: torch.full((n, 4), 7, dtype=torch.int64), k=8)
+    _concat_cases(emu, oracle, 0, lambda n: torch.full((n, 4), 7, dtype=torch.int64), k=10)     # 5 * 2^10 scalars: the sharded forms stream (>= 2 stripes per shard)
 
 
 def test_emu_sharded_fold_with_rotations(emu, oracle):
