@@ -485,7 +485,7 @@ int srs_pg_compute_F(srs_structure *S, const srs_fe *betas, size_t n_betas, cons
                      srs_fe *poly_F);
 /* compute_G (:308-425) with FoldedWitness (folded_witness.rs:20-180) fused (never materialised):
  * poly_G[fft_points_count_G] = ifft_X( sum_i pow_i(betas_stroke) f_i( sum_j L_j(X) w_j ) ); W[0] / challenges[0] = accumulator,
- * W[1..] = incoming traces; n_instances = L + 1 (a power of two, <= 4). */
+ * W[1..] = incoming traces; n_instances = L + 1 (a power of two, <= 16: `const L` is generic in the reference). */
 int srs_pg_compute_G(srs_structure *S, const srs_fe *betas_stroke, size_t n_betas, const srs_fe *const *W,
                      const srs_fe *const *challenges, size_t n_challenges, size_t n_instances, int space,
                      int reference_compat, void *stream, srs_fe *poly_G);
@@ -502,7 +502,7 @@ int srs_pg_calculate_e(const srs_fe *poly_F, size_t n_F, const srs_fe *poly_K, s
 int srs_lagrange_eval(const srs_fe *X, uint32_t log_n, srs_fe *out);
 /* UnivariatePoly::eval (src/polynomial/univariate.rs:67-75); host */
 int srs_poly_eval(const srs_fe *coeffs, size_t n, const srs_fe *x, srs_fe *out);
-/* ProtoGalaxy::fold_witness (protogalaxy/mod.rs:176-210): out[i] = sum_{j<J} coefs[j] * W[j][i]  (J <= 4) */
+/* ProtoGalaxy::fold_witness (protogalaxy/mod.rs:176-210): out[i] = sum_{j<J} coefs[j] * W[j][i]  (J <= 16) */
 int srs_fold_lincomb(int field, srs_fe *out, const srs_fe *const *W, const srs_fe *coefs, size_t J, size_t n,
                      int space, void *stream);
 /* The same fold on a process-per-GPU rank: DEVICE vectors; only the elements of the rank's block-cyclic stripes (2^10 elements

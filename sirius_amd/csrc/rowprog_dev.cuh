@@ -18,7 +18,7 @@ constexpr uint32_t RP_THREADS = 128;
 constexpr uint32_t DMAX = 8;   // cross terms kept in VGPRs per pass; higher degrees take ceil(d / 8) passes over the points
 constexpr uint32_t DEGREE_LIMIT = 255;   // evaluation points 0..d must stay < 2^8 (small_times)
 
-constexpr uint32_t JMAX = 4;   // witnesses combined by one advice load (cross terms: 2; ProtoGalaxy G: L + 1 <= 4)
+constexpr uint32_t JMAX = 16;  // witnesses combined by one advice load (cross terms: 2; ProtoGalaxy G: L + 1 <= 16)
 
 // everything a row needs besides the program
 struct RowCtx {

@@ -112,6 +112,10 @@ def test_emu_protogalaxy(emu, oracle):
     run_pg_case(emu, oracle, 3, [5, 3, 2], 1, False)
     run_pg_case(emu, oracle, 8, [5, 3], 1, True)
     run_pg_case(emu, oracle, 4, [2], 3, False)
+    run_pg_case(emu, oracle, 4, [2], 7, False)             # r05: L + 1 up to 16 (JMAX)
+    run_pg_case(emu, oracle, 5, [3, 2], 15, True)
+    with pytest.raises(emu.SiriusAmdError, match="unsupported number of traces"):      # 32 instances: refused, not truncated
+        run_pg_case(emu, oracle, 4, [2], 31, False)
 
 
 def test_emu_protogalaxy_polynomial_tree_F(emu, oracle):

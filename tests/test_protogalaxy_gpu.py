@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("k,gate_T,L,compat", [(4, [2], 1, True), (4, [2], 1, False), (5, [3, 2], 1, True),
                                               (3, [5, 3, 2], 1, False), (8, [5, 3], 1, True), (10, [5, 3], 1, False),
-                                              (4, [2], 3, False), (7, [5], 3, True),
+                                              (4, [2], 3, False), (7, [5], 3, True), (4, [2], 7, True), (10, [5, 3], 7, False), (5, [3, 2], 15, True),   # L up to 15 (r05)
                                               (10, [5, 3], 1, True), (11, [5, 3], 3, False)])   # k >= 10 with [5, 3]: specialised leaf kernel
 def test_protogalaxy_vs_oracle(srs, oracle, k, gate_T, L, compat):
     # the reference's own protogalaxy tests fold L = 3 traces at k = 10 (src/nifs/protogalaxy/tests.rs:187-309)
