@@ -275,14 +275,32 @@ def test_emu_bench_harness():
     import json
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emu", "--k", "3", "--log-key", "7", "--steps", "1", "--warmup", "0",
-                        "--cpu-threads", "2", "--no-extras", "--verify"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--cpu-threads", "2", "--verify"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    # the secondary lines run too (tiny sizes); device_resident asserts inside bench.py that every resident commit == the streamed commit of the same witness
+    assert line["secondary"]["device_resident"]["ms_per_step"] > 0 and line["secondary"]["true_leaf_rows"]["ms_per_step"] > 0
     assert line["verify"]["match"] and line["verify"]["first_step_digest"] == line["verify"]["oracle_first_step_digest"]     # --verify: first step == oracle chain
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["config"]["workload"].startswith("cyclefold_poseidon") and line["cpu_baseline"]["kind"] == "port"
+
+
+def test_emu_bench_resident_chain():
+    """bench.py --resident (the step with its inputs already in HBM: secondary.device_resident's form) folds the SAME chain as the headline
+    form, which uploads the witness inside the step: equal state_digest after the same number of steps (resident runs one extra from-host
+    step first, so that both witnesses have been committed by the streamed path -- every resident commitment is asserted equal inside)."""
+    import json
+    import sys
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--emu", "--k", "3", "--log-key", "7", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    res = _run_all([("host", common + ["--steps", "3"], dict(os.environ)), ("resident", common + ["--steps", "2", "--resident"], dict(os.environ))])
+    lines = {}
+    for tag, r in res.items():
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        lines[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert lines["host"]["state_digest"] == lines["resident"]["state_digest"]
+    assert "inputs" in lines["resident"]["config"] and "inputs" not in lines["host"]["config"]
 
 
 def test_emu_commit_vs_eip196():
