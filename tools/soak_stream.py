@@ -1,6 +1,6 @@
 """Randomised soak of the STREAMED commit in slot mode on the GPU (not part of the test suite): random lengths around the chunking
 thresholds, random value mixtures (no hot buckets / bits and small values / every scalar equal / one scalar hot), pinned and pageable
-sources, two keys on two host threads, plus (r05) a 3-shard multi-device key on a third thread -- every commitment against the oracle; prints the
+sources, two keys on two host threads, plus (r05) a 3-shard multi-device key on a third thread and the column form on a fourth -- every commitment against the oracle; prints the
 slot-mode counters at the end.
 usage: python tools/soak_stream.py [seed] [seconds]"""
 import os, sys, threading, time
@@ -85,7 +85,46 @@ def worker_multi(cid, wseed, shards):
     ck.close()
 
 
-th = [threading.Thread(target=worker, args=(c, seed * 7 + c)) for c in (0, 1)] + [threading.Thread(target=worker_multi, args=(0, seed * 7 + 5, 3))]
+def worker_columns(cid, wseed, shards):
+    """r05: the COLUMN form (concatenate_with_padding assembled in HBM) streamed per shard on a multi-device key: random column lengths and pads"""
+    import torch
+    rng = np.random.default_rng(wseed)
+    n_key = 1 << 20
+    ck = S.CommitmentKey.setup_synthetic_multi(cid, n_key, seed=300 + cid, n_devices=shards)
+    bases = ck.bases()
+    t0, done = time.time(), 0
+    try:
+        while time.time() - t0 < budget:
+            pad = int(rng.choice([0, 1, 1 << 15, (1 << 16) + 7, 1 << 17]))
+            cols, tot = [], 0
+            while True:
+                ln = int(rng.choice([0, 1, 1000, 1 << 15, (1 << 16) - 3, (1 << 17) + 11, int(rng.integers(1, 1 << 17))]))
+                if tot + max(ln, pad) > n_key or (tot >= n_key // 2 and rng.random() < 0.3):
+                    break
+                cols.append(seeded_scalars(O, cid, ln, int(rng.integers(0, 1 << 30)), ("uniform", "trace")[int(rng.integers(0, 2))]) if ln
+                            else np.zeros((0, 4), np.uint64))
+                tot += max(ln, pad)
+            if tot == 0:
+                continue
+            W = np.zeros((tot, 4), np.uint64)
+            at = 0
+            for c in cols:
+                W[at:at + c.shape[0]] = c
+                at += max(c.shape[0], pad)
+            d = torch.full((tot, 4), 7, dtype=torch.int64, device="cuda")
+            got = ck.commit_upload_columns(cols, pad, dev_copy=d)
+            assert np.array_equal(got, O.msm(cid, W, bases[:tot])), ("columns commit", cid, tot, pad, [c.shape[0] for c in cols])
+            torch.cuda.synchronize()
+            assert np.array_equal(d.cpu().numpy().view(np.uint64), W), ("columns device copy", cid, tot, pad)
+            done += 1
+        stats[f"columns{shards}_{cid}"] = (done, ck.msm_stats())
+    except Exception as e:
+        errs.append(repr(e))
+    ck.close()
+
+
+th = [threading.Thread(target=worker, args=(c, seed * 7 + c)) for c in (0, 1)] + [threading.Thread(target=worker_multi, args=(0, seed * 7 + 5, 3)),
+                                                                                 threading.Thread(target=worker_columns, args=(1, seed * 7 + 6, 3))]
 [t.start() for t in th]
 [t.join() for t in th]
 assert not errs, errs
