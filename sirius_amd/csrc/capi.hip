@@ -1152,7 +1152,10 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
 }
 
 // bucket additions per scalar of the key's last streamed commit (0: none yet)
-double key_density(const msm::Key &k) { return k.last_scalars ? (double)k.last_entries / (double)k.last_scalars : 0.0; }
+double key_density(const msm::Key &k) {
+    if (msm::wcc_next(k)) return 1.0;        // the wide chunked path accumulates faster than the upload: the even, upload-bound cuts
+    return k.last_scalars ? (double)k.last_entries / (double)k.last_scalars : 0.0;
+}
 
 // chunk boundaries of a streamed commit of n elements; `align`: boundaries are multiples of it (columns are never split)
 // `n_eff`: the scalars one device accumulates (n / world on a sharded key): what the number of chunks is chosen from

@@ -104,6 +104,10 @@ struct Key {
     bool slot_ovf_on[LANDING_SLOTS] = {};   // ... with its overflow kernels launched
     uint32_t slot_batch[LANDING_SLOTS] = {};
     uint64_t stat_slot_sets = 0, stat_hot_sets = 0, stat_redo = 0, stat_other_sets = 0;   // srs_ck_msm_stats
+    // wide chunked commit (msm.hip: k_accum_wb; opt-in): the sets of a streamed commit on the 20-bit windows
+    xyzz_t *wb = nullptr;             // [NSEG_W][NBUCKET] persistent bucket sums of the running commit (64 MiB; owned by the key)
+    bool wcc_active = false;          // the running chunked commit takes this path (its first set decides)
+    bool wcc_set[LANDING_SLOTS] = {}; // landing slot -> the set ran on this path (its hot-bucket report is in h_ovf)
     Arena arena;              // per-key scratch (grow-only)
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
 };
@@ -150,6 +154,7 @@ void reserve(Key &k, uint32_t n_max, uint32_t batch);
 // been switched, so the second run is complete); note_commit() records what the finished commit saw for the next prediction (on at
 // once -- and from a key's first commit --, off after three commits in a row without hot buckets).
 bool overflow_missed(const Key &k, uint32_t slot);
+bool wcc_next(const Key &k);                 // the key's next streamed commit takes the wide chunked path (its chunks want the even, upload-bound cuts)
 void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots);
 
 // Chunked commit with a DEFERRED TAIL (one 16-bit-window MSM cut into `sets` <= BATCH_ARGS chunks of <= n_max scalars, all over one

@@ -527,6 +527,36 @@ def test_emu_slot_mode_commits():
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_emu_wide_chunked_commit():
+    """msm.hip's opt-in wide chunked commit (SRS_MSM_WCC; profiles/r05_ab_wide_chunked.txt: measured, not adopted): the sets of a streamed commit
+    on the 20-bit windows -- one thread per (segment, bucket) into persistent bucket sums, threads ordered by chain length; a bucket with more than
+    512 entries in one set makes the commit run again on the standard pipeline (redo) -- against the oracle, both curves."""
+    import sys
+    code = (
+        "import os, sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from sirius_amd import _lib\n"
+        f"_lib.load({EMU_LIB!r})\n"
+        "import sirius_amd as S, oracle as O\n"
+        "from conftest import seeded_scalars\n"
+        "n = 1700\n"
+        "for cid, kinds in ((0, ('uniform', 'trace')), (1, ('uniform',))):\n"
+        "    bases = O.make_bases(cid, 7 + cid, n); ck = S.CommitmentKey(cid, bases)\n"
+        "    assert ck.has_wide_table\n"
+        "    for rep, kind in enumerate(kinds):\n"
+        "        sc = seeded_scalars(O, cid, n - 7 * rep, 20 + rep, kind)\n"
+        "        assert np.array_equal(ck.commit_upload(sc), O.msm(cid, sc, bases[:len(sc)])), (cid, rep, kind)\n"
+        "    st = ck.msm_stats(); assert st['slot_sets'] == 0 and st['redo'] == 0 and st['other_sets'] >= 2 * len(kinds), st\n"
+        "    if cid == 0:\n"
+        "        v = O.ints_to_mont(O.SCALAR_FIELD[cid], [5] * n); assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases[:n]))      # ONE bucket holds everything\n"
+        "        st = ck.msm_stats(); assert st['redo'] == 1 and st['hot_sets'] >= 2, st\n"
+        "    ck.close()\n"
+        "print('ok')\n")
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_WCC="2", SRS_MSM_WIDE="1", SRS_COMMIT_CHUNKS="3"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_emu_long_level0_parts():
     """msm.hip l0_log_for: 64 gathered additions per level-0 thread (the setting of large MSMs), forced on a small one."""
     import sys
