@@ -1907,11 +1907,11 @@ __global__ void SRS_KERNEL_BOUNDS(256, 1)
 //   k_wcc_classes : histogram of min(count, 63) over the 2^19 buckets
 //   k_wcc_perm    : perm[] = the buckets by class, longest chains first (a counting sort; the order inside a class is arbitrary, the sums
 //                   do not depend on it), empty buckets last
-//   k_accum_wb    : thread u takes bucket perm[u].  A bucket with more than WCC_CAP entries in ONE set (a hot bucket: witnesses of 0 / 1 /
+//   k_accum_wb    : thread u takes bucket perm[u].  A bucket with more than max(WCC_CAP, 4 x mean) entries in ONE set (a hot bucket: witnesses of 0 / 1 /
 //                   small values) is NOT accumulated but counted in *rep: the host then runs the commit again on the standard pipeline and
 //                   the key stops choosing this path (overflow_missed / note_commit, as slot mode's prediction)
 // after the last set the usual wide-window reduction runs on wb (k_rowcol from_buckets, k_reduce_final, k_wide_combine).
-constexpr uint32_t WCC_CLASSES = 64, WCC_CAP = 512;
+constexpr uint32_t WCC_CLASSES = 64, WCC_CAP = 256;
 __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     k_wcc_classes(const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t *__restrict__ bins) {
     __shared__ uint32_t h[WCC_CLASSES];
@@ -1947,7 +1947,7 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum_wb(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ plan, size_t plan_stride, const uint32_t *__restrict__ perm,
                const uint32_t *__restrict__ bins, const affine_t *__restrict__ table, xyzz_t *__restrict__ wb, int first,
-               uint32_t *__restrict__ rep) {
+               uint32_t *__restrict__ rep, uint32_t cap) {
     using E29 = Ec29<C>;
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= NSEG_W * NBUCKET) return;
@@ -1959,7 +1959,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     const uint32_t *off = plan + (size_t)(g / NBUCKET) * plan_stride + (g % NBUCKET);
     const uint32_t s = off[0], e = off[1];
     xyzz29_t acc = first ? E29::identity() : E29::unpack(wb[g]);
-    if (e - s > WCC_CAP) {                                       // hot bucket: reported, not accumulated (the commit is run again)
+    if (e - s > cap) {                                           // hot bucket: reported, not accumulated (the commit is run again)
         atomicAdd(rep, 1u);
         if (first) wb[g] = E29::pack(acc);
         return;
@@ -2731,6 +2731,8 @@ static int wcc_mode_env() {
     return v;
 }
 static bool use_wcc(const Key &k) { return k.table_w != nullptr && (wcc_mode_env() == 2 || (wcc_mode_env() == 1 && !k.expect_ovf)); }
+// (A WHOLE wide-window MSM as one such set -- no parts, no levels -- was measured too: 25.0 against 19.5 ms at 2^24, the short top window gives
+// the low 2^14 buckets 3.5x the mean chain and 2^19 threads are two rounds of the chip; profiles/r05_ab_wide_chunked.txt section 3.)
 bool wcc_next(const Key &k) { return use_wcc(k); }
 static size_t workspace_bytes_wcc(uint32_t n) {
     return workspace_bytes_wide(n) + Arena::pad((size_t)NSEG_W * NBUCKET * sizeof(uint32_t)) + Arena::pad(4 * WCC_CLASSES * sizeof(uint32_t)) + 4096;
@@ -2741,6 +2743,9 @@ static bool enqueue_wcc_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t 
     if (n == 0) return false;
     const bool first = fold == FOLD_FIRST, last = fold == FOLD_LAST;
     const WideShape w = wide_shape(n);
+    // a bucket is hot when it holds several times what a set without zero digits gives the heaviest regular ones (the short top window adds
+    // n / 2^14 entries to each of the low 2^14 buckets: ~3.5x the mean)
+    const uint32_t cap = std::max<uint32_t>(WCC_CAP, 4u * (uint32_t)(w.M >> 19) + 64u);
     if (!k.wb) SRS_HIP_CHECK(hipMalloc((void **)&k.wb, (size_t)NSEG_W * NBUCKET * sizeof(xyzz_t)));
     if (!k.h_ovf) {
         SRS_HIP_CHECK(hipHostMalloc((void **)&k.h_ovf, 2 * (size_t)LANDING_SLOTS * BATCH_ARGS * sizeof(uint32_t)));
@@ -2801,7 +2806,7 @@ static bool enqueue_wcc_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t 
     SRS_LAUNCH(k_wcc_perm, (NSEG_W * NBUCKET / 1024), (1024), 0, stream, (const uint32_t *)plan, w.plan_stride, (const uint32_t *)bins, cls_cur, perm);
     SRS_LAUNCH_TIMED("msm_accum0", n, (k_accum_wb<C>), (NSEG_W * NBUCKET / ACC_THREADS), (ACC_THREADS), 0, stream, (const uint32_t *)sorted,
                      (const uint32_t *)plan, w.plan_stride, (const uint32_t *)perm, (const uint32_t *)bins, (const affine_t *)k.table_w, k.wb,
-                     first ? 1 : 0, rep);
+                     first ? 1 : 0, rep, cap);
     SRS_HIP_CHECK(hipMemcpyAsync(k.h_ovf + (size_t)slot * BATCH_ARGS, rep, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     k.slot_mode[slot] = false;
     k.wcc_set[slot] = true;

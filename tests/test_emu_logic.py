@@ -530,7 +530,7 @@ def test_emu_slot_mode_commits():
 def test_emu_wide_chunked_commit():
     """msm.hip's opt-in wide chunked commit (SRS_MSM_WCC; profiles/r05_ab_wide_chunked.txt: measured, not adopted): the sets of a streamed commit
     on the 20-bit windows -- one thread per (segment, bucket) into persistent bucket sums, threads ordered by chain length; a bucket with more than
-    512 entries in one set makes the commit run again on the standard pipeline (redo) -- against the oracle, both curves."""
+    max(256, 4 x mean) entries in one set makes the commit run again on the standard pipeline (redo) -- against the oracle, both curves."""
     import sys
     code = (
         "import os, sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
