@@ -24,7 +24,8 @@ def main():
     back = int(([a for a in sys.argv[1:] if a.isdigit()] or ["2"])[0])
     ks = load(args[0], "Kernel_Name")
     cps = load(args[1], "Direction") if len(args) > 1 else []
-    starts = [i for i, k in enumerate(ks) if "k_pg_F_leaves" in k[2]]
+    # (a prove may launch k_pg_F_leaves more than once back to back: a step starts at the first of a run)
+    starts = [i for i, k in enumerate(ks) if "k_pg_F_leaves" in k[2] and (i == 0 or "k_pg_F_leaves" not in ks[i - 1][2])]
     a, b = starts[-back - 1], starts[-back]
     t0 = ks[a][0]
     t1 = ks[b][0]
