@@ -433,7 +433,11 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
     for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
         uint32_t kp = e / COLS, c = e % COLS;
         size_t oidx = (size_t)(k1_0 + c) + ((size_t)out_mid << r1) + ((size_t)kp << (pa.log_n - RBITS));
-        const uint32_t r3 = fin.on ? (uint32_t)(oidx % 3) : 0u;
+        if (!fin.on) {                 // r05: nothing to scale -- the lazy value is reduced directly (Fr29::reduce_lazy) instead of multiplied by the radix' one
+            dst[oidx] = Fr29::to_canonical_fe(Fr29::reduce_lazy(lazy::get(tile, e)));
+            continue;
+        }
+        const uint32_t r3 = fin.on == 1 ? (uint32_t)(oidx % 3) : 0u;          // (on == 2: SRS_NTT_CLOSE_MUL=1, the r04 closing product with one, for A/B)
         const f29_t m = r3 == 1 ? z1 : (r3 == 2 ? z2 : one);
         dst[oidx] = Fr29::to_canonical_fe(Fr29::mul(lazy::get(tile, e), m));
     }
@@ -614,6 +618,8 @@ static void launch_last(const fe_t *src, fe_t *dst, const PassArgs &pa, const Pl
             f29.z1 = Fr::mul(fin.z1, p.unit);
             f29.z2 = Fr::mul(fin.z2, p.unit);
         }
+        static const bool close_mul = [] { const char *e = std::getenv("SRS_NTT_CLOSE_MUL"); return e && e[0] == '1'; }();
+        if (!fin.on && close_mul) f29.on = 2;
         SRS_LAUNCH((k_ntt_last_lazy<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], f29, p.unit);
     } else {
         SRS_LAUNCH((k_ntt_last<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);

@@ -53,6 +53,7 @@ static void field_op(const std::string &op, std::istringstream &in) {
     else if (op == "norm") { f29_t a = rd9<P>(in); pr(G::normalize(a).v, 9); }
     else if (op == "add") { f29_t a = rd9<P>(in), b = rd9<P>(in); pr(G::add_lazy(a, b).v, 9); }
     else if (op == "canon") { f29_t a = rd9<P>(in); pr(G::to_canonical_fe(a).v, 8); }
+    else if (op == "redlazy") { f29_t a = rd9<P>(in); pr(G::reduce_lazy(a).v, 9); }
     else if (op == "unpack") { fe_t a = rd8(in); pr(G::unpack(a).v, 9); }
     else if (op == "pack") { f29_t a = rd9<P>(in); pr(G::pack(a).v, 8); }
     else if (op == "sub" || op == "neg") {

@@ -134,6 +134,14 @@ def test_lazy_sums_differences_and_reductions(calc, name, p):
     for v in [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p, 3 * p, 4 * p - 1] + [rnd.randrange(4 * p) for _ in range(100)]:
         r = calc(f"canon {name} {hx(limbs29(v))}")
         assert sum(w << (32 * i) for i, w in enumerate(r)) == v % p
+    # r05 reduce_lazy (the NTT's closing reduction): any normalised value below 2^263 -> the same residue below 2P, normalised
+    top = (1 << 263) - 1
+    for v in ([0, 1, p - 1, p, p + 1, 2 * p, 469 * p, 469 * p - 1, 470 * p + 5, 700 * p, top, top - p, (1 << 232) - 1, 1 << 232, (1 << 262) + 12345]
+              + [k * p + d for k in (1, 7, 29, 117, 235, 468, 600) for d in (-1, 0, 1)] + [rnd.randrange(top) for _ in range(300)]
+              + [rnd.randrange(1, 720) * p + rnd.choice([0, 1, p - 1, rnd.randrange(p)]) for _ in range(300)]):
+        v = min(v, top)
+        r = calc(f"redlazy {name} {hx(limbs29(v))}")
+        assert val(r) % p == v % p and val(r) < 2 * p and all(x < (1 << 29) for x in r[:8]), hex(v)
     for v in [0, 1, (1 << 256) - 1, p, rnd.randrange(1 << 256)]:
         l = calc(f"unpack {name} {hx(words(v, 8))}")
         assert val(l) == v and all(x < (1 << 29) for x in l[:8])
