@@ -41,7 +41,9 @@ assert pow(FR_ZETA, 3, FR) == 1 and FR_ZETA != 1
 
 
 def inv(a, p):
-    return pow(a, p - 2, p)
+    """Field inversion with ff's convention for zero (`invert()` of 0 is None; callers that unwrap_or(0) get 0): a^(p-2)."""
+    a %= p
+    return pow(a, -1, p) if a else 0
 
 
 def to_mont(a, p):

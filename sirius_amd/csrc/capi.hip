@@ -2462,6 +2462,10 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
         rowprog::PgSizes z;
         if (!rowprog::pg_sizes(s, n_instances - 1, z)) return fail(SRS_ERR_INVALID, "structure has no gates");
         if (n_betas < z.betas_count) return fail(SRS_ERR_INVALID, "srs_pg_prove: not enough betas");
+        // K's domain "log" (quirk Q2) above F::S: the reference gets as far as coset_ifft and panics there (src/fft.rs:13); refused here
+        // before anything is computed or written
+        if (z.log_domain_K > ntt::FR_S)
+            return fail(SRS_ERR_K_TOO_LARGE, "srs_pg_prove (compute_K_from_G): k=" + std::to_string(z.log_domain_K) + " should no larger than F::S=28");
         const size_t wlen = rowprog::num_witness_columns(s) * rowprog::rows(s);
         std::vector<const fe_t *> dW(n_instances), ch(n_instances);
         for (size_t j = 0; j < n_instances; ++j) {

@@ -35,6 +35,12 @@ class PolyContext:
         return 1 << self.fft_log_domain_size_K
 
 
+def _k_len(ctx):
+    """Coefficients of K.  A domain "log" above F::S = 28 (quirk Q2 with 32 points of G or >= 8 instances) is refused by the
+    library with rc 3 -- the reference's `assert!(k <= F::S)` (src/fft.rs:13) -- before anything is written: no buffer then."""
+    return 1 << ctx.fft_log_domain_size_K if ctx.fft_log_domain_size_K <= 28 else 0
+
+
 def _fe(a):
     return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
 
@@ -73,7 +79,7 @@ def compute_G(ctx, betas_stroke, Ws, challenges_list=None, reference_compat=True
 
 def compute_K_from_G(ctx, poly_G, poly_F_in_alpha):
     g, fa = _fe(poly_G), _fe(poly_F_in_alpha)
-    out = np.zeros((1 << ctx.fft_log_domain_size_K, 4), dtype=np.uint64)
+    out = np.zeros((_k_len(ctx), 4), dtype=np.uint64)
     L.check(L.lib().srs_pg_compute_K_from_G(g.ctypes.data, g.shape[0], fa.ctypes.data, ctx.instances_to_fold,
                                             ctx.fft_log_domain_size_K, _stream(), out.ctypes.data))
     return out
@@ -148,7 +154,7 @@ def prove(ctx, betas, delta, Ws, ro=None, alpha=None, gamma=None, challenges_lis
     ag = np.zeros((2, 4), dtype=np.uint64)
     if ro is None:
         ag[0], ag[1] = _fe(alpha).reshape(4), _fe(gamma).reshape(4)
-    out = dict(poly_F=np.zeros((ctx.fft_points_count_F, 4), np.uint64), poly_K=np.zeros((1 << ctx.fft_log_domain_size_K, 4), np.uint64),
+    out = dict(poly_F=np.zeros((ctx.fft_points_count_F, 4), np.uint64), poly_K=np.zeros((_k_len(ctx), 4), np.uint64),
                betas_stroke=np.zeros((ctx.betas_count, 4), np.uint64), e=np.zeros(4, np.uint64), lagrange=np.zeros((J, 4), np.uint64),
                W=_alloc_like(Ws[0], bufs[0][2]) if fold else None)
     d = _fe(delta)

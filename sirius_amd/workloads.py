@@ -82,6 +82,28 @@ def make_support_inputs(k, seed):
                 modulus=MODULUS[1])
 
 
+def high_degree_gate(T, d, num_selectors=0, fixed_offset=0, advice_offset=0, num_fixed_total=None):
+    """A "high-degree gate" for BASELINE configs[3]: MainGate<T>'s polynomial plus the monomial  q_1[0] * s[0]^ceil(d/2) * s[1]^floor(d/2)
+    of degree d (Expression::degree counts advice queries only, src/polynomial/expression.rs:431-447) over the SAME columns (T + 2 advice,
+    2T + 5 fixed).  ProtoGalaxy sizes that follow (src/nifs/protogalaxy/poly/mod.rs:535-545, :263-268): one incoming trace and
+    d = 8..15 -> 16 points of G and, by quirk Q2, a 2^16-point K domain; d >= 16 -> 32 points, whose K "log" exceeds F::S."""
+    nf = 2 * T + 5
+    if num_fixed_total is None:
+        num_fixed_total = nf
+    q = X.Polynomial(num_selectors + fixed_offset)
+    s0 = X.Polynomial(num_selectors + num_fixed_total + advice_offset)
+    s1 = X.Polynomial(num_selectors + num_fixed_total + advice_offset + 1)
+
+    def power(v, e):
+        out = v
+        for _ in range(e - 1):
+            out = X.Product(out, v)
+        return out
+    a, b = (d + 1) // 2, d // 2
+    mono = X.Product(q, X.Product(power(s0, a), power(s1, b)) if b else power(s0, a))
+    return X.Sum(X.main_gate(T, num_selectors, fixed_offset, advice_offset, num_fixed_total), mono)
+
+
 def gates_for(gate_T):
     nfix = sum(2 * T + 5 for T in gate_T)
     nadv = sum(T + 2 for T in gate_T)

@@ -4,7 +4,21 @@ import random
 import numpy as np
 
 
-def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
+def high_degree_gates(d, T=2):
+    """([gate], nfix, nadv) of `workloads.high_degree_gate`: MainGate<T> plus one monomial of degree d (d = 8..15 -> 16 points of G,
+    a 2^16-point K domain by quirk Q2; d >= 16 -> 32 points -> K's domain "log" 32 > F::S: the reference panics in fft.rs:13)."""
+    from workloads import high_degree_gate
+    return [high_degree_gate(T, d)], 2 * T + 5, T + 2
+
+
+def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4, gates=None, ro_check=None):
+    """Every ProtoGalaxy prover polynomial of one (structure, L) case, product vs the oracle's literal restatement -- F, beta',
+    G, F(alpha), K, calculate_e, evaluate_e, the Lagrange values, fold_witness, and `prove` as one call (given challenges, and
+    with alpha / gamma squeezed from a Poseidon transcript) -- whatever K's domain is: 2^8 points (L = 1, degree <= 7), 2^16 points
+    (L = 3 at degree 5 = the reference's own test shape, src/nifs/protogalaxy/tests.rs:187-309; L = 1 at degree 8..15), or a
+    "log" above F::S = 28 (L >= 7; degree >= 16), where the reference panics in fft.rs:13 and the product returns rc 3.
+    gates = (product gates, nfix, nadv) replaces the MainGate<T> list (the node tuples are the oracle's too).  ro_check: compare the
+    transcript variant of prove as well (default: whenever K has 256 coefficients; the python sponge over 2^16 takes ~10 s)."""
     from oracle import expr as OE
     from oracle import protogalaxy as OPG
     from oracle import pyref as P
@@ -12,11 +26,15 @@ def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
     from workloads import gates_for, rand_fe
     rnd = random.Random(seed)
     rows = 1 << k
-    gates, nfix, nadv = gates_for(gate_T)
-    og, fo, ao = [], 0, 0
-    for T in gate_T:
-        og.append(OE.main_gate_expression(T, 0, fo, ao, nfix)); fo += 2 * T + 5; ao += T + 2
-    rng = np.random.default_rng(k * 7 + len(gate_T) + seed)
+    if gates is None:
+        gates, nfix, nadv = gates_for(gate_T)
+        og, fo, ao = [], 0, 0
+        for T in gate_T:
+            og.append(OE.main_gate_expression(T, 0, fo, ao, nfix)); fo += 2 * T + 5; ao += T + 2
+    else:
+        gates, nfix, nadv = gates
+        og = list(gates)
+    rng = np.random.default_rng(k * 7 + len(gates) + seed)
     fixed = [rand_fe(rng, rows, 0.3) for _ in range(nfix)]
     Ws = [rand_fe(rng, nadv * rows) for _ in range(L_traces + 1)]
     St = S.PlonkStructure(0, k, [], fixed, nadv, gates)
@@ -28,6 +46,7 @@ def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
             ctx.fft_log_domain_size_K, ctx.lagrange_domain) == \
         (octx.count_with_padding, octx.betas_count(), octx.fft_points_count_F(), octx.fft_points_count_G,
          octx.fft_log_domain_size_K(), octx.lagrange_domain())
+    logK = octx.fft_log_domain_size_K()
     t = ctx.betas_count
     beta = rnd.randrange(P.FR)
     betas = OPG.new_accumulator_betas(beta, t)                 # Q3
@@ -43,26 +62,39 @@ def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
     assert O.mont_to_ints(O.FR, pG) == eG, "compute_G"
     Fa = OPG.poly_eval(eF, alpha)
     assert O.mont_to_ints(O.FR, PG.poly_eval(pF, m([alpha])[0])) == [Fa]
-    if octx.fft_log_domain_size_K() <= 8:
-        pK = PG.compute_K_from_G(ctx, pG, m([Fa])[0])
-        eK = OPG.compute_K_from_G(octx, eG, Fa)
-        assert O.mont_to_ints(O.FR, pK) == eK, "compute_K_from_G"
-        got = PG.calculate_e(pF, pK, m([gamma])[0], m([alpha])[0], ctx.lagrange_domain)
-        assert O.mont_to_ints(O.FR, got) == [OPG.calculate_e(eF, eK, gamma, alpha, octx.lagrange_domain())]
     pe = PG.evaluate_e_from_trace(ctx, m(betas), Ws[0], reference_compat=compat)
     assert O.mont_to_ints(O.FR, pe) == [OPG.evaluate_e_from_trace(oS, octx, betas, Ws[0], [], compat)], "evaluate_e"
     Lg = P.eval_lagrange_poly_for_cyclic_group(gamma, octx.lagrange_domain())
     assert O.mont_to_ints(O.FR, PG.eval_lagrange_poly_for_cyclic_group(m([gamma])[0], ctx.lagrange_domain)) == Lg
     assert np.array_equal(PG.fold_witness(0, Ws, m(Lg)), OPG.fold_witness(O, Ws, Lg)), "fold_witness"
+    import torch
+    dWs = [torch.from_numpy(w.view(np.int64)).cuda() for w in Ws] if torch.cuda.is_available() else Ws    # device-resident (emulator: host)
+    if logK > P.FR_S:
+        # the reference cannot get past K here: coset_ifft -> get_omega_or_inv asserts "k should no larger than F::S" (src/fft.rs:13).
+        # The product reports the same condition as rc 3 from K itself and from the one-call prove, outputs untouched.
+        for call in (lambda: PG.compute_K_from_G(ctx, pG, m([Fa])[0]),
+                     lambda: PG.prove(ctx, m(betas), m([delta])[0], dWs, alpha=m([alpha])[0], gamma=m([gamma])[0], reference_compat=compat)):
+            try:
+                call()
+            except S.SiriusAmdError as e:
+                assert e.rc == 3 and "should no larger than F::S" in str(e), e
+            else:
+                raise AssertionError("a K domain above F::S must be refused")
+        St.close()
+        return ctx
+    pK = PG.compute_K_from_G(ctx, pG, m([Fa])[0])
+    eK = OPG.compute_K_from_G(octx, eG, Fa)
+    assert pK.shape[0] == len(eK) == 1 << logK
+    assert O.mont_to_ints(O.FR, pK) == eK, "compute_K_from_G"
+    got = PG.calculate_e(pF, pK, m([gamma])[0], m([alpha])[0], ctx.lagrange_domain)
+    assert O.mont_to_ints(O.FR, got) == [OPG.calculate_e(eF, eK, gamma, alpha, octx.lagrange_domain())], "calculate_e"
     # ProtoGalaxy::prove as one call (srs_pg_prove) == the step-by-step results; with an oracle: alpha / gamma squeezed inside
-    if octx.fft_log_domain_size_K() <= 8:
-        import torch
-        dWs = [torch.from_numpy(w.view(np.int64)).cuda() for w in Ws] if torch.cuda.is_available() else Ws    # device-resident (emulator: host)
-        pr = PG.prove(ctx, m(betas), m([delta])[0], dWs, alpha=m([alpha])[0], gamma=m([gamma])[0], reference_compat=compat)
-        assert np.array_equal(pr["poly_F"], pF) and np.array_equal(pr["poly_K"], pK) and O.mont_to_ints(O.FR, pr["betas_stroke"]) == bs
-        assert np.array_equal(pr["e"], got) and np.array_equal(pr["lagrange"], m(Lg)[: len(Ws)])
-        Wf = pr["W"]
-        assert np.array_equal(Wf.cpu().numpy().view(np.uint64).reshape(-1, 4) if hasattr(Wf, "cpu") else Wf, OPG.fold_witness(O, Ws, Lg))
+    pr = PG.prove(ctx, m(betas), m([delta])[0], dWs, alpha=m([alpha])[0], gamma=m([gamma])[0], reference_compat=compat)
+    assert np.array_equal(pr["poly_F"], pF) and np.array_equal(pr["poly_K"], pK) and O.mont_to_ints(O.FR, pr["betas_stroke"]) == bs
+    assert np.array_equal(pr["e"], got) and np.array_equal(pr["lagrange"], m(Lg)[: len(Ws)])
+    Wf = pr["W"]
+    assert np.array_equal(Wf.cpu().numpy().view(np.uint64).reshape(-1, 4) if hasattr(Wf, "cpu") else Wf, OPG.fold_witness(O, Ws, Lg))
+    if ro_check if ro_check is not None else logK <= 8:
         from oracle import poseidon as OP
         ro, oro = S.PoseidonHash(0, 5, 4, 10, 10), OP.PoseidonHash(P.FR, 5, 4, 10, 10)
         ro.absorb_field(m([delta])); oro.absorb_field_iter([delta])
@@ -72,7 +104,9 @@ def run_pg_case(S, O, k, gate_T, L_traces, compat, seed=4):
         g2 = oro.absorb_field_iter(O.mont_to_ints(O.FR, pr2["poly_K"])).squeeze(255)
         assert O.mont_to_ints(O.FR, pr2["gamma"]) == [g2]
         eG2 = OPG.compute_G(oS, octx, OPG.beta_stroke(betas, a2, delta), Ws, [[] for _ in Ws], compat)
-        assert O.mont_to_ints(O.FR, pr2["poly_K"]) == OPG.compute_K_from_G(octx, eG2, OPG.poly_eval(eF, a2))
+        eK2 = OPG.compute_K_from_G(octx, eG2, OPG.poly_eval(eF, a2))
+        assert O.mont_to_ints(O.FR, pr2["poly_K"]) == eK2
+        assert O.mont_to_ints(O.FR, pr2["e"]) == [OPG.calculate_e(eF, eK2, g2, a2, octx.lagrange_domain())]
     St.close()
     return ctx
 

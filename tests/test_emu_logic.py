@@ -118,6 +118,20 @@ def test_emu_protogalaxy(emu, oracle):
         run_pg_case(emu, oracle, 4, [2], 31, False)
 
 
+def test_emu_protogalaxy_K_domain_2p16_and_high_degree(emu, oracle):
+    """r06: K domains above 256 points (k_pg_K_points + the 2^16-point coset_ifft: three incoming traces = the reference's own test
+    shape, src/nifs/protogalaxy/tests.rs:187-309; a gate of degree 9 / 15 with one incoming trace), the transcript variant of the
+    one-call prove over K's 65536 coefficients, and the refusal of a K "log" above F::S (degree 16: 32 points of G)."""
+    from pg_cases import high_degree_gates, run_pg_case
+    ctx = run_pg_case(emu, oracle, 4, [2], 3, False, ro_check=True)
+    assert (ctx.fft_points_count_G, ctx.fft_log_domain_size_K) == (16, 16)
+    ctx = run_pg_case(emu, oracle, 4, None, 1, True, gates=high_degree_gates(9))
+    assert (ctx.fft_points_count_G, ctx.fft_log_domain_size_K) == (16, 16)
+    run_pg_case(emu, oracle, 3, None, 1, False, gates=high_degree_gates(15))
+    ctx = run_pg_case(emu, oracle, 3, None, 1, False, gates=high_degree_gates(16))
+    assert ctx.fft_log_domain_size_K == 32
+
+
 def test_emu_protogalaxy_polynomial_tree_F(emu, oracle):
     """k >= 10: compute_F runs the polynomial tree (k_pg_F_leaves / k_pg_F_level), interpreter and specialised leaves."""
     from pg_cases import run_pg_case

@@ -4,7 +4,7 @@ quirks Q1 (row index), Q2 (K domain) and Q3 (betas) reproduced."""
 import numpy as np
 import pytest
 
-from pg_cases import direct_eval_case, run_pg_case
+from pg_cases import direct_eval_case, high_degree_gates, run_pg_case
 
 pytestmark = pytest.mark.gpu
 
@@ -14,8 +14,37 @@ pytestmark = pytest.mark.gpu
                                               (4, [2], 3, False), (7, [5], 3, True), (4, [2], 7, True), (10, [5, 3], 7, False), (5, [3, 2], 15, True),   # L up to 15 (r05)
                                               (10, [5, 3], 1, True), (11, [5, 3], 3, False)])   # k >= 10 with [5, 3]: specialised leaf kernel
 def test_protogalaxy_vs_oracle(srs, oracle, k, gate_T, L, compat):
-    # the reference's own protogalaxy tests fold L = 3 traces at k = 10 (src/nifs/protogalaxy/tests.rs:187-309)
+    # every case compares F, G, K, e, the Lagrange values, fold_witness and the one-call prove; L = 3 cases have a 2^16-point K domain
+    # (k_pg_K_points + a device coset_ifft), L >= 7 cases a K "log" above F::S: refused with rc 3 where the reference panics
     run_pg_case(srs, oracle, k, gate_T, L, compat)
+
+
+def test_protogalaxy_reference_test_shape(srs, oracle):
+    """The shape the reference's own ProtoGalaxy tests fold (src/nifs/protogalaxy/tests.rs:187-309: three incoming traces at k = 10;
+    with a degree-5 gate: 16 points of G and, by quirk Q2, a 2^16-point K domain), end to end: prove -> K -> gamma -> calculate_e with
+    alpha and gamma squeezed from the Poseidon transcript over F's 16 and K's 65536 coefficients."""
+    ctx = run_pg_case(srs, oracle, 10, [5], 3, True, ro_check=True)
+    assert (ctx.fft_points_count_G, ctx.fft_log_domain_size_K, ctx.instances_to_fold) == (16, 16, 4)
+
+
+@pytest.mark.parametrize("k,d,L,compat,ro", [(5, 9, 1, True, True), (10, 15, 1, False, False), (10, 9, 1, True, False), (4, 8, 1, False, False),
+                                            (6, 6, 1, True, None), (4, 7, 3, False, False)])
+def test_protogalaxy_high_degree_gate_vs_oracle(srs, oracle, k, d, L, compat, ro):
+    """BASELINE configs[3] names a "high-degree gate": one incoming trace and a gate of degree 8..15 give 16 points of G
+    (src/nifs/protogalaxy/poly/mod.rs:535-545) -- the non-8-point instantiation of the leaf kernels -- and a 2^16-point K domain
+    (:263-268).  Degree 6 / 7 stay at 8 points; L = 3 at degree 7 reaches 32 points and a refused K."""
+    ctx = run_pg_case(srs, oracle, k, None, L, compat, gates=high_degree_gates(d), ro_check=ro)
+    want_G = 1 << (L * d).bit_length()
+    assert ctx.fft_points_count_G == want_G
+
+
+def test_protogalaxy_K_domain_above_S_is_refused(srs, oracle):
+    """points_G >= 32 -> fft_log_domain_size_K = 32 > F::S = 28: `get_omega_or_inv` panics "k should no larger than F::S" in the
+    reference (src/fft.rs:13); rc 3 here from compute_K_from_G and from prove (F, G, e and the fold still compare with the oracle)."""
+    ctx = run_pg_case(srs, oracle, 3, None, 1, False, gates=high_degree_gates(16))
+    assert (ctx.fft_points_count_G, ctx.fft_log_domain_size_K) == (32, 32)
+    ctx = run_pg_case(srs, oracle, 4, [2], 7, True)            # 8 instances at degree 5: 64 points, "log" 64
+    assert ctx.fft_log_domain_size_K == 64
 
 
 def test_lagrange_kats(srs, oracle):
@@ -161,13 +190,14 @@ def test_fast_paths_equal_general_paths(srs, oracle):
     St.close()
 
 
-def _config_size_case(srs, oracle, k, compare_oracle):
+def _config_size_case(srs, oracle, k, compare_oracle, high_degree=None, modes=(True, False)):
     """BASELINE configs[2] / [3] shapes: the primary CycleFold structure (MainGate<5> + MainGate<3>, 12 advice / 26 fixed,
     2 gates -> n = 2^(k+1) leaves).  Size-independent identities in both leaf modes:
       F(0) = evaluate_e(betas);  G(1) = evaluate_e(betas');  deg F <= t;  K and e against the oracle's (cheap) restatement;
       fold_witness is linear: fold(acc, in; L) - L0 acc - L1 in = 0 on a sample of rows.
     With compare_oracle the coefficient vectors of F and G and the value e are compared with the CPU oracle (oracle/
-    protogalaxy.py *_fast: the reference's leaf function, folded witnesses and reduction trees, in C) at FULL size."""
+    protogalaxy.py *_fast: the reference's leaf function, folded witnesses and reduction trees, in C) at FULL size.
+    high_degree = d: the first gate is `workloads.high_degree_gate(5, d)` (same columns): 16 points of G, K on 2^16 points."""
     import random
     import torch
     from oracle import expr as OE
@@ -177,11 +207,14 @@ def _config_size_case(srs, oracle, k, compare_oracle):
     from workloads import make_structure_inputs
     O = oracle
     w = make_structure_inputs("primary", k, seed=1000 + k)
+    if high_degree:      # configs[3]'s "high-degree gate": MainGate<5> + a monomial of degree d over the same 12 advice / 26 fixed columns
+        from workloads import high_degree_gate
+        w["gates"] = [high_degree_gate(5, high_degree, 0, 0, 0, w["num_fixed"]), w["gates"][1]]
     S = srs.PlonkStructure(0, k, [], w["fixed"], w["num_advice"], w["gates"])
     ctx = PG.PolyContext(S, 1)
     t = k + 1
     assert (ctx.count_of_evaluation_with_padding, ctx.betas_count, ctx.fft_points_count_F, ctx.fft_points_count_G,
-            ctx.fft_log_domain_size_K) == (1 << t, t, 32, 8, 8)
+            ctx.fft_log_domain_size_K) == ((1 << t, t, 32, 16, 16) if high_degree else (1 << t, t, 32, 8, 8))
     dev = lambda a: torch.from_numpy(a.view(np.int64)).cuda()
     W0, W1 = dev(w["W1"]), dev(w["W2"])
     rnd = random.Random(k)
@@ -194,10 +227,12 @@ def _config_size_case(srs, oracle, k, compare_oracle):
         og, fo, ao = [], 0, 0
         for T in gate_T:
             og.append(OE.main_gate_expression(T, 0, fo, ao, w["num_fixed"])); fo += 2 * T + 5; ao += T + 2
+        if high_degree:
+            og[0] = w["gates"][0]                                  # the node tuples are the oracle's too
         oS = OPG.Structure(O, og, k, [], w["fixed"], w["num_advice"], 0)
         octx = oS.context(1)
     seen = {}
-    for compat in (True, False):
+    for compat in modes:
         pF = PG.compute_F(ctx, m(betas), m([delta])[0], W0, reference_compat=compat)
         pG = PG.compute_G(ctx, m(bs), [W0, W1], reference_compat=compat)
         iF, iG = O.mont_to_ints(O.FR, pF), O.mont_to_ints(O.FR, pG)
@@ -208,7 +243,7 @@ def _config_size_case(srs, oracle, k, compare_oracle):
         assert all(c == 0 for c in iF[t + 1:]), "deg F <= t"
         Fa = PG.poly_eval(pF, m([alpha])[0])
         pK = PG.compute_K_from_G(ctx, pG, Fa)
-        # K (256 coefficients, quirk Q2) and e against the oracle's literal compute_K_from_G / calculate_e on the product's F, G:
+        # K (256 coefficients, quirk Q2; 2^16 with a high-degree gate) and e against the oracle's literal compute_K_from_G / calculate_e on the product's F, G:
         # cheap at any k (the incoming witness is random, not satisfying, so K is an interpolant, not an exact quotient)
         Fa_i = OPG.poly_eval(iF, alpha)
         assert O.mont_to_ints(O.FR, Fa) == [Fa_i]
@@ -226,7 +261,7 @@ def _config_size_case(srs, oracle, k, compare_oracle):
             assert iF == OPG.compute_F_fast(oS, octx, betas, delta, w["W1"], [], compat), f"compute_F vs oracle (compat={compat})"
             assert iG == OPG.compute_G_fast(oS, octx, bs, [w["W1"], w["W2"]], [[], []], compat), f"compute_G vs oracle (compat={compat})"
             assert e_b == OPG.evaluate_e_fast(oS, octx, betas, w["W1"], [], compat), "evaluate_e vs oracle"
-    assert seen[True] != seen[False]
+    assert len(modes) < 2 or seen[True] != seen[False]
     Lg = PG.eval_lagrange_poly_for_cyclic_group(m([gamma])[0], ctx.lagrange_domain)
     Wf = PG.fold_witness(0, [W0, W1], Lg)
     idx = torch.from_numpy(np.random.default_rng(k).integers(0, w["W1"].shape[0], size=4096)).cuda()
@@ -246,3 +281,16 @@ def test_protogalaxy_config_k22_vs_oracle(srs, oracle):
     """BASELINE configs[3] (ProtoGalaxy at k = 22, n = 2^23 leaves) on one GPU: F / G / e at full size against the CPU oracle
     (both leaf modes) and the size-independent identities."""
     _config_size_case(srs, oracle, 22, compare_oracle=True)
+
+
+def test_protogalaxy_high_degree_config_k20_vs_oracle(srs, oracle):
+    """configs[3]'s "high-degree gate" at a bench size: a degree-9 gate -> 16 points of G (the leaf kernels' 16-point
+    instantiation), K on 2^16 points; F / G / e at full size against the CPU oracle, K and calculate_e against the literal restatement.
+    Intended leaf rows here; the k = 22 case below runs the reference's rows."""
+    _config_size_case(srs, oracle, 20, compare_oracle=True, high_degree=9, modes=(False,))
+
+
+def test_protogalaxy_high_degree_config_k22_vs_oracle(srs, oracle):
+    """BASELINE configs[3] as named: ProtoGalaxy high-degree-gate fold at k = 22 (n = 2^23 leaves, degree 15) on one GPU, the
+    reference's leaf rows, full size against the CPU oracle."""
+    _config_size_case(srs, oracle, 22, compare_oracle=True, high_degree=15, modes=(True,))
