@@ -385,6 +385,11 @@ class PgPrimary:
         self.ro = S.PoseidonHash(0, 5, 4, 10, 10)
         self.step_no = 0
         self.dev_W, self.seen_C = None, {}
+        self.page_W = None            # secondary.pageable_witness: plain (pageable) copies of the two host witnesses
+
+    def set_pageable(self, on):
+        """secondary.pageable_witness: the step's new witness comes from ordinary pageable host memory (a Rust Vec<F>), not from a page-locked buffer"""
+        self.page_W = [np.array(hb.array, copy=True) for hb in self.host_W] if on else None
 
     def set_resident(self, D, on):
         """secondary.device_resident: the two witnesses the steps alternate between are ALREADY in HBM when a step starts (the contract's
@@ -486,6 +491,8 @@ class PgPrimary:
     def witness_commit(self, S, D):
         """generate_plonk_trace -> run_sps_protocol_1: ck.commit(W1) of the NEW witness, host -> HBM inside the call."""
         hb = self.host_W[self.step_no & 1]
+        if self.page_W is not None:
+            hb = _Plain(self.page_W[self.step_no & 1])
         if self.dev_W is not None:                    # resident form: nothing crosses PCIe; the deferred fold of the previous incoming trace
             w = self.dev_W[self.step_no & 1]          # (another buffer) runs on the side stream under this MSM
             self.fold_start()
@@ -511,6 +518,12 @@ class PgPrimary:
         self.inC = D.combine(S.CURVE_BN256, self.ck.commit_upload(hb.array, dev_copy=self.inW))
         if self.sharded:                              # rows the rank's leaf tiles read beyond its stripes (row 0 under reference_compat)
             self.S.upload_shard_halo(hb.array, self.inW, self.compat)
+
+
+class _Plain:
+    """a pageable numpy array behind the `.array` attribute the witness code reads"""
+    def __init__(self, a):
+        self.array = a
 
 
 def PGint(fe):
@@ -796,6 +809,74 @@ def extras_microbench(S, D, ck24, log_n=24, reps=3):
     return out
 
 
+def extras_high_degree(S, D, args, k=22, degree=15, reps=5):
+    """BASELINE configs[3] as named -- "ProtoGalaxy NIFS high-degree-gate fold, k=22": ProtoGalaxy::prove (one incoming trace) on the CycleFold
+    primary shape with its first gate raised to `degree` (workloads.high_degree_gate: same 12 advice / 26 fixed columns).  16 evaluation
+    points of G instead of 8, K on 2^16 points (quirk Q2), its 65536 coefficients absorbed by the transcript.  The prove only: the k = 22
+    witness commit needs a 2^26 key and is timed by `bench.py --k 22 --log-key 26` (profiles/*_bench_cyclefold_k22_key26_*.json)."""
+    import random
+    from sirius_amd import _lib as _L
+    from sirius_amd import protogalaxy as PG
+    from sirius_amd.field import FR, ints_to_mont
+    from sirius_amd.workloads import high_degree_gate, make_structure_inputs
+    w = make_structure_inputs("primary", k, seed=0x5349524955530000 + 5)
+    gates = [high_degree_gate(5, degree, 0, 0, 0, w["num_fixed"]), w["gates"][1]]
+    t0 = time.perf_counter()
+    St = S.PlonkStructure(0, k, [], w["fixed"], w["num_advice"], gates)
+    t_create = time.perf_counter() - t0
+    ctx = PG.PolyContext(St, 1)
+    accW, inW = up(D, w["W1"]), up(D, w["W2"])
+    rnd = random.Random(4)
+    m = lambda v: ints_to_mont(0, list(v))
+    betas, delta = m([rnd.randrange(FR) for _ in range(ctx.betas_count)]), m([rnd.randrange(FR)])[0]
+    ro = S.PoseidonHash(0, 5, 4, 10, 10)
+    compat = args.leaf_rows == "compat"
+
+    def prove():
+        ro.reset().absorb_field(delta.reshape(1, 4))
+        return PG.prove(ctx, betas, delta, [accW, inW], ro=ro, reference_compat=compat, fold=True)
+    prove()
+    S.profile_reset()
+    dt = timed(D, prove, reps)
+    prof = {}
+    for name in ("pg_F_leaves", "pg_G_leaves"):
+        st = S.profile_get(name)
+        if st and st["launches"]:
+            prof[name + "_ms"] = round(st["total_ms"] / st["launches"], 4)
+    out = {"workload": f"ProtoGalaxy::prove, k={k}, 2 gates (degree {degree} + MainGate<3>), n = 2^{k + 1} leaves, F {ctx.fft_points_count_F} / G "
+                       f"{ctx.fft_points_count_G} points, K 2^{ctx.fft_log_domain_size_K} points (BASELINE configs[3]: high-degree gate)",
+           "prove_ms": round(dt / reps * 1e3, 3), "kernel_ms": prof, "structure_create_s": round(t_create, 3), "leaf_rows": args.leaf_rows,
+           "leaf_kernels": "ahead-of-time sweep kernels" if _L.lib().srs_structure_kernel_kind(St._h, 2) == 1 else "interpreter (k_pg_leaves: no ahead-of-time kernel for this gate set)",
+           "note": "prove = F, alpha, G, K, gamma, e, fold_witness in one call (srs_pg_prove); of it ~16 k Poseidon permutations on the host absorb "
+                   "K's 2^16 coefficients (the reference's quirk Q2 sizes K's domain 2^16 for 16 points of G)"}
+    St.close()
+    del accW, inW
+    return out
+
+
+def extras_key_setup(S, D, ck24):
+    """What a drop-in's `IVC::new` pays once: srs_ck_create of a 2^24-base key from host memory (upload + window expansion, with and without
+    the second, 20-bit-window table) and the HBM it holds."""
+    import torch
+    bases = ck24.bases()
+    n = bases.shape[0]
+    out = {"bases": n, "host_bytes": int(bases.nbytes)}
+    for name, wide in (("with_wide_table", 1), ("narrow_only", 0)):
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        with S.tuning(msm_wide=wide):
+            t0 = time.perf_counter()
+            ck = S.CommitmentKey(S.CURVE_BN256, bases)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        held = free0 - torch.cuda.mem_get_info()[0]
+        out[name] = {"create_s": round(dt, 3), "hbm_bytes": int(held), "has_wide_table": bool(ck.has_wide_table)}
+        ck.close()
+    out["note"] = ("srs_ck_create(2^24 bn256 bases from pageable host memory): 1 GiB upload + 15 (+ 13) windows of doublings and batched normalisations; "
+                   "`narrow_only` = tuning msm_wide = 0 / environment SRS_MSM_WIDE=0 (whole MSMs of >= 2^23 scalars then stay on the 16-bit windows)")
+    return out
+
+
 def extras_msm_sharded(S, D, ck, log_n, reps=3):
     """BASELINE configs[4] on N ranks: the 2^log_n-point MSM over the SHARDED key -- every rank adds up its block-cyclic stripes of the
     same device-resident vector, the 64-byte partials are all-gathered and summed (inside the timed call).  scalars_per_s at
@@ -971,6 +1052,18 @@ def main():
                             "region); `value` above is the PCIe-inclusive step -- the reference's witness is synthesised on the host every step "
                             "(403 MB = 7.3 ms of upload at 56 GB/s, overlapped with the streamed commit)"}
                 pri.set_resident(D, False)
+            if D.world == 1 and not D.multi and not args.no_extras and args.witness == "bench" and not resident:
+                # beside the headline: the same step fed from PAGEABLE host memory (a Rust Vec<F>; the headline alternates between two page-locked
+                # buffers): the runtime stages pageable sources through its own pinned buffers
+                pri.set_pageable(True)
+                for _ in range(2):
+                    cyclefold_step(S, D, pri, sup, args.ro_challenge)
+                n_pg = max(1, min(args.steps, 10))
+                dt_pg = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), n_pg, after=lambda: (pri.settle(), sup.settle()))
+                pri.set_pageable(False)
+                out["pageable_witness"] = {"fold_steps_per_s": round(n_pg / dt_pg, 4), "ms_per_step": round(dt_pg / n_pg * 1e3, 4), "steps": n_pg,
+                                           "note": "the new 12 * 2^k witness comes from plain pageable numpy memory (what a Rust Vec<F> is) instead of the "
+                                                   "page-locked buffers of the headline; same chunked upload inside the step"}
             if D.world == 1 and not args.no_cpu_baseline:
                 try:
                     out["cpu_baseline"] = cpu_baseline_cyclefold(args, pri, sup, compat)
@@ -991,11 +1084,28 @@ def main():
             micro = extras_microbench(S, D, ck24) if ck24 is not None else (extras_microbench(S, D, pri.ck, log_key, 1) if D.emu else None)
             S.profile_enable(False)
             if D.rank == 0:
+                hd = extras_high_degree(S, D, args) if not D.emu else extras_high_degree(S, D, args, 4, 9, 1)
+                setup = extras_key_setup(S, D, ck24) if ck24 is not None else None
                 out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "survey_mixture": out.pop("survey_mixture", None),
-                                    "device_resident": out.pop("device_resident", None),
-                                    "sangria_k17": sec_obj, "microbench_2p24": micro,
+                                    "device_resident": out.pop("device_resident", None), "pageable_witness": out.pop("pageable_witness", None),
+                                    "sangria_k17": sec_obj, "microbench_2p24": micro, "high_degree_k22": hd, "key_setup": setup,
                                     "predicted_scaling": PREDICTED_SCALING}
                 out["host_path_ms_per_step"] = sec_obj["host_path_ms_per_step"]
+                # LAST in the line (a reader that keeps only the tail of a long line still gets the figures of every configuration)
+                mb = micro or {}
+                out["summary"] = {
+                    "cyclefold_k20_ms_per_step": out["ms_per_step"], "fold_steps_per_s": out["value"],
+                    "resident_ms": (out["secondary"]["device_resident"] or {}).get("ms_per_step"),
+                    "pageable_ms": (out["secondary"]["pageable_witness"] or {}).get("ms_per_step"),
+                    "survey_mixture_ms": (out["secondary"]["survey_mixture"] or {}).get("ms_per_step"),
+                    "true_rows_ms": (out["secondary"]["true_leaf_rows"] or {}).get("ms_per_step"),
+                    "sangria_k17_ms": [sec_obj["device_resident"]["ms_per_step"], sec_obj["host_witness"]["ms_per_step"]],
+                    "msm_2p24_ms": [mb.get("msm_uniform", {}).get("ms"), mb.get("msm_trace", {}).get("ms")],
+                    "ntt_2p24_ms": [mb.get("ntt_fft", {}).get("ms"), mb.get("ntt_ifft", {}).get("ms")],
+                    "ntt_2p24_hbm_frac": [mb.get("ntt_fft", {}).get("roofline", {}).get("frac"), mb.get("ntt_ifft", {}).get("roofline", {}).get("frac")],
+                    "high_degree_k22_prove_ms": (hd or {}).get("prove_ms"),
+                    "accum_hbm_frac": (out["roofline"] or {}).get("frac"), "accum_alu_frac": ((out["roofline"] or {}).get("alu") or {}).get("frac"),
+                    "cpu_fold_steps_per_s": (out.get("cpu_baseline") or {}).get("value")}
         if not args.no_extras and D.world > 1 and (log_key == 24 or D.emu):
             del pri.accW, pri.inW
             for hb in pri.host_W:

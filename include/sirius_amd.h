@@ -62,6 +62,16 @@ enum { SRS_REPR_MONT = 0, SRS_REPR_CANON = 1 };
 int srs_init(int device_ordinal);            /* binds the calling thread's HIP device; checks gfx950 */
 const char *srs_last_error(void);
 const char *srs_version(void);
+/* Run-time tunables (csrc/tuning.h holds the table): each selects among code paths the library takes by default for SOME input size
+ * (or moves the size threshold between them); none changes a result.  Tests use them to run a large-input path on an input the CPU
+ * oracle can check; a deployer may set "msm_wide" = 0 to save 13/16 of a large key's HBM (also: environment SRS_MSM_WIDE=0).
+ * Names (srs_tuning_name(i), i = 0, 1, ... until NULL): msm_sort, msm_l0, msm_wide, msm_wide_min, msm_slots, msm_slot_log,
+ * msm_expect_ovf, msm_quad_max, commit_chunks, pg_f_eval, pg_g_fft, jit_always, no_jit.  Process-wide; set before the calls they
+ * affect (a value is read when a call starts).  rc SRS_ERR_INVALID for an unknown name.  No reference counterpart. */
+int srs_tuning_set(const char *name, int64_t value);
+int srs_tuning_get(const char *name, int64_t *value);        /* *value = INT64_MIN while unset */
+void srs_tuning_reset(void);
+const char *srs_tuning_name(int index);
 /* Scalar field of a curve (bn256 -> Fr, grumpkin -> Fq). */
 int srs_scalar_field_of(int curve);
 /* Layout self-test: the shim passes the raw bytes of F::ONE and F::from(2); rc SRS_ERR_LAYOUT if they

@@ -37,3 +37,45 @@ def profile_get(name):
     if _lib.lib().srs_profile_get(name.encode(), _C.byref(ms), _C.byref(n), _C.byref(u)) != 0:
         return None
     return dict(total_ms=ms.value, launches=n.value, units=u.value)
+
+
+class tuning:
+    """`with sirius_amd.tuning(msm_sort=2, commit_chunks=3): ...` -- run-time tunables of the library (srs_tuning_set, csrc/tuning.h):
+    each selects among code paths that are the default for SOME input size; none changes a result.  Restored on exit."""
+    UNSET = -(1 << 63)
+
+    def __init__(self, **kv):
+        self.kv = kv
+        self.old = {}
+
+    @staticmethod
+    def names():
+        out, i = [], 0
+        while True:
+            n = _lib.lib().srs_tuning_name(i)
+            if n is None:
+                return out
+            out.append(n.decode())
+            i += 1
+
+    @staticmethod
+    def get(name):
+        import ctypes as _C
+        v = _C.c_int64()
+        _lib.check(_lib.lib().srs_tuning_get(name.encode(), _C.byref(v)))
+        return None if v.value == tuning.UNSET else v.value
+
+    @staticmethod
+    def set(name, value):
+        _lib.check(_lib.lib().srs_tuning_set(name.encode(), tuning.UNSET if value is None else int(value)))
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = tuning.get(k)
+            tuning.set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning.set(k, v)
+        return False

@@ -30,6 +30,10 @@ def _prototypes():
         "srs_init": (i32, [i32]),
         "srs_last_error": (C.c_char_p, []),
         "srs_version": (C.c_char_p, []),
+        "srs_tuning_set": (i32, [C.c_char_p, C.c_int64]),
+        "srs_tuning_get": (i32, [C.c_char_p, C.POINTER(C.c_int64)]),
+        "srs_tuning_reset": (None, []),
+        "srs_tuning_name": (C.c_char_p, [i32]),
         "srs_scalar_field_of": (i32, [i32]),
         "srs_layout_selftest": (i32, [i32, vp, vp]),
         "srs_layout_selftest_point": (i32, [i32, vp]),
@@ -150,6 +154,12 @@ def load(path=None):
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # test hook: SRS_TEST_TUNING="msm_sort=2,commit_chunks=3" applies srs_tuning_set after loading (the tests' subprocesses; the library
+    # itself reads no tunable from the environment)
+    for item in filter(None, os.environ.get("SRS_TEST_TUNING", "").split(",")):
+        name, _, value = item.partition("=")
+        if lib.srs_tuning_set(name.strip().encode(), int(value)) != 0:
+            raise ValueError(f"SRS_TEST_TUNING: unknown tunable {name!r}")
     return lib
 
 

@@ -24,6 +24,7 @@
 #include "poseidon.h"
 #include "prof.h"
 #include "rowprog.h"
+#include "tuning.h"
 
 namespace srs {
 static thread_local std::string g_err;
@@ -68,9 +69,10 @@ struct CkShard {
     hipStream_t stream = nullptr;
     // streamed commits on a multi-device key (r05, multi_commit_streamed): the shard's stripes come up over ITS link in chunks that overlap ITS
     // MSM; `full` = a vector-sized landing buffer on the shard's device in which only the shard's stripes are ever filled
-    hipStream_t copy_stream = nullptr, sort_stream = nullptr, peer_stream = nullptr;
+    hipStream_t copy_stream = nullptr, peer_stream = nullptr;
     std::vector<hipEvent_t> events;
     hipEvent_t peer_done = nullptr;
+    bool peer_pending = false;      // peer_done has been recorded: the forwarded stripes of the previous commit may still be read from `full`
     fe_t *full = nullptr;
     size_t full_cap = 0;
     uint64_t stat_h2d_bytes = 0, stat_peer_bytes = 0, stat_streamed = 0;
@@ -146,7 +148,6 @@ struct srs_ck {
     msm::Key key;       // the key of a single-device handle; for a multi-device handle only curve / global_len are meaningful
     Arena staging;      // H2D staging of host scalars
     hipStream_t copy_stream = nullptr;       // srs_commit_upload: uploads run here, the MSMs on the caller's stream
-    hipStream_t sort_stream = nullptr;       // chunked commits: the sort kernels of chunk j + 1 slip into the drain of k_accum0 of chunk j
     std::vector<hipEvent_t> events;
     std::vector<std::unique_ptr<CkShard>> shards;      // non-empty: multi-device key
 };
@@ -410,7 +411,6 @@ void free_shards(srs_ck *ck) {
         for (hipEvent_t e : sh->events) (void)hipEventDestroy(e);
         if (sh->peer_done) (void)hipEventDestroy(sh->peer_done);
         if (sh->copy_stream) (void)hipStreamDestroy(sh->copy_stream);
-        if (sh->sort_stream) (void)hipStreamDestroy(sh->sort_stream);
         if (sh->peer_stream) (void)hipStreamDestroy(sh->peer_stream);
         if (sh->stream) (void)hipStreamDestroy(sh->stream);
     }
@@ -443,7 +443,18 @@ int create_multi(int curve, size_t len, int n_devices, Fill fill, srs_ck **out) 
             sh->key.len = shard_count(len, d, world);
             sh->key.compact_scalars = true;                    // the shard is handed ITS scalars, already gathered
             SRS_HIP_CHECK(hipSetDevice(sh->device));
-            if (sh->device != home) (void)hipDeviceEnablePeerAccess(home, 0);      // stripes of device-resident scalars come by peer copy
+            if (sh->device != home) {        // stripes of device-resident scalars come, and streamed stripes leave, by peer copies: they need the access
+                int can = 0;
+                SRS_HIP_CHECK(hipDeviceCanAccessPeer(&can, sh->device, home));
+                hipError_t pe = can ? hipDeviceEnablePeerAccess(home, 0) : hipErrorInvalidDevice;
+                if (pe == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); pe = hipSuccess; }
+                if (pe != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("srs_ck_create_multi: device " + std::to_string(sh->device) + " has no peer access to device " + std::to_string(home) +
+                              " (multi-device keys copy stripes between their devices: xGMI or PCIe P2P is required)");
+                    throw DeviceError{SRS_ERR_DEVICE};
+                }
+            }
             SRS_HIP_CHECK(hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking));
             if (sh->key.len) {
                 SRS_HIP_CHECK(hipMalloc((void **)&sh->key.table, sh->key.len * msm::NWIN * sizeof(affine_t)));
@@ -473,6 +484,20 @@ extern "C" {
 
 const char *srs_last_error(void) { return get_error(); }
 const char *srs_version(void) { return "sirius_amd 0.1.0 (gfx950)"; }
+
+int srs_tuning_set(const char *name, int64_t value) {
+    if (tuning::set(name, value) != 0) return fail(SRS_ERR_INVALID, std::string("srs_tuning_set: unknown tunable '") + (name ? name : "(null)") + "'");
+    return SRS_OK;
+}
+int srs_tuning_get(const char *name, int64_t *value) {
+    int found = 0;
+    const int64_t v = tuning::get_by_name(name, &found);
+    if (!found || !value) return fail(SRS_ERR_INVALID, "srs_tuning_get: unknown tunable or null output");
+    *value = v;
+    return SRS_OK;
+}
+void srs_tuning_reset(void) { tuning::reset(); }
+const char *srs_tuning_name(int index) { return tuning::name_of(index); }
 
 int srs_init(int device_ordinal) {
     return guarded([&]() -> int {
@@ -840,7 +865,6 @@ void srs_ck_free(srs_ck *ck) {
     }
     for (hipEvent_t e : ck->events) (void)hipEventDestroy(e);
     if (ck->copy_stream) (void)hipStreamDestroy(ck->copy_stream);
-    if (ck->sort_stream) (void)hipStreamDestroy(ck->sort_stream);
     if (ck->key.table) (void)hipFree(ck->key.table);
     msm::release(ck->key);
     ck->staging.release();
@@ -999,7 +1023,7 @@ size_t upload_stripes(fe_t *dst, const std::vector<Seg> &segs, size_t n, size_t 
 // shard, where its stripes are forwarded once they are in its HBM (the device copy the caller asked for lives on the process's device).
 struct StreamRes {
     msm::Key &key;
-    hipStream_t &copy_stream, &sort_stream;
+    hipStream_t &copy_stream;
     std::vector<hipEvent_t> &events;
     uint64_t *h2d_bytes = nullptr;        // statistics: bytes this commit brought up from host memory
     // peer forwarding (multi-device keys): every uploaded chunk's stripes are copied from `dst` (this device) to the same positions of
@@ -1021,7 +1045,7 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
     size_t per = 0;
     for (size_t j = 0; j < chunks; ++j) per = std::max(per, local(cut[j], cut[j + 1]));
     if (!ck->copy_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->copy_stream, hipStreamNonBlocking));
-    while (ck->events.size() < 2 * chunks + 2) {
+    while (ck->events.size() < chunks + 1) {
         hipEvent_t e;
         SRS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ck->events.push_back(e);
@@ -1031,24 +1055,9 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
     SRS_HIP_CHECK(hipStreamWaitEvent(ck->copy_stream, ck->events[chunks], 0));
     std::vector<bool> launched(chunks, false);
     // every chunk on the 16-bit windows: the chunks fold their buckets into one running set and only the last one is reduced
-    bool fold = chunks > 1 && !std::getenv("SRS_COMMIT_NO_FOLD");
+    bool fold = chunks > 1;
     for (size_t j = 0; j < chunks; ++j) fold = fold && local(cut[j], cut[j + 1]) > 0 && msm::may_fold(ck->key, (uint32_t)local(cut[j], cut[j + 1]));
-    // ... and with a DEFERRED TAIL (msm::chunked_*): a chunk runs only its sort and k_accum0, the accumulation levels run once for all
-    // chunks as a batch; the sort kernels go to a second stream so that they start in the drain of the previous chunk's k_accum0
-    const bool deferred = fold && msm::chunked_supported(ck->key, (uint32_t)per, (uint32_t)chunks);
-    static const bool two_streams = [] { const char *e = std::getenv("SRS_COMMIT_SORT_STREAM"); return !(e && e[0] == '0'); }();
-    hipStream_t s_sort = st;
-    if (deferred) {
-        msm::chunked_begin(ck->key, (uint32_t)per, (uint32_t)chunks, st);
-        if (two_streams) {
-            if (!ck->sort_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&ck->sort_stream, hipStreamNonBlocking));
-            s_sort = ck->sort_stream;
-            SRS_HIP_CHECK(hipEventRecord(ck->events[2 * chunks + 1], st));          // the workspace is free / its counters are cleared
-            SRS_HIP_CHECK(hipStreamWaitEvent(s_sort, ck->events[2 * chunks + 1], 0));
-        }
-    } else {
-        msm::reserve(ck->key, (uint32_t)per, 1);
-    }
+    msm::reserve(ck->key, (uint32_t)per, 1);
     auto upload = [&](size_t j) {
         if (W == 1) {
             upload_range(dst, segs, cut[j], cut[j + 1], ck->copy_stream);
@@ -1066,9 +1075,9 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
             fe_t *pd = ck->peer_dst + cut[j];
             if (mine)
                 SRS_HIP_CHECK(hipMemcpy2DAsync(pd + R * SL, W * SL * sizeof(fe_t), d + R * SL, W * SL * sizeof(fe_t), SL * sizeof(fe_t), mine,
-                                               hipMemcpyDeviceToDevice, ck->peer_stream));
+                                               hipMemcpyDefault, ck->peer_stream));      // (peer access was checked when the key was made)
             if (len % SL && full % W == R)
-                SRS_HIP_CHECK(hipMemcpyAsync(pd + full * SL, d + full * SL, (len % SL) * sizeof(fe_t), hipMemcpyDeviceToDevice, ck->peer_stream));
+                SRS_HIP_CHECK(hipMemcpyAsync(pd + full * SL, d + full * SL, (len % SL) * sizeof(fe_t), hipMemcpyDefault, ck->peer_stream));
             if (ck->peer_bytes) *ck->peer_bytes += local(cut[j], cut[j + 1]) * sizeof(fe_t);
         }
     };
@@ -1079,13 +1088,6 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
         const uint32_t nn = (uint32_t)local(cut[j], cut[j + 1]), base = (uint32_t)(W == 1 ? cut[j] : cut[j] / W);
         if (nn == 0) {                       // a rank without a stripe in this chunk (ragged end)
             SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
-            return;
-        }
-        if (deferred) {
-            SRS_HIP_CHECK(hipStreamWaitEvent(s_sort, ck->events[j], 0));
-            msm::chunked_front(ck->key, (uint32_t)j, ptr, nn, base, repr == SRS_REPR_MONT, s_sort, st, ck->events[chunks + 1 + j]);
-            launched[j] = true;
-            if (j + 1 == chunks) msm::chunked_tail(ck->key, st, (uint32_t)j);
             return;
         }
         SRS_HIP_CHECK(hipStreamWaitEvent(st, ck->events[j], 0));
@@ -1111,8 +1113,7 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
         used_slots.push_back((uint32_t)j);
         missed = missed || msm::overflow_missed(ck->key, (uint32_t)j);
     }
-    msm::note_commit(ck->key, used_slots.data(), (uint32_t)used_slots.size());
-    ck->key.last_scalars = local(0, n);                          // with note_commit's entry count: the density the next commit's cuts follow
+    msm::note_commit(ck->key, used_slots.data(), (uint32_t)used_slots.size(), local(0, n));   // + the scalars: the density the next commit's cuts follow
     xyzz_t redo;
     if (missed) {
         ++ck->key.stat_redo;
@@ -1142,7 +1143,7 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
 int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const std::vector<size_t> &cut, fe_t *dst, int repr,
                     hipStream_t st, srs_affine *out) {
     xyzz_t sum;
-    StreamRes r{ck->key, ck->copy_stream, ck->sort_stream, ck->events};
+    StreamRes r{ck->key, ck->copy_stream, ck->events};
     int rc = commit_streamed_core(r, segs, n, cut, dst, repr, st, &sum);
     if (rc) return rc;
     affine_t a;
@@ -1153,7 +1154,6 @@ int commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, const st
 
 // bucket additions per scalar of the key's last streamed commit (0: none yet)
 double key_density(const msm::Key &k) {
-    if (msm::wcc_next(k)) return 1.0;        // the wide chunked path accumulates faster than the upload: the even, upload-bound cuts
     return k.last_scalars ? (double)k.last_entries / (double)k.last_scalars : 0.0;
 }
 
@@ -1165,18 +1165,16 @@ double key_density(const msm::Key &k) {
 // chunk, the commit ends one chunk's work after the last byte, and the schedule that fits is many even chunks with a SMALL last one
 // (r05, profiles/r05_ab_survey_cuts.txt).
 std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0, double density = 0.0) {
-    static const size_t want = [] { const char *e = std::getenv("SRS_COMMIT_CHUNKS"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
+    const size_t want = (size_t)std::max<int64_t>(0, tuning::get_or(tuning::COMMIT_CHUNKS, 0));      // tests: n equal chunks
     if (!n_eff) n_eff = n;
     size_t chunks = want ? want : std::min<size_t>(4, std::max<size_t>(1, n_eff >> 20));
     chunks = std::min<size_t>(chunks, msm::LANDING_SLOTS);
     auto up = [&](size_t x) { return std::min(n, (x + align - 1) / align * align); };
     std::vector<size_t> cut(1, 0);
-    static const bool tuned_env = std::getenv("SRS_COMMIT_CUTS") != nullptr;
-    const bool tuned = tuned_env && n_eff >= ((size_t)1 << 20);     // the tuning switch leaves small commits (support circuit) alone
-    if (!want && !tuned && chunks < 4 && n_eff >= ((size_t)1 << 19)) {       // 0.5 - 4 M scalars: a quarter first, so that 3/4 of the upload hides behind its MSM
+    if (!want && chunks < 4 && n_eff >= ((size_t)1 << 19)) {       // 0.5 - 4 M scalars: a quarter first, so that 3/4 of the upload hides behind its MSM
         const size_t c = up(n / 4);
         if (c > 0 && c < n) cut.push_back(c);
-    } else if (want || (chunks < 4 && !tuned)) {     // equal pieces
+    } else if (want || chunks < 4) {     // equal pieces
         const size_t per = up((n + chunks - 1) / chunks);
         for (size_t a = per; a < n; a += per) cut.push_back(a);
     } else {                             // a SHORT first chunk (its upload is the only one nothing overlaps), growing ones after it
@@ -1191,19 +1189,8 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0, double
         // ~0.14 ms and accumulation about as fast per byte as the upload, the no-wait condition  upload(j + 1) <= cost(j)  means chunks
         // growing LINEARLY: ten of them, 11.2 -> 11.0 ms (same file, last section)
         std::vector<double> frac = {0.02, 0.058, 0.115, 0.19, 0.285, 0.40, 0.535, 0.69, 0.86};
-        static const bool adaptive = [] { const char *e = std::getenv("SRS_COMMIT_ADAPTIVE"); return !(e && e[0] == '0'); }();
-        if (adaptive && density > 0.0 && density < 4.5)            // upload-bound regime: eleven even chunks, the last one 4 %
+        if (density > 0.0 && density < 4.5)            // upload-bound regime: eleven even chunks, the last one 4 %
             frac = {0.03, 0.12, 0.24, 0.36, 0.48, 0.60, 0.72, 0.82, 0.90, 0.96};
-        if (const char *e = std::getenv(density > 0.0 && density < 4.5 && std::getenv("SRS_COMMIT_CUTS_SPARSE") ? "SRS_COMMIT_CUTS_SPARSE" : "SRS_COMMIT_CUTS")) {      // tuning: cumulative fractions, e.g. "0.1,0.4"
-            frac.clear();
-            for (const char *q = e; *q;) {
-                char *end = nullptr;
-                const double v = std::strtod(q, &end);
-                if (end == q) break;
-                frac.push_back(v);
-                q = *end ? end + 1 : end;
-            }
-        }
         for (double f : frac) {
             const size_t c = up((size_t)(f * (double)n));
             if (c > cut.back() && c < n && cut.size() < msm::LANDING_SLOTS) cut.push_back(c);    // one landing slot per chunk
@@ -1246,6 +1233,9 @@ int multi_commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, fe
                 }
                 dst = sh->full;
             }
+            // `full` is reused by every commit: this commit's uploads must not overwrite stripes the PREVIOUS commit's peer copies still read
+            // (the core orders its copy stream behind sh->stream)
+            if (!direct && sh->peer_pending) SRS_HIP_CHECK(hipStreamWaitEvent(sh->stream, sh->peer_done, 0));
             if (dev_copy && !direct) {
                 if (!sh->peer_stream) SRS_HIP_CHECK(hipStreamCreateWithFlags(&sh->peer_stream, hipStreamNonBlocking));
                 if (!sh->peer_done) SRS_HIP_CHECK(hipEventCreateWithFlags(&sh->peer_done, hipEventDisableTiming));
@@ -1253,7 +1243,7 @@ int multi_commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, fe
             } else if (direct) {
                 SRS_HIP_CHECK(hipStreamWaitEvent(sh->stream, ready, 0));           // (the core orders its copy stream behind sh->stream)
             }
-            StreamRes r{sh->key, sh->copy_stream, sh->sort_stream, sh->events};
+            StreamRes r{sh->key, sh->copy_stream, sh->events};
             r.h2d_bytes = &sh->stat_h2d_bytes;
             if (dev_copy && !direct) {
                 r.peer_dst = dev_copy;
@@ -1266,7 +1256,10 @@ int multi_commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, fe
             ++sh->stat_streamed;
             int rc = commit_streamed_core(r, segs, n, cut, dst, repr, sh->stream, &parts[d]);
             if (rc) throw DeviceError{rc};
-            if (dev_copy && !direct) SRS_HIP_CHECK(hipEventRecord(sh->peer_done, sh->peer_stream));
+            if (dev_copy && !direct) {
+                SRS_HIP_CHECK(hipEventRecord(sh->peer_done, sh->peer_stream));
+                sh->peer_pending = true;
+            }
         });
     }
     int rc = SRS_OK;
@@ -1312,10 +1305,9 @@ int srs_commit_upload(srs_ck *ck, const srs_fe *scalars_host, size_t n, srs_fe *
             return commit_streamed(ck, segs, n, commit_cuts(n, align, n / ck->key.world, key_density(ck->key)), reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
         });
     }
-    static const bool multi_streamed = [] { const char *e = std::getenv("SRS_MULTI_STREAMED"); return !(e && e[0] == '0'); }();
-    if (!ck->shards.empty() && multi_streamed && n >= ((size_t)ck->shards.size() << (msm::STRIPE_LOG + 1))) {
+    if (!ck->shards.empty() && n >= ((size_t)ck->shards.size() << (msm::STRIPE_LOG + 1))) {
         // multi-device key: every shard streams its stripes over its own link, overlapped with its MSM; the device copy is assembled on the
-        // process's device by peer copies (multi_commit_streamed).  SRS_MULTI_STREAMED=0: the r04 path below (A/B)
+        // process's device by peer copies (multi_commit_streamed)
         return guarded([&]() -> int {
             std::vector<Seg> segs(1, Seg{reinterpret_cast<const fe_t *>(scalars_host), 0, n});
             return multi_commit_streamed(ck, segs, n, reinterpret_cast<fe_t *>(dev_copy), repr, st, out);
@@ -1394,8 +1386,7 @@ int srs_commit_upload_columns(srs_ck *ck, const srs_fe *const *columns_host, con
             off += std::max(lens[c], pad_size);
         }
         fe_t *dst = reinterpret_cast<fe_t *>(dev_copy);
-        static const bool multi_streamed = [] { const char *e = std::getenv("SRS_MULTI_STREAMED"); return !(e && e[0] == '0'); }();
-        if (!ck->shards.empty() && multi_streamed && n >= ((size_t)ck->shards.size() << (msm::STRIPE_LOG + 1)))
+        if (!ck->shards.empty() && n >= ((size_t)ck->shards.size() << (msm::STRIPE_LOG + 1)))
             // multi-device key (r05): every shard streams ITS stripes of the columns (and of their zero padding) over its own link
             return multi_commit_streamed(ck, segs, n, dst, repr, st, out);
         const bool sharded_streamed = ck->shards.empty() && ck->key.world > 1 && n >= ((size_t)ck->key.world << (msm::STRIPE_LOG + 1));

@@ -2,6 +2,7 @@
 #pragma once
 #include "curve.cuh"
 #include "devrt.h"
+#include "tuning.h"
 
 #include <cstdlib>
 
@@ -30,8 +31,6 @@ constexpr int MAX_LEVELS = 8;
 constexpr uint32_t RED_ROWS = 256;        // bucket index = hi * RED_COLS + lo
 constexpr uint32_t RED_COLS = NBUCKET / RED_ROWS;
 constexpr uint32_t RED_THREADS = 4 * RED_COLS;   // k_reduce_final: one quad per element, 128 elements
-constexpr uint32_t ACC1_TREE_MAX = 0;            // tree mode (4 lanes per output, each on a quarter of the parts) above the quad mode: measured no gain
-                                                 // (the level is VALU-bound, not latency-bound: profiles/r03_sq_counters_msm.txt); SRS_MSM_TREE_MAX=<log2> enables it
 constexpr uint32_t ACC1_QUAD_MAX = 1u << 17;     // k_accum1 runs one quad per output when a level has at most this many outputs (x batch); r04: 2^16 -> 2^17 (the support circuit's 3 x 2^15 outputs: 138 -> 109 us)
 constexpr uint32_t BATCH_ARGS = 16;    // MSMs per set of launches (batch descriptor = kernel argument); larger batches are chunked
 constexpr uint32_t LANDING_SLOTS = 16;  // sets of launches whose results may be in flight at once (chunked commits)
@@ -39,7 +38,7 @@ constexpr uint32_t NORM_G = 16;           // points per inversion in the key-exp
 // Slot mode (r04): every bucket owns 2^SLOT_LOG persistent partial sums ("slots") in HBM.  Part p of bucket b adds its entries INTO
 // slot (b, p) -- across all the chunks of a streamed commit -- so the accumulation levels, the wave-level pass and the bucket fold that
 // every chunk used to run are replaced by ONE reduction of the slots per commit.  The last slot of a bucket takes the (rare) parts
-// beyond 2^SLOT_LOG - 1, which go through the level kernels as before.  SRS_MSM_SLOT_LOG=<2..8> overrides (tests force overflow).
+// beyond 2^SLOT_LOG - 1, which go through the level kernels as before.  tuning msm_slot_log = 2..8 overrides (tests force overflow).
 constexpr uint32_t SLOT_LOG = 6;
 constexpr uint32_t SLOT_L0_MIN_LOG = 2, SLOT_L0_MAX_LOG = 16;   // part length 2^l0, chosen on the device from the mean bucket load (k_plan_s)
 // Wide windows for large MSMs: 13 signed 20-bit digits per scalar instead of 16 signed 16-bit ones (19 % fewer bucket additions).
@@ -51,29 +50,14 @@ constexpr uint32_t NSEG_W = 16;           // 2^(WBITS_W - 1) / NBUCKET
 constexpr uint32_t WIDE_THREADS = 256, WIDE_PER = 2, WIDE_TILE = WIDE_THREADS * WIDE_PER;   // scalars per workgroup of the segment passes
 // Measured (profiles/r02_wide_windows.txt): the wide pipeline wins from ~8 M scalars (12 * 2^20 uniform: 20.3 vs 22.2 ms);
 // below, its 16 bucket reductions and the extra grouping pass cost more than the 3 / 16 of the additions it saves.
-constexpr uint32_t WIDE_MIN_KEY_LOG = 23; // keys from 2^23 bases get the second, 13-window table (r04, see wants_wide_table in msm.hip; SRS_MSM_WIDE=0 / 1)
-constexpr uint32_t WIDE_MIN_N_LOG = 23;   // whole device-resident MSMs from 2^23 scalars take the wide path (SRS_MSM_WIDE_MIN=<log2> overrides)
+constexpr uint32_t WIDE_MIN_KEY_LOG = 23; // keys from 2^23 bases get the second, 13-window table (r04, see wants_wide_table in msm.hip; tuning msm_wide / environment SRS_MSM_WIDE = 0 / 1)
+constexpr uint32_t WIDE_MIN_N_LOG = 23;   // whole device-resident MSMs from 2^23 scalars take the wide path (tuning msm_wide_min = <log2> overrides)
 
 static_assert(RED_ROWS == 256 && RED_COLS == 128, "k_rowcol lane layout");
 static_assert(NBUCKET % PLAN_THREADS == 0, "k_plan tiling");
 
-// workspace of a chunked commit with a deferred tail (msm.hip: chunked_*): set j of the commit lives in batch slot j
-struct Chunked {
-    uint32_t sets = 0, l0_log = 0;
-    int levels = 0;
-    bool defer_tail = false;      // the accumulation levels of all sets run once, batched, in chunked_tail (else per set, after its k_accum0)
-    uint64_t M = 0, parts0_cap = 0, parts1_cap = 0;      // per slot: digit slots, level-0 / level-1 part capacity
-    size_t plan_stride = 0;
-    uint16_t *dig = nullptr, *tb = nullptr;
-    uint32_t *sorted = nullptr, *count = nullptr, *cursor = nullptr, *plan = nullptr;
-    xyzz_t *ping = nullptr, *pong = nullptr, *buckets = nullptr, *rc = nullptr, *d_out = nullptr;
-};
-
-// a new key's hot-bucket prediction: expected (SRS_MSM_EXPECT_OVF=0: not expected -- the tests of the redo path start cold)
-inline bool expect_ovf_initial() {
-    static const bool v = [] { const char *e = std::getenv("SRS_MSM_EXPECT_OVF"); return !(e && e[0] == '0'); }();
-    return v;
-}
+// a new key's hot-bucket prediction: expected (tuning msm_expect_ovf = 0: not expected -- the tests of the redo path start cold)
+inline bool expect_ovf_initial() { return tuning::get_or(tuning::MSM_EXPECT_OVF, 1) != 0; }
 
 // Device-resident commitment key: window-expanded table T[w * len + i] = 2^(16 w) P_i, coordinates in the
 // R' = 2^261 Montgomery form of the 9 x 29-bit multiplier (field29.cuh) once build_table has run.
@@ -87,14 +71,13 @@ struct Key {
     affine_t *table_w = nullptr;   // T_w[w][i] = 2^(20 w) P_i, w < NWIN_W (keys of >= 2^WIDE_MIN_KEY_LOG bases; owned by the key: release())
     xyzz_t *fold_buckets = nullptr;   // running bucket sums of a chunked commit (enqueue(.., fold)); owned by the key
     bool slot_wide[LANDING_SLOTS] = {};       // landing slot -> which pipeline produced it (finish() combines 3 or 4 partial sums)
-    Chunked chunked;          // layout of the running chunked commit (pointers into `arena`)
     // slot mode (see SLOT_LOG): owned by the key, grow-only
     xyzz_t *slots = nullptr;          // [batch][NBUCKET][S] persistent partial sums of the running commit
     size_t slots_pts = 0;
     uint8_t *used = nullptr;          // [2][BATCH_ARGS][NBUCKET]: slots of a bucket that hold a sum (parity = set index inside the commit)
     uint32_t *h_ovf = nullptr;        // page-locked [2][LANDING_SLOTS][BATCH_ARGS]: parts beyond the slots, then non-zero digits, reported by k_plan_s
     uint64_t last_entries = 0;        // non-zero digits (= bucket additions) of the last commit that ran in slot mode (note_commit) ...
-    uint64_t last_scalars = 0;        // ... and its scalars (set by the caller): the density the next streamed commit's chunk cuts are chosen for
+    uint64_t last_scalars = 0;        // ... and its scalars (both set by note_commit, both 0 when the commit had no slot-mode set): the density the next streamed commit's chunk cuts are chosen for
     uint32_t slot_s = 0;              // S of the running commit
     uint32_t seq = 0;                 // sets enqueued in the running commit
     bool commit_ovf = false;          // the running commit launches the overflow kernels
@@ -104,15 +87,11 @@ struct Key {
     bool slot_ovf_on[LANDING_SLOTS] = {};   // ... with its overflow kernels launched
     uint32_t slot_batch[LANDING_SLOTS] = {};
     uint64_t stat_slot_sets = 0, stat_hot_sets = 0, stat_redo = 0, stat_other_sets = 0;   // srs_ck_msm_stats
-    // wide chunked commit (msm.hip: k_accum_wb; opt-in): the sets of a streamed commit on the 20-bit windows
-    xyzz_t *wb = nullptr;             // [NSEG_W][NBUCKET] persistent bucket sums of the running commit (64 MiB; owned by the key)
-    bool wcc_active = false;          // the running chunked commit takes this path (its first set decides)
-    bool wcc_set[LANDING_SLOTS] = {}; // landing slot -> the set ran on this path (its hot-bucket report is in h_ovf)
     Arena arena;              // per-key scratch (grow-only)
     void *h_result = nullptr; // page-locked landing buffer of the 3 partial sums per MSM (direct copy, no staging hop)
 };
 
-// fills table[len .. 16*len) from table[0 .. len); with SRS_MSM_WIDE=1 the key also gets table_w
+// fills table[len .. 16*len) from table[0 .. len); keys that want it (wants_wide_table) also get table_w
 void build_table(Key &k, hipStream_t stream);
 // frees what the key owns besides `table`: table_w, the scratch arena, the landing buffer
 void release(Key &k);
@@ -154,19 +133,7 @@ void reserve(Key &k, uint32_t n_max, uint32_t batch);
 // been switched, so the second run is complete); note_commit() records what the finished commit saw for the next prediction (on at
 // once -- and from a key's first commit --, off after three commits in a row without hot buckets).
 bool overflow_missed(const Key &k, uint32_t slot);
-bool wcc_next(const Key &k);                 // the key's next streamed commit takes the wide chunked path (its chunks want the even, upload-bound cuts)
-void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots);
-
-// Chunked commit with a DEFERRED TAIL (one 16-bit-window MSM cut into `sets` <= BATCH_ARGS chunks of <= n_max scalars, all over one
-// bucket set): chunked_begin lays the sets out as the batch slots of one workspace; chunked_front(j) runs only the sort and k_accum0
-// of set j (sort kernels on s_sort, k_accum0 on s_acc after `sorted_ev`; both may be the same stream); chunked_tail runs the
-// accumulation levels ONCE for all sets as a batch, adds the sets' buckets, reduces, and lands the 3 partial sums in `slot`
-// (finish(k, 1, slot, true, ..) after the stream has been synchronised).  Every set must be non-empty.
-bool chunked_supported(const Key &k, uint32_t n_max, uint32_t sets);
-void chunked_begin(Key &k, uint32_t n_max, uint32_t sets, hipStream_t stream);
-void chunked_front(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t s_sort, hipStream_t s_acc,
-                   hipEvent_t sorted_ev);
-void chunked_tail(Key &k, hipStream_t stream, uint32_t slot);
+void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots, uint64_t scalars);   // scalars: what the commit accumulated (with the entry count: its density)
 
 }  // namespace msm
 }  // namespace srs

@@ -38,6 +38,7 @@
 // host and emulator builds keep the C form.
 #define SRS_F29_CHAIN 1
 #include "msm.h"
+#include "tuning.h"
 #include "curve29.cuh"
 #include "prof.h"
 
@@ -426,23 +427,11 @@ static_assert(SORT_TILE2 == SORT_THREADS * S2_PER, "k_scatter2: one tile = S2_PE
 __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
     k_scatter2(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ gpay, size_t g_stride,
                const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t *__restrict__ cursor /* [batch][NBUCKET] */,
-               uint32_t *__restrict__ sorted, size_t sorted_stride, uint32_t TILE2, uint16_t *__restrict__ tb, size_t tb_stride, uint32_t arr) {
+               uint32_t *__restrict__ sorted, size_t sorted_stride, uint32_t TILE2) {
     __shared__ uint32_t cnt[S2_RANGE], lb[S2_RANGE], gb[S2_RANGE], sc[64];
     __shared__ uint32_t spay[SORT_TILE2];
     __shared__ uint16_t skey[SORT_TILE2];
     const uint32_t m = blockIdx.y, tid = threadIdx.x;
-    if (tb) {
-        // sort v2: the thread -> bucket map of level 0 (k_expand's work, from the plan array `arr`) rides on this launch, a bucket per
-        // wavefront and round (in the r04 flow it rode on k_group's launch, which v2 runs BEFORE the plan)
-        const uint32_t *tp = plan + (size_t)m * plan_stride + (size_t)arr * (NBUCKET + 1);
-        uint16_t *map = tb + (size_t)m * tb_stride;
-        const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-        const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (tid >> 6), lane = tid & 63u;
-        for (uint32_t b = wv; b < NBUCKET; b += waves) {
-            const uint32_t s0 = tp[b], e0 = tp[b + 1];
-            for (uint32_t t = s0 + lane; t < e0; t += 64) map[t] = (uint16_t)b;
-        }
-    }
     const uint32_t total = plan[(size_t)m * plan_stride + NBUCKET];        // number of non-zero digits of this MSM
     // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b
     // takes tile (b % 8) * ceil(tiles / 8) + b / 8 -- every XCD sorts one contiguous eighth of the grouped array, i.e.
@@ -505,192 +494,6 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
     for (uint32_t i = tid; i < n_tile; i += blockDim.x) {
         const uint32_t b = skey[i];
         out[gb[b] + (i - lb[b])] = spay[i];
-    }
-}
-
-// ---- r05: the two-pass sort WITHOUT a digit array and without the 2^15-counter flush ("sort v2"; measured SLOWER, off: see use_sort_v2) ----
-// The r03 flow stores 16 digits per scalar (k_digits: 32 B written, then read twice) and counts the entries of every bucket in k_hist,
-// whose workgroups each flush a 2^15-counter LDS histogram through global atomics -- 25 of its 33 us per launch, ten launches per streamed
-// commit.  Here the digits are RECOMPUTED from the scalar by the two kernels that need them (32 B read either way, one Montgomery product
-// per scalar), the first pass only counts per SEGMENT (128 counters), and the per-bucket counts are taken from the GROUPED array, where a
-// tile of 8192 entries spans a few hundred consecutive buckets: an LDS histogram of <= 512 counters and as many global atomics per tile.
-//   k_seghist  : scalars -> entries of the tile per segment (tile_hist); clears the bucket counters
-//   k_scan_seg2: per-tile segment counts -> offsets into the grouped array (segment bases from the counts themselves), seg_off[]
-//   k_group2   : scalars -> entries grouped by segment (k_group's LDS sort; one scalar = 16 digit slots per thread and sub-tile)
-//   k_count    : grouped entries -> count[bucket]
-//   (k_plan / k_plan_s, then k_scatter2 as before; the thread -> bucket map rides on k_scatter2's launch)
-template <class C>
-__device__ __forceinline__ void scalar_codes(const fe_t *__restrict__ ptr, uint32_t i, int is_mont, uint32_t rank, uint32_t world,
-                                             uint32_t (&code)[NWIN]) {
-    using S = typename C::S;
-    fe_t s = ptr[shard_global_index(i, rank, world)];
-    if (is_mont) s = S::from_mont(s);
-    uint32_t carry = 0;
-#pragma unroll
-    for (int w = 0; w < NWIN; ++w) {
-        const uint32_t raw = (s.v[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu;
-        const uint32_t v = raw + carry;
-        if (v > 0x8000u) {
-            code[w] = (((0x10000u - v) - 1u) | 0x8000u) & 0xFFFFu;   // negative digit, magnitude 1..0x7FFF (v = 2^16: zero digit 0xFFFF, carry)
-            carry = 1;
-        } else {
-            code[w] = v ? (v - 1u) : 0xFFFFu;            // positive digit 1..0x8000, or zero
-            carry = 0;
-        }
-    }
-}
-
-constexpr uint32_t SEGHIST_THREADS = 256;
-template <class C>
-__global__ void SRS_KERNEL_BOUNDS(SEGHIST_THREADS, 1)
-    k_seghist(BatchDesc bd, int is_mont, uint32_t rank, uint32_t world, uint32_t tile_s, uint32_t *__restrict__ tile_hist /* [batch][SEG][tiles] */,
-              uint32_t *__restrict__ count_zero, uint32_t n_zero) {
-    constexpr uint32_t NW = SEGHIST_THREADS / 64;
-    __shared__ uint32_t cnt[NW][SEG];              // per wavefront: an atomic only meets the lanes of its own wavefront
-    const uint32_t m = blockIdx.y, tid = threadIdx.x, wave = tid >> 6;
-    for (uint32_t j = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + tid; j < n_zero; j += gridDim.x * gridDim.y * blockDim.x) count_zero[j] = 0;
-    for (uint32_t j = tid; j < NW * SEG; j += blockDim.x) (&cnt[0][0])[j] = 0;
-    __syncthreads();
-    const uint32_t n = bd.n[m], lo = blockIdx.x * tile_s;
-    const uint32_t hi = lo + tile_s < n ? lo + tile_s : n;
-    for (uint32_t i = lo + tid; i < hi; i += blockDim.x) {
-        uint32_t code[NWIN];
-        scalar_codes<C>(bd.ptr[m], i, is_mont, rank, world, code);
-#pragma unroll
-        for (int w = 0; w < NWIN; ++w)
-            if (code[w] != 0xFFFFu) atomicAdd(&cnt[wave][(code[w] & 0x7FFFu) / SEG_BUCKETS], 1u);
-    }
-    __syncthreads();
-    for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) {
-        uint32_t c = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < NW; ++w) c += cnt[w][sgm];
-        tile_hist[((size_t)m * SEG + sgm) * gridDim.x + blockIdx.x] = c;
-    }
-}
-
-// grid = (SEG, batch): workgroup `sgm` adds up the counts of all segments before its own (the segment's first entry in the grouped array),
-// then turns its own row into exclusive offsets.  seg_off[m][sgm] = that base; seg_off[m][SEG] = the MSM's number of entries.
-__global__ void SRS_KERNEL_BOUNDS(1024, 1)
-    k_scan_seg2(const uint32_t *__restrict__ tile_hist, uint32_t *__restrict__ tile_off, uint32_t T1, uint32_t *__restrict__ seg_off) {
-    // (the offsets go to an array of their own: every workgroup reads the COUNTS of all segments before its own)
-    __shared__ uint32_t lds[64];
-    const uint32_t sgm = blockIdx.x, m = blockIdx.y;
-    const uint32_t *all = tile_hist + (size_t)m * SEG * T1;
-    uint32_t part = 0;
-    for (uint32_t i = threadIdx.x; i < sgm * T1; i += blockDim.x) part += all[i];
-    uint32_t base;
-    (void)block_exclusive_scan(part, lds, &base);
-    const uint32_t *row = tile_hist + ((size_t)m * SEG + sgm) * T1;
-    uint32_t *orow = tile_off + ((size_t)m * SEG + sgm) * T1;
-    uint32_t carry = 0;
-    for (uint32_t at = 0; at < T1; at += blockDim.x) {
-        const uint32_t i = at + threadIdx.x;
-        const uint32_t v = i < T1 ? row[i] : 0;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, lds, &total);
-        if (i < T1) orow[i] = base + carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) {
-        seg_off[(size_t)m * (SEG + 1) + sgm] = base;
-        if (sgm == SEG - 1) seg_off[(size_t)m * (SEG + 1) + SEG] = base + carry;
-    }
-}
-
-template <class C>
-__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
-    k_group2(BatchDesc bd, int is_mont, uint32_t rank, uint32_t world, uint32_t tile_s, const uint32_t *__restrict__ tile_off,
-             uint16_t *__restrict__ gkey, uint32_t *__restrict__ gpay, size_t g_stride, uint32_t table_stride) {
-    static_assert(GRP_PER == NWIN, "k_group2: a thread's GRP_PER digit slots are the NWIN windows of one scalar");
-    __shared__ uint32_t cur[SEG], cnt[SEG], lb[SEG], sc[64];
-    __shared__ uint32_t spay[GRP_SUB];
-    __shared__ uint16_t skey[GRP_SUB];
-    const uint32_t m = blockIdx.y, tid = threadIdx.x;
-    const uint32_t n = bd.n[m];
-    const uint32_t lo = blockIdx.x * tile_s;
-    if (lo >= n) return;
-    const uint32_t hi = lo + tile_s < n ? lo + tile_s : n;
-    const uint32_t T1 = gridDim.x;
-    for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cur[sgm] = tile_off[((size_t)m * SEG + sgm) * T1 + blockIdx.x];
-    uint16_t *ok = gkey + (size_t)m * g_stride;
-    uint32_t *op = gpay + (size_t)m * g_stride;
-    const uint32_t pay0 = bd.base[m];
-    for (uint32_t sub = lo; sub < hi; sub += SORT_THREADS) {            // workgroup-uniform: SORT_THREADS scalars = GRP_SUB digit slots
-        for (uint32_t sgm = tid; sgm < SEG; sgm += blockDim.x) cnt[sgm] = 0;
-        __syncthreads();
-        const uint32_t i = sub + tid;
-        uint32_t code[NWIN], rank_[NWIN];
-        if (i < hi) {
-            scalar_codes<C>(bd.ptr[m], i, is_mont, rank, world, code);
-        } else {
-#pragma unroll
-            for (int w = 0; w < NWIN; ++w) code[w] = 0xFFFFu;
-        }
-#pragma unroll
-        for (int w = 0; w < NWIN; ++w) rank_[w] = code[w] != 0xFFFFu ? atomicAdd(&cnt[(code[w] & 0x7FFFu) / SEG_BUCKETS], 1u) : 0u;
-        __syncthreads();
-        uint32_t n_sub;
-        const uint32_t ex = block_exclusive_scan(tid < SEG ? cnt[tid] : 0u, sc, &n_sub);
-        if (tid < SEG) lb[tid] = ex;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < NWIN; ++w) {
-            if (code[w] != 0xFFFFu) {
-                const uint32_t bkt = code[w] & 0x7FFFu, pos = lb[bkt / SEG_BUCKETS] + rank_[w];
-                skey[pos] = (uint16_t)bkt;
-                spay[pos] = ((uint32_t)w * table_stride + pay0 + i) | ((code[w] & 0x8000u) << 16);
-            }
-        }
-        __syncthreads();
-        for (uint32_t e = tid; e < n_sub; e += blockDim.x) {             // index order: a segment's run goes out as one contiguous piece
-            const uint32_t key = skey[e], sgm = key / SEG_BUCKETS, g = cur[sgm] + (e - lb[sgm]);
-            ok[g] = (uint16_t)key;
-            op[g] = spay[e];
-        }
-        __syncthreads();
-        if (tid < SEG) cur[tid] += cnt[tid];
-    }
-}
-
-// entries per bucket from the grouped array: same tiles (and XCD mapping) as k_scatter2.   grid = (8 * ceil(tiles / 8), batch)
-__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
-    k_count(const uint16_t *__restrict__ gkey, size_t g_stride, const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ count, uint32_t TILE2) {
-    __shared__ uint32_t cnt[S2_RANGE];
-    const uint32_t m = blockIdx.y, tid = threadIdx.x;
-    const uint32_t total = seg_off[(size_t)m * (SEG + 1) + SEG];
-    const uint32_t n_tiles = (total + TILE2 - 1) / TILE2, per_xcd = (n_tiles + 7) / 8;
-    if (blockIdx.x / 8 >= per_xcd) return;
-    const uint32_t tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    if (tile_id >= n_tiles) return;
-    const uint32_t lo = tile_id * TILE2;
-    if (lo >= total) return;
-    const uint32_t hi = lo + TILE2 < total ? lo + TILE2 : total;
-    const uint16_t *key = gkey + (size_t)m * g_stride;
-    uint32_t *out = count + (size_t)m * NBUCKET;
-    const uint32_t b_lo = ((uint32_t)key[lo] / SEG_BUCKETS) * SEG_BUCKETS;
-    const uint32_t b_hi = ((uint32_t)key[hi - 1] / SEG_BUCKETS + 1) * SEG_BUCKETS;
-    if (b_hi - b_lo > S2_RANGE) {            // a tile over more than two segments (few entries for the bucket range): entry by entry
-        for (uint32_t i = lo + tid; i < hi; i += blockDim.x) atomicAdd(&out[key[i]], 1u);
-        return;
-    }
-    for (uint32_t b = tid; b < S2_RANGE; b += blockDim.x) cnt[b] = 0;
-    __syncthreads();
-    const uint32_t i0 = lo + tid * S2_PER;
-    if (i0 + S2_PER <= hi && (reinterpret_cast<uintptr_t>(key + i0) & 15u) == 0) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(key + i0);
-        atomicAdd(&cnt[(x.x & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.x >> 16) - b_lo], 1u);
-        atomicAdd(&cnt[(x.y & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.y >> 16) - b_lo], 1u);
-        atomicAdd(&cnt[(x.z & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.z >> 16) - b_lo], 1u);
-        atomicAdd(&cnt[(x.w & 0xFFFFu) - b_lo], 1u); atomicAdd(&cnt[(x.w >> 16) - b_lo], 1u);
-    } else {
-        for (uint32_t k = 0; k < S2_PER; ++k)
-            if (i0 + k < hi) atomicAdd(&cnt[(uint32_t)key[i0 + k] - b_lo], 1u);
-    }
-    __syncthreads();
-    for (uint32_t b = tid; b < S2_RANGE; b += blockDim.x) {
-        const uint32_t c = cnt[b];
-        if (c) atomicAdd(&out[b_lo + b], c);
     }
 }
 
@@ -1087,31 +890,6 @@ __global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 2)
         const uint32_t b = skey[i];
         sorted[gb[b] + (i - lb[b])] = spay[i];
     }
-}
-
-__global__ void SRS_KERNEL_BOUNDS(SORT_THREADS, 1)
-    k_scatter_g(const uint16_t *__restrict__ gkey, const uint32_t *__restrict__ gpay, const uint32_t *__restrict__ seg_off,
-                const uint32_t *__restrict__ tile_base, uint32_t *__restrict__ cursor /* [NSEG_W][NBUCKET], absolute */,
-                uint32_t *__restrict__ sorted) {
-    __shared__ uint32_t h[NBUCKET];
-    uint32_t v, lo, hi;
-    if (!wide_tile(seg_off, tile_base, v, lo, hi)) return;
-    tile_histogram(h, gkey, lo, hi);
-    uint32_t *cur = cursor + (size_t)v * NBUCKET;
-    for (uint32_t b0 = threadIdx.x; b0 < NBUCKET; b0 += 4 * blockDim.x) {   // 4 reservations in flight per thread
-        uint32_t c[4], r[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = h[b0 + u * blockDim.x];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&cur[b0 + u * blockDim.x], c[u]) : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (c[u]) h[b0 + u * blockDim.x] = r[u];
-    }
-    __syncthreads();
-    for_each_digit(gkey, lo, hi, [&](uint32_t i, uint32_t code) {
-        uint32_t pos = atomicAdd(&h[code & 0x7FFFu], 1u);
-        sorted[pos] = gpay[i];
-    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1519,11 +1297,11 @@ template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum1(const xyzz_t *__restrict__ in, size_t in_stride, const uint32_t *__restrict__ plan,
              size_t plan_stride, int level, xyzz_t *__restrict__ out, size_t out_stride, uint32_t l1,
-             const Link *__restrict__ link, uint32_t quad_max, uint32_t tree_max) {
+             const Link *__restrict__ link, uint32_t quad_max) {
     uint32_t m = blockIdx.y;
     const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t t;
-    bool quad, tree = false;
+    bool quad;
     size_t in_off, out_off;
     if (link) {                                // wide windows: flat thread space of this level over the segments
         const uint32_t n_all = link->base[level][NSEG_W];
@@ -1544,8 +1322,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     const uint32_t n_out = tp[NBUCKET];
     if (!link) {
         quad = (uint64_t)n_out * gridDim.y <= quad_max;   // whole batch: latency-bound only while the chip is not full
-        tree = !quad && (uint64_t)n_out * gridDim.y <= tree_max;
-        t = (quad || tree) ? (lin >> 2) : lin;
+        t = quad ? (lin >> 2) : lin;
     }
     if (t >= n_out) return;                    // in quad mode the 4 lanes of a quad leave together
     uint32_t b = upper_bucket(tp, t);
@@ -1555,22 +1332,6 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     if (e > s + l1) e = s + l1;
     using E29 = Ec29<C>;
     const xyzz_t *src = in + in_off;
-    if (tree) {
-        // a level with too many outputs for the quad mode and too few to fill the chip one lane each (< ~1.5 wavefronts per SIMD, every
-        // lane a chain of l1 - 1 dependent additions): the 4 lanes of a quad take every 4th part (l1 / 4 - 1 additions), then two
-        // exchange rounds -- 5 dependent additions instead of 15 and 4x the wavefronts to interleave them
-        const uint32_t q = threadIdx.x & 3u;
-        uint32_t j = s + q;
-        xyzz29_t acc = j < e ? E29::unpack(src[j]) : E29::identity();
-        for (j += 4; j < e; j += 4) acc = E29::add(acc, E29::unpack(src[j]));
-#pragma unroll 1
-        for (unsigned d = 2; d >= 1; d >>= 1) {
-            const xyzz29_t other = shfl_down_point29(acc, d, 4);
-            if (q < d) acc = E29::add(acc, other);
-        }
-        if (q == 0) out[out_off + t] = E29::pack(acc);
-        return;
-    }
     xyzz29_t acc = E29::unpack(src[s]);
     if (quad) {
         const uint32_t q = threadIdx.x & 3u;
@@ -1737,24 +1498,6 @@ __global__ void SRS_KERNEL_BOUNDS(64, 1)
     }
 }
 
-// chunked commits with a deferred tail (chunked_* below): the finished buckets of ALL chunk sets (batch slot m: where k_rowcol would
-// read them) are added up into the key's running buckets.  One QUAD per bucket.   grid = NBUCKET * 4 / 256
-template <class C>
-__global__ void SRS_KERNEL_BOUNDS(256, 1)
-    k_bucket_sum(const xyzz_t *__restrict__ buckets, const xyzz_t *__restrict__ ping, size_t ping_stride, const xyzz_t *__restrict__ pong,
-                 size_t pong_stride, const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t sets, xyzz_t *__restrict__ total) {
-    using E29 = Ec29<C>;
-    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x, b = lin >> 2, q = lin & 3u;
-    xyzz29_t acc = E29::identity();
-    for (uint32_t m = 0; m < sets; ++m) {
-        const uint32_t *hdr = plan + (size_t)m * plan_stride + plan_stride - 4;      // [0] levels run, [1] all buckets single
-        const xyzz_t *B = hdr[1] ? ((hdr[0] & 1u) ? ping + (size_t)m * ping_stride : pong + (size_t)m * pong_stride) : buckets + (size_t)m * NBUCKET;
-        const xyzz29_t x = E29::unpack(B[b]);
-        acc = m == 0 ? x : E29::add_quad(acc, x, q);
-    }
-    if (q == 0) total[b] = E29::pack(acc);
-}
-
 // ---------------------------------------------------------------------------------------------
 // 5. bucket reduction  S = sum_b (b+1) B_b,  b = hi * RED_COLS + lo
 //    S = RED_COLS * sum_hi hi * R_hi  +  sum_lo (lo+1) * C_lo
@@ -1900,88 +1643,6 @@ __global__ void SRS_KERNEL_BOUNDS(256, 1)
     if (lane == 0) out[which] = E29::pack(x);
 }
 
-// ---- wide chunked commit (r05; OPT-IN: SRS_MSM_WCC=1, see use_wcc) -- the sets of a streamed commit on the 20-bit windows -------------
-// VERDICT r04 asked for wider windows in the chunked commit.  At chunk size a bucket of the 2^19 sees only ~10-30 entries, so there are no
-// slots and no parts: ONE thread per (segment, bucket) adds the bucket's entries of this set into the bucket's PERSISTENT sum (wb, 64 MiB
-// per key), and what would idle half of every wavefront -- Poisson chain lengths -- is removed by ORDERING the threads by chain length:
-//   k_wcc_classes : histogram of min(count, 63) over the 2^19 buckets
-//   k_wcc_perm    : perm[] = the buckets by class, longest chains first (a counting sort; the order inside a class is arbitrary, the sums
-//                   do not depend on it), empty buckets last
-//   k_accum_wb    : thread u takes bucket perm[u].  A bucket with more than max(WCC_CAP, 4 x mean) entries in ONE set (a hot bucket: witnesses of 0 / 1 /
-//                   small values) is NOT accumulated but counted in *rep: the host then runs the commit again on the standard pipeline and
-//                   the key stops choosing this path (overflow_missed / note_commit, as slot mode's prediction)
-// after the last set the usual wide-window reduction runs on wb (k_rowcol from_buckets, k_reduce_final, k_wide_combine).
-constexpr uint32_t WCC_CLASSES = 64, WCC_CAP = 256;
-__global__ void SRS_KERNEL_BOUNDS(1024, 1)
-    k_wcc_classes(const uint32_t *__restrict__ plan, size_t plan_stride, uint32_t *__restrict__ bins) {
-    __shared__ uint32_t h[WCC_CLASSES];
-    const uint32_t t = threadIdx.x, g = blockIdx.x * blockDim.x + t;
-    if (t < WCC_CLASSES) h[t] = 0;
-    __syncthreads();
-    const uint32_t *off = plan + (size_t)(g / NBUCKET) * plan_stride + (g % NBUCKET);
-    const uint32_t cnt = off[1] - off[0];
-    atomicAdd(&h[cnt < WCC_CLASSES - 1 ? cnt : WCC_CLASSES - 1], 1u);
-    __syncthreads();
-    if (t < WCC_CLASSES && h[t]) atomicAdd(&bins[t], h[t]);
-}
-__global__ void SRS_KERNEL_BOUNDS(1024, 1)
-    k_wcc_perm(const uint32_t *__restrict__ plan, size_t plan_stride, const uint32_t *__restrict__ bins, uint32_t *__restrict__ cursor,
-               uint32_t *__restrict__ perm) {
-    __shared__ uint32_t h[WCC_CLASSES], base[WCC_CLASSES];
-    const uint32_t t = threadIdx.x, g = blockIdx.x * blockDim.x + t;
-    if (t < WCC_CLASSES) h[t] = 0;
-    __syncthreads();
-    const uint32_t *off = plan + (size_t)(g / NBUCKET) * plan_stride + (g % NBUCKET);
-    const uint32_t cnt = off[1] - off[0], c = cnt < WCC_CLASSES - 1 ? cnt : WCC_CLASSES - 1;
-    const uint32_t rank = atomicAdd(&h[c], 1u);
-    __syncthreads();
-    if (t < WCC_CLASSES) {
-        uint32_t st = 0;                                         // longest chains first: class c starts behind the classes above it
-        for (uint32_t k2 = t + 1; k2 < WCC_CLASSES; ++k2) st += bins[k2];
-        base[t] = st + (h[t] ? atomicAdd(&cursor[t], h[t]) : 0u);
-    }
-    __syncthreads();
-    perm[base[c] + rank] = g;
-}
-template <class C>
-__global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
-    k_accum_wb(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ plan, size_t plan_stride, const uint32_t *__restrict__ perm,
-               const uint32_t *__restrict__ bins, const affine_t *__restrict__ table, xyzz_t *__restrict__ wb, int first,
-               uint32_t *__restrict__ rep, uint32_t cap) {
-    using E29 = Ec29<C>;
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= NSEG_W * NBUCKET) return;
-    const uint32_t g = perm[u];
-    if (u >= NSEG_W * NBUCKET - bins[0]) {                       // the empty buckets (class 0) are the tail of the thread space
-        if (first) wb[g] = E29::pack(E29::identity());
-        return;
-    }
-    const uint32_t *off = plan + (size_t)(g / NBUCKET) * plan_stride + (g % NBUCKET);
-    const uint32_t s = off[0], e = off[1];
-    xyzz29_t acc = first ? E29::identity() : E29::unpack(wb[g]);
-    if (e - s > cap) {                                           // hot bucket: reported, not accumulated (the commit is run again)
-        atomicAdd(rep, 1u);
-        if (first) wb[g] = E29::pack(acc);
-        return;
-    }
-    uint32_t v = sorted[s];
-    uint32_t vn = s + 1 < e ? sorted[s + 1] : 0u;
-    affine_t p = table[v & 0x7FFFFFFFu];
-    for (uint32_t j = s; j < e; ++j) {                           // the next point and the index after it travel behind the addition (k_accum0s)
-        uint32_t vnn = 0;
-        affine_t pn = p;
-        if (j + 1 < e) {
-            pn = table[vn & 0x7FFFFFFFu];
-            if (j + 2 < e) vnn = sorted[j + 2];
-        }
-        acc = E29::madd_signed(acc, E29::load_raw(p), (v >> 31) != 0);
-        v = vn;
-        vn = vnn;
-        p = pn;
-    }
-    wb[g] = E29::pack(acc);
-}
-
 // ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
@@ -2006,7 +1667,9 @@ static void expand_windows(affine_t *table, uint32_t n, int nwin, int nbits, xyz
 // device-resident MSMs of >= 2^WIDE_MIN_N_LOG scalars take the 20-bit windows; the sets of a streamed commit stay on the 16-bit windows
 // and the slots (their chunks are 0.3-3 M scalars, where the wide pipeline's fixed costs lose).  SRS_MSM_WIDE=0 / 1: never / every key.
 static bool wants_wide_table(size_t len) {
-    static const int forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();
+    // tuning msm_wide; unset: the environment's SRS_MSM_WIDE (a deployer's memory switch: 0 = no second table), else by key size
+    static const int env_forced = [] { const char *e = std::getenv("SRS_MSM_WIDE"); return e ? std::atoi(e) : -1; }();
+    const int forced = (int)tuning::get_or(tuning::MSM_WIDE, env_forced);
     if (forced == 0 || len == 0) return false;
     return forced == 1 || len >= ((size_t)1 << WIDE_MIN_KEY_LOG);
 }
@@ -2085,18 +1748,16 @@ void build_table(Key &k, hipStream_t stream) {
 // later levels combine with the dearer full additions (+ 1.4 / L0 of the level-0 work), and the launch ends with a
 // partly filled last wave of workgroups (the chip holds 2^18 level-0 threads at a time: + ~0.5 / waves, waves = entries /
 // (L0 * 2^18)).  16 is best up to ~10 M scalars (measured on the chunks of a 12 * 2^20 commit: 64 cost 0.9 ms more in
-// k_accum0 than it saved in k_accum1), 32 above, 64 from ~40 M.  SRS_MSM_L0=<log2> forces a value (tests).
+// k_accum0 than it saved in k_accum1), 32 above, 64 from ~40 M.  Tuning msm_l0 = <log2> forces a value (tests).
 static uint32_t l0_log_for(uint64_t M) {
-    static const int forced = [] { const char *e = std::getenv("SRS_MSM_L0"); return e ? std::atoi(e) : 0; }();
+    const int forced = (int)tuning::get_or(tuning::MSM_L0, 0);
     if (forced >= 1 && forced <= 7) return (uint32_t)forced;
     // small MSMs (the support circuit's 3 * 2^15 and 2^15-row commits) cannot fill the chip with 16-entry parts: 2^21 digit slots give
-    // < 2^17 level-0 threads, each a chain of 16 dependent additions on a chip that holds 2^17.6 -- shorter parts, more threads
-    // (r03; SRS_MSM_L0_SMALL=0 restores 16 everywhere)
-    static const bool small_on = [] { const char *e = std::getenv("SRS_MSM_L0_SMALL"); return !(e && e[0] == '0'); }();
+    // < 2^17 level-0 threads, each a chain of 16 dependent additions on a chip that holds 2^17.6 -- shorter parts, more threads (r03)
     // r05: parts of 8 from 2^20 digit slots on (was 2^21): the support circuit's batch (3 * 2^15 + 2 x 2^15 scalars, 1.6 M slots) 589 -> 501 us per call,
     // profiles/r05_ab_small_msm.txt -- with parts of 4 its first accumulation level has 5 partial sums per bucket to combine, with 8 two or three
-    if (small_on && M < (1ull << 20)) return 2;
-    if (small_on && M < (1ull << 22)) return 3;
+    if (M < (1ull << 20)) return 2;
+    if (M < (1ull << 22)) return 3;
     uint32_t lg = ACC_L0_LOG;
     while (lg < 7 && (M >> (lg + 1)) >= (5ull << 20)) ++lg;
     return lg;
@@ -2104,24 +1765,10 @@ static uint32_t l0_log_for(uint64_t M) {
 
 // k_accum1 gives every output to a quad of lanes while a level has at most this many outputs (x batch): a level that cannot
 // fill the chip's 2^17.6 resident lanes is a chain of dependent additions, and a quad shortens each by 3.3x for 1.3x the
-// lane-cycles.  SRS_MSM_QUAD_MAX=<log2> overrides (A/B).
-// k_accum1's tree mode for levels of (quad_max, tree_max] outputs; SRS_MSM_TREE_MAX=<log2> (0: off)
-static uint32_t acc1_tree_max() {
-    static const uint32_t v = [] {
-        const char *e = std::getenv("SRS_MSM_TREE_MAX");
-        if (!e) return ACC1_TREE_MAX;
-        const int lg = std::atoi(e);
-        return (lg >= 1 && lg <= 24) ? (1u << lg) : 0u;
-    }();
-    return v;
-}
+// lane-cycles.  Tuning msm_quad_max = <log2> overrides (tests).
 static uint32_t acc1_quad_max() {
-    static const uint32_t v = [] {
-        const char *e = std::getenv("SRS_MSM_QUAD_MAX");
-        const int lg = e ? std::atoi(e) : 0;
-        return (lg >= 1 && lg <= 24) ? (1u << lg) : ACC1_QUAD_MAX;
-    }();
-    return v;
+    const int64_t lg = tuning::get_or(tuning::MSM_QUAD_MAX, 0);
+    return (lg >= 1 && lg <= 24) ? (1u << lg) : ACC1_QUAD_MAX;
 }
 
 static int levels_for(uint64_t max_entries) {
@@ -2135,29 +1782,12 @@ static int levels_for(uint64_t max_entries) {
     return levels;
 }
 
-// large MSMs take the two-pass scatter (k_group + k_scatter2); SRS_MSM_SORT=1 / 2 forces the single- / two-pass path
+// large MSMs take the two-pass scatter (k_group + k_scatter2); tuning msm_sort = 1 / 2 forces the single- / two-pass path
 static bool use_two_pass(uint64_t M, uint32_t batch) {
-    static const int forced = [] { const char *e = std::getenv("SRS_MSM_SORT"); return e ? std::atoi(e) : 0; }();
+    const int forced = (int)tuning::get_or(tuning::MSM_SORT, 0);
     if (forced == 1) return false;
     if (forced == 2) return true;
     return M * batch >= TWO_PASS_MIN_SLOTS;
-}
-
-// sort v2 (k_seghist / k_scan_seg2 / k_group2 / k_count: no digit array, no 2^15-counter flush) is OFF by measurement (r05,
-// profiles/r05_ab_sort_v2.txt): per 1.7 M-scalar chunk it takes 244 us against the r04 flow's 185 (k_seghist 85 + k_scan_seg2 12 + k_group2 79 +
-// k_count 14 vs k_digits 32 + k_hist 37 + k_scan_seg 8 + k_group 56; plan and k_scatter2 equal) -- recomputing the digits from the scalars
-// twice (a Montgomery product and sixteen LDS atomics per scalar behind ONE dependent 32-byte load per thread and round) costs more than the
-// digit array's write and two reads, and what k_hist's 2^15-counter flush costs (25 us) k_count + the second pass over the scalars give back.
-// The k = 20 step: 11.00 / 11.03 ms with it, 10.95 / 11.00 without, same box.  SRS_MSM_SORTV=2 turns it on for every set (tests, A/B).
-static bool use_sort_v2(uint64_t, uint32_t) {
-    static const int forced = [] { const char *e = std::getenv("SRS_MSM_SORTV"); return e ? std::atoi(e) : 0; }();
-    return forced == 2;
-}
-// scalars per workgroup of k_seghist / k_group2: ~SORT_TARGET_BLOCKS workgroups over the whole batch, whole sub-tiles of SORT_THREADS scalars
-static uint32_t sort_v2_tile(uint32_t n_max, uint32_t batch) {
-    uint32_t t = (uint32_t)(((uint64_t)n_max * batch + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
-    t = (t + SORT_THREADS - 1) / SORT_THREADS * SORT_THREADS;
-    return t < SORT_THREADS ? SORT_THREADS : t;
 }
 
 size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
@@ -2176,11 +1806,9 @@ size_t workspace_bytes(uint32_t n_max, uint32_t batch) {
     per += Arena::pad(parts1 * sizeof(xyzz_t));              // pong
     per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));     // buckets
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
-    if (use_two_pass(M, batch) || use_sort_v2(M, batch)) {
+    if (use_two_pass(M, batch)) {
         per += Arena::pad(M * sizeof(uint16_t)) + Arena::pad(M * sizeof(uint32_t));                     // grouped keys / payloads
         per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));            // per-tile segment counts
-        per += Arena::pad((SEG + 1) * sizeof(uint32_t));                                                // segment offsets (sort v2)
-        per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));            // per-tile segment offsets (sort v2)
     }
     return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 4096;
 }
@@ -2214,12 +1842,10 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     xyzz_t *pong = A.take<xyzz_t>(parts1_cap * batch);
     xyzz_t *buckets = A.take<xyzz_t>((size_t)NBUCKET * batch);
     xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
-    const bool v2 = use_sort_v2(M, batch), two_pass = v2 || use_two_pass(M, batch);
+    const bool two_pass = use_two_pass(M, batch);
     uint16_t *gkey = two_pass ? A.take<uint16_t>(M * batch) : nullptr;
     uint32_t *gpay = two_pass ? A.take<uint32_t>(M * batch) : nullptr;
     uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
-    uint32_t *seg_off = v2 ? A.take<uint32_t>((size_t)(SEG + 1) * batch) : nullptr;
-    uint32_t *tile_off = v2 ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
 
     BatchDesc bd;
     for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
@@ -2235,21 +1861,6 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
     const uint32_t tiles = ceil_div(n_max, tile);
     const Link *no_link = nullptr;
-    if (v2) {
-        const uint32_t tile_s = sort_v2_tile(n_max, batch), tiles_s = ceil_div(n_max, tile_s);
-        SRS_LAUNCH((k_seghist<C>), (tiles_s, batch), (SEGHIST_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, tile_hist, count,
-                   (uint32_t)(NBUCKET * batch));
-        SRS_LAUNCH(k_scan_seg2, (SEG, batch), (1024), 0, stream, (const uint32_t *)tile_hist, tile_off, tiles_s, seg_off);
-        SRS_LAUNCH((k_group2<C>), (tiles_s, batch), (SORT_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, (const uint32_t *)tile_off, gkey,
-                   gpay, (size_t)M, (uint32_t)k.len);
-        SRS_LAUNCH(k_count, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (size_t)M,
-                   (const uint32_t *)seg_off, count, (uint32_t)SORT_TILE2);
-        SRS_LAUNCH(k_plan, (batch, levels + 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, plan_stride,
-                   levels, l0_log, (uint32_t)ACC_L1_LOG, (const uint32_t *)nullptr);
-        SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
-                   (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, plan_stride, cursor, sorted, (size_t)M,
-                   (uint32_t)SORT_TILE2, tb, (size_t)parts0_cap, 1u);                  // + the thread -> bucket map (k_expand's work)
-    } else {
     SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont, s_rank, s_world, count,
                (uint32_t)(NBUCKET * batch));
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
@@ -2265,13 +1876,12 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
         // 8 x ceil(tiles / 8) workgroups: the XCD-aware mapping of k_scatter2 needs every (XCD, slot) pair to exist
         SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
                    (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, plan_stride, cursor, sorted, (size_t)M,
-                   (uint32_t)SORT_TILE2, (uint16_t *)nullptr, (size_t)0, 0u);
+                   (uint32_t)SORT_TILE2);
     } else {
         SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                    bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
     }
     SRS_LAUNCH(k_expand, (NBUCKET / 4, batch), (256), 0, stream, (const uint32_t *)plan, plan_stride, tb, (size_t)parts0_cap, no_link, 1u);
-    }
 
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
@@ -2283,9 +1893,9 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
     uint64_t cap = parts0_cap;
     for (int level = 1; level < levels; ++level) {
         cap = cap / ACC_L1 + NBUCKET + 1;
-        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                    (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, plan_stride, level, nxt, nxt_stride,
-                   (uint32_t)ACC_L1, no_link, acc1_quad_max(), acc1_tree_max());
+                   (uint32_t)ACC_L1, no_link, acc1_quad_max());
         std::swap(cur, nxt);
         std::swap(cur_stride, nxt_stride);
         // both buffers can hold any later level: parts shrink monotonically and pong >= level-1 cap
@@ -2319,28 +1929,17 @@ static bool enqueue_t(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_
 static bool use_wide(const Key &k, uint32_t n_max, uint32_t batch);
 // ---- slot mode: host side -------------------------------------------------------------------------------------------------------
 static uint32_t slot_log() {
-    static const uint32_t v = [] {
-        const char *e = std::getenv("SRS_MSM_SLOT_LOG");
-        const int lg = e ? std::atoi(e) : 0;
-        return (lg >= 2 && lg <= 8) ? (uint32_t)lg : SLOT_LOG;
-    }();
-    return v;
+    const int64_t lg = tuning::get_or(tuning::MSM_SLOT_LOG, 0);
+    return (lg >= 2 && lg <= 8) ? (uint32_t)lg : SLOT_LOG;
 }
-// the part length a large set prefers when its buckets would fit shorter parts: 2^4 (SRS_MSM_SLOT_L0=<log2> for A/B)
-static uint32_t slot_want_cap() {
-    static const uint32_t v = [] {
-        const char *e = std::getenv("SRS_MSM_SLOT_L0");
-        const int lg = e ? std::atoi(e) : 4;
-        return (lg >= 2 && lg <= 8) ? (uint32_t)lg : 4u;
-    }();
-    return v;
-}
+// the part length a large set prefers when its buckets would fit shorter parts: 2^4
+static uint32_t slot_want_cap() { return 4u; }
 // Slot mode is for the sets of a CHUNKED commit (fold != FOLD_NONE): that is where every set used to pay its own accumulation levels, wave-level
 // pass and bucket fold.  A set that is a whole MSM keeps the r03 flow, by measurement (profiles/r04_ab_slots_cuts.txt): the batched
 // cross-term commitments would each pay a slot reduction (k = 17 Sangria step 6.02 vs 5.76 ms), a single 2^24 MSM is 2 % slower (22.3 vs
-// 21.85 ms).  SRS_MSM_SLOTS=0: never; SRS_MSM_SLOTS=2: every 16-bit-window set (what the emulator tests force).
+// 21.85 ms).  Tuning msm_slots = 0: never; 2: every 16-bit-window set (what the emulator tests force).
 static bool use_slots(const Key &k, uint32_t n_max, uint32_t batch, Fold fold) {
-    static const int mode = [] { const char *e = std::getenv("SRS_MSM_SLOTS"); return e ? std::atoi(e) : 1; }();
+    const int mode = (int)tuning::get_or(tuning::MSM_SLOTS, 1);
     if (mode == 0) return false;
     if (fold != FOLD_NONE) return batch == 1;
     return mode == 2 && !use_wide(k, n_max, batch);
@@ -2377,10 +1976,8 @@ static size_t workspace_bytes_slots(uint32_t n_max, uint32_t batch) {
     per += Arena::pad(h.cap * sizeof(xyzz_t)) + Arena::pad(h.cap * sizeof(uint16_t)) + Arena::pad(h.cap1 * sizeof(xyzz_t));   // overflow parts, map, pong
     per += Arena::pad((size_t)NBUCKET * (h.S / 8 + 1) * sizeof(xyzz_t)) + Arena::pad((size_t)NBUCKET * (h.S / 64 + 1) * sizeof(xyzz_t));   // reduction ping / pong
     per += Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t));
-    if (use_two_pass(h.M, batch) || use_sort_v2(h.M, batch)) {
+    if (use_two_pass(h.M, batch)) {
         per += Arena::pad(h.M * sizeof(uint16_t)) + Arena::pad(h.M * sizeof(uint32_t));
-        per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));
-        per += Arena::pad((SEG + 1) * sizeof(uint32_t));
         per += Arena::pad((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * sizeof(uint32_t));
     }
     return per * batch + Arena::pad(3 * batch * sizeof(xyzz_t)) + 8192;
@@ -2438,12 +2035,10 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
     xyzz_t *red_a = A.take<xyzz_t>((size_t)NBUCKET * (S / 8 + 1) * batch);
     xyzz_t *red_b = A.take<xyzz_t>((size_t)NBUCKET * (S / 64 + 1) * batch);
     xyzz_t *rc = A.take<xyzz_t>((size_t)(RED_ROWS + RED_COLS) * batch);
-    const bool v2 = use_sort_v2(M, batch), two_pass = v2 || use_two_pass(M, batch);
+    const bool two_pass = use_two_pass(M, batch);
     uint16_t *gkey = two_pass ? A.take<uint16_t>(M * batch) : nullptr;
     uint32_t *gpay = two_pass ? A.take<uint32_t>(M * batch) : nullptr;
     uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
-    uint32_t *seg_off = v2 ? A.take<uint32_t>((size_t)(SEG + 1) * batch) : nullptr;
-    uint32_t *tile_off = v2 ? A.take<uint32_t>((size_t)SEG * (SORT_TARGET_BLOCKS + 2 * NWIN) * batch) : nullptr;
 
     BatchDesc bd;
     for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
@@ -2458,21 +2053,6 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
     const uint32_t tiles = ceil_div(n_max, tile);
     uint32_t *h_ovf = k.h_ovf + (size_t)slot * BATCH_ARGS;
     const uint32_t arr = (uint32_t)h.levels + 1;
-    if (v2) {
-        const uint32_t tile_s = sort_v2_tile(n_max, batch), tiles_s = ceil_div(n_max, tile_s);
-        SRS_LAUNCH((k_seghist<C>), (tiles_s, batch), (SEGHIST_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, tile_hist, count,
-                   (uint32_t)(NBUCKET * batch));
-        SRS_LAUNCH(k_scan_seg2, (SEG, batch), (1024), 0, stream, (const uint32_t *)tile_hist, tile_off, tiles_s, seg_off);
-        SRS_LAUNCH((k_group2<C>), (tiles_s, batch), (SORT_THREADS), 0, stream, bd, is_mont, s_rank, s_world, tile_s, (const uint32_t *)tile_off, gkey,
-                   gpay, (size_t)M, (uint32_t)k.len);
-        SRS_LAUNCH(k_count, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (size_t)M,
-                   (const uint32_t *)seg_off, count, (uint32_t)SORT_TILE2);
-        SRS_LAUNCH(k_plan_s, (batch, h.levels + 2), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, h.plan_stride, h.levels, S,
-                   (uint32_t)ACC_L1_LOG, used_prev, used_next, first ? 1 : 0, h_ovf, slot_want_cap());
-        SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
-                   (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, h.plan_stride, cursor, sorted, (size_t)M,
-                   (uint32_t)SORT_TILE2, tb, (size_t)h.cap, arr);                      // + the thread -> bucket map (k_expand's work)
-    } else {
     SRS_LAUNCH((k_digits<C>), (ceil_div(n_max, 256), batch), (256), 0, stream, bd, dig, (size_t)M, is_mont, s_rank, s_world, count,
                (uint32_t)(NBUCKET * batch));
     SRS_LAUNCH(k_hist, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
@@ -2487,11 +2067,10 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
                    (size_t)h.cap, (uint32_t)h.levels + 1);                 // + the thread -> bucket map (k_expand's work)
         SRS_LAUNCH(k_scatter2, (8 * ceil_div(ceil_div(M, SORT_TILE2), 8), batch), (SORT_THREADS), 0, stream, (const uint16_t *)gkey,
                    (const uint32_t *)gpay, (size_t)M, (const uint32_t *)plan, h.plan_stride, cursor, sorted, (size_t)M,
-                   (uint32_t)SORT_TILE2, (uint16_t *)nullptr, (size_t)0, 0u);
+                   (uint32_t)SORT_TILE2);
     } else {
         SRS_LAUNCH(k_scatter, (tiles, NWIN, batch), (SORT_THREADS), 0, stream, (const uint16_t *)dig, (size_t)M,
                    bd, cursor, sorted, (size_t)M, (uint32_t)k.len, tile);
-    }
     }
     uint64_t units = 0;
     for (uint32_t m = 0; m < batch; ++m) units += n_host[m];
@@ -2508,7 +2087,7 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
             cap = cap / ACC_L1 + NBUCKET + 1;
             SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS), batch), (ACC_THREADS), 0, stream,
                        (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, h.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
-                       acc1_quad_max(), 0u);
+                       acc1_quad_max());
             std::swap(cur, nxt);
             std::swap(cur_stride, nxt_stride);
         }
@@ -2550,22 +2129,16 @@ static bool enqueue_slots_t(Key &k, const fe_t *const *scalars_dev, const uint32
 }
 
 bool overflow_missed(const Key &k, uint32_t slot) {
-    if (slot < LANDING_SLOTS && k.wcc_set[slot]) return k.h_ovf && k.h_ovf[(size_t)slot * BATCH_ARGS] != 0;   // hot buckets the wide chunked set skipped
     if (slot >= LANDING_SLOTS || !k.slot_mode[slot] || k.slot_ovf_on[slot] || !k.h_ovf) return false;
     for (uint32_t m = 0; m < k.slot_batch[slot]; ++m)
         if (k.h_ovf[(size_t)slot * BATCH_ARGS + m]) return true;
     return false;
 }
-void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots) {
+void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots, uint64_t scalars) {
     bool any = false, slot_sets = false;
     uint64_t entries = 0;
     for (uint32_t i = 0; i < n_slots; ++i) {
         const uint32_t sl = slots_used[i];
-        if (sl < LANDING_SLOTS && k.wcc_set[sl] && k.h_ovf && k.h_ovf[(size_t)sl * BATCH_ARGS]) {   // a wide chunked set met a hot bucket: back to slot mode
-            k.expect_ovf = true;
-            k.cold_streak = 0;
-            ++k.stat_hot_sets;
-        }
         if (sl >= LANDING_SLOTS || !k.slot_mode[sl] || !k.h_ovf) continue;
         slot_sets = true;
         for (uint32_t m = 0; m < k.slot_batch[sl]; ++m) entries += k.h_ovf[(size_t)(LANDING_SLOTS + sl) * BATCH_ARGS + m];
@@ -2578,8 +2151,12 @@ void note_commit(Key &k, const uint32_t *slots_used, uint32_t n_slots) {
     // the common case and its first commit used to run twice) -- and un-expected only after COLD_COMMITS commits in a row without them:
     // launching the overflow kernels for nothing costs ~0.3 ms of empty launches per commit, missing them costs the commit run a second time
     constexpr uint32_t COLD_COMMITS = 3;
-    if (!slot_sets) return;
+    if (!slot_sets) {                        // no slot-mode set: no entry count either -- the next commit's cuts fall back to the default schedule
+        k.last_entries = k.last_scalars = 0;
+        return;
+    }
     k.last_entries = entries;
+    k.last_scalars = scalars;
     if (any) {
         k.expect_ovf = true;
         k.cold_streak = 0;
@@ -2628,7 +2205,7 @@ static size_t workspace_bytes_wide(uint32_t n) {
 }
 
 static bool use_wide(const Key &k, uint32_t n_max, uint32_t batch) {
-    static const int min_log = [] { const char *e = std::getenv("SRS_MSM_WIDE_MIN"); return e ? std::atoi(e) : (int)WIDE_MIN_N_LOG; }();
+    const int min_log = (int)tuning::get_or(tuning::MSM_WIDE_MIN, (int64_t)WIDE_MIN_N_LOG);
     return k.table_w != nullptr && batch == 1 && n_max >= (1u << min_log);
 }
 
@@ -2644,12 +2221,10 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     uint32_t *gpay = A.take<uint32_t>(w.M);
     uint32_t *sorted = A.take<uint32_t>(w.M);
     uint32_t *tile_cnt = A.take<uint32_t>((size_t)NSEG_W * w.T);
-    // the counting sort inside the segments: two passes through LDS (k_group_g + k_scatter2_g) unless SRS_MSM_WIDE_SORT=1 asks for the
-    // single pass (k_scatter_g: every entry stored on its own)
-    static const bool two_pass = [] { const char *e = std::getenv("SRS_MSM_WIDE_SORT"); return !(e && e[0] == '1'); }();
-    uint16_t *gkey2 = two_pass ? A.take<uint16_t>(w.M) : nullptr;
-    uint32_t *gpay2 = two_pass ? A.take<uint32_t>(w.M) : nullptr;
-    uint32_t *tile_hist = two_pass ? A.take<uint32_t>((size_t)SEG * w.tiles_g) : nullptr;
+    // the counting sort inside the segments: two passes through LDS (k_group_g + k_scatter2_g)
+    uint16_t *gkey2 = A.take<uint16_t>(w.M);
+    uint32_t *gpay2 = A.take<uint32_t>(w.M);
+    uint32_t *tile_hist = A.take<uint32_t>((size_t)SEG * w.tiles_g);
     uint32_t *seg3 = A.take<uint32_t>(4 * (NSEG_W + 2));
     uint32_t *seg_total = seg3, *seg_off = seg3 + (NSEG_W + 2), *tile_base = seg3 + 2 * (NSEG_W + 2), *tile_base2 = seg3 + 3 * (NSEG_W + 2);
     Link *link = A.take<Link>(1);
@@ -2683,18 +2258,13 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
                (const uint32_t *)tile_base, count, tile_hist);
     SRS_LAUNCH(k_plan, (NSEG_W, w.levels + 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, w.plan_stride, w.levels, w.l0_log,
                (uint32_t)ACC_L1_LOG, (const uint32_t *)seg_off);
-    if (two_pass) {
-        SRS_LAUNCH(k_scan_seg_g, (SEG, NSEG_W), (1024), 0, stream, tile_hist, w.tiles_g, (const uint32_t *)tile_base, (const uint32_t *)plan,
-                   w.plan_stride);
-        SRS_LAUNCH(k_group_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay, (const uint32_t *)seg_off,
-                   (const uint32_t *)tile_base, (const uint32_t *)tile_hist, gkey2, gpay2);
-        // tiles of SORT_TILE2 entries cut per segment: at most M / SORT_TILE2 + NSEG_W of them; 8 x ceil(. / 8) workgroups (XCD mapping)
-        SRS_LAUNCH(k_scatter2_g, (8 * ceil_div(ceil_div(w.M, tile2_host) + NSEG_W, 8)), (SORT_THREADS), 0, stream, (const uint16_t *)gkey2,
-                   (const uint32_t *)gpay2, (const uint32_t *)seg_off, (const uint32_t *)tile_base2, cursor, sorted);
-    } else {
-        SRS_LAUNCH(k_scatter_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay,
-                   (const uint32_t *)seg_off, (const uint32_t *)tile_base, cursor, sorted);
-    }
+    SRS_LAUNCH(k_scan_seg_g, (SEG, NSEG_W), (1024), 0, stream, tile_hist, w.tiles_g, (const uint32_t *)tile_base, (const uint32_t *)plan,
+               w.plan_stride);
+    SRS_LAUNCH(k_group_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay, (const uint32_t *)seg_off,
+               (const uint32_t *)tile_base, (const uint32_t *)tile_hist, gkey2, gpay2);
+    // tiles of SORT_TILE2 entries cut per segment: at most M / SORT_TILE2 + NSEG_W of them; 8 x ceil(. / 8) workgroups (XCD mapping)
+    SRS_LAUNCH(k_scatter2_g, (8 * ceil_div(ceil_div(w.M, tile2_host) + NSEG_W, 8)), (SORT_THREADS), 0, stream, (const uint16_t *)gkey2,
+               (const uint32_t *)gpay2, (const uint32_t *)seg_off, (const uint32_t *)tile_base2, cursor, sorted);
     SRS_LAUNCH(k_link, (1), (64), 0, stream, (const uint32_t *)plan, w.plan_stride, w.levels, link);
     const Link *lk = link;
     SRS_LAUNCH(k_expand, (NBUCKET / 4, NSEG_W), (256), 0, stream, (const uint32_t *)plan, w.plan_stride, tb, (size_t)0, lk, 1u);
@@ -2705,9 +2275,9 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     uint64_t cap = w.parts0_cap;
     for (int level = 1; level < w.levels; ++level) {
         cap = cap / ACC_L1 + (uint64_t)NSEG_W * (NBUCKET + 1);
-        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS)), (ACC_THREADS), 0,
+        SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, acc1_quad_max())), ACC_THREADS)), (ACC_THREADS), 0,
                    stream, (const xyzz_t *)cur, (size_t)0, (const uint32_t *)plan, w.plan_stride, level, nxt, (size_t)0, (uint32_t)ACC_L1, lk,
-                   acc1_quad_max(), 0u);
+                   acc1_quad_max());
         std::swap(cur, nxt);
     }
     SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), NSEG_W), (FINAL_THREADS), 0, stream, (const xyzz_t *)ping, (size_t)0,
@@ -2721,278 +2291,6 @@ static bool enqueue_wide_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t
     SRS_HIP_CHECK(hipMemcpyAsync(land, d_out, 4 * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
     k.slot_wide[slot] = true;
     return true;
-}
-
-// ---- wide chunked commit: host side (kernels: k_wcc_classes / k_wcc_perm / k_accum_wb) ----------------------------------------------------
-// SRS_MSM_WCC=1: the sets of a streamed commit take the 20-bit windows when the key has the second table and does not expect hot buckets
-// (Key::expect_ovf, learnt by the slot-mode commits before); =2: whatever the prediction (tests).  Default: off -- see DESIGN.md 9.
-static int wcc_mode_env() {
-    static const int v = [] { const char *e = std::getenv("SRS_MSM_WCC"); return e ? std::atoi(e) : 0; }();
-    return v;
-}
-static bool use_wcc(const Key &k) { return k.table_w != nullptr && (wcc_mode_env() == 2 || (wcc_mode_env() == 1 && !k.expect_ovf)); }
-// (A WHOLE wide-window MSM as one such set -- no parts, no levels -- was measured too: 25.0 against 19.5 ms at 2^24, the short top window gives
-// the low 2^14 buckets 3.5x the mean chain and 2^19 threads are two rounds of the chip; profiles/r05_ab_wide_chunked.txt section 3.)
-bool wcc_next(const Key &k) { return use_wcc(k); }
-static size_t workspace_bytes_wcc(uint32_t n) {
-    return workspace_bytes_wide(n) + Arena::pad((size_t)NSEG_W * NBUCKET * sizeof(uint32_t)) + Arena::pad(4 * WCC_CLASSES * sizeof(uint32_t)) + 4096;
-}
-
-template <class C>
-static bool enqueue_wcc_t(Key &k, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t stream, uint32_t slot, Fold fold) {
-    if (n == 0) return false;
-    const bool first = fold == FOLD_FIRST, last = fold == FOLD_LAST;
-    const WideShape w = wide_shape(n);
-    // a bucket is hot when it holds several times what a set without zero digits gives the heaviest regular ones (the short top window adds
-    // n / 2^14 entries to each of the low 2^14 buckets: ~3.5x the mean)
-    const uint32_t cap = std::max<uint32_t>(WCC_CAP, 4u * (uint32_t)(w.M >> 19) + 64u);
-    if (!k.wb) SRS_HIP_CHECK(hipMalloc((void **)&k.wb, (size_t)NSEG_W * NBUCKET * sizeof(xyzz_t)));
-    if (!k.h_ovf) {
-        SRS_HIP_CHECK(hipHostMalloc((void **)&k.h_ovf, 2 * (size_t)LANDING_SLOTS * BATCH_ARGS * sizeof(uint32_t)));
-        for (size_t i = 0; i < 2 * (size_t)LANDING_SLOTS * BATCH_ARGS; ++i) k.h_ovf[i] = 0;
-    }
-    Arena &A = k.arena;
-    A.reserve(workspace_bytes_wcc(n));
-    A.reset();
-    xyzz_t *d_out = A.take<xyzz_t>(4);
-    xyzz_t *d_seg = A.take<xyzz_t>(4 * NSEG_W);
-    uint16_t *gkey = A.take<uint16_t>(w.M);
-    uint32_t *gpay = A.take<uint32_t>(w.M);
-    uint32_t *sorted = A.take<uint32_t>(w.M);
-    uint32_t *tile_cnt = A.take<uint32_t>((size_t)NSEG_W * w.T);
-    uint16_t *gkey2 = A.take<uint16_t>(w.M);
-    uint32_t *gpay2 = A.take<uint32_t>(w.M);
-    uint32_t *tile_hist = A.take<uint32_t>((size_t)SEG * w.tiles_g);
-    uint32_t *seg3 = A.take<uint32_t>(4 * (NSEG_W + 2));
-    uint32_t *seg_total = seg3, *seg_off = seg3 + (NSEG_W + 2), *tile_base = seg3 + 2 * (NSEG_W + 2), *tile_base2 = seg3 + 3 * (NSEG_W + 2);
-    uint32_t *count = A.take<uint32_t>((size_t)NSEG_W * NBUCKET);
-    uint32_t *cursor = A.take<uint32_t>((size_t)NSEG_W * NBUCKET);
-    uint32_t *plan = A.take<uint32_t>(w.plan_stride * NSEG_W);
-    xyzz_t *rc = A.take<xyzz_t>((size_t)NSEG_W * (RED_ROWS + RED_COLS));
-    uint32_t *perm = A.take<uint32_t>((size_t)NSEG_W * NBUCKET);
-    uint32_t *bins = A.take<uint32_t>(4 * WCC_CLASSES);          // [0] class counts, [1] class cursors, [2][0] hot buckets skipped
-    uint32_t *cls_cur = bins + WCC_CLASSES, *rep = bins + 2 * WCC_CLASSES;
-
-    WideDesc wd;
-    wd.ptr = scalars_dev;
-    wd.n = n;
-    wd.base = base;
-    wd.rank = k.compact_scalars ? 0u : k.rank;
-    wd.world = k.compact_scalars ? 1u : k.world;
-    wd.is_mont = is_mont;
-    const uint32_t table_stride = (uint32_t)k.len;
-    // the wide pipeline's sort (enqueue_wide_t): MSD pass into the 16 segments, then the two-pass counting sort inside them; of the plan
-    // only the entry offsets are used (k_plan's first workgroup row)
-    SRS_HIP_CHECK(hipMemsetAsync(seg_total, 0, (NSEG_W + 1) * sizeof(uint32_t), stream));
-    SRS_HIP_CHECK(hipMemsetAsync(count, 0, (size_t)NSEG_W * NBUCKET * sizeof(uint32_t), stream));
-    SRS_HIP_CHECK(hipMemsetAsync(bins, 0, 4 * WCC_CLASSES * sizeof(uint32_t), stream));
-    SRS_LAUNCH((k_seg_pass<C, false>), (w.T), (WIDE_THREADS), 0, stream, wd, tile_cnt, w.T, seg_total, (uint16_t *)nullptr,
-               (uint32_t *)nullptr, table_stride);
-    const uint32_t small_tiles = (w.M >> 19) < 64 ? 1u : 0u, tile2_host = small_tiles ? SORT_TILE2 / 4 : SORT_TILE2;
-    SRS_LAUNCH(k_seg_scan, (NSEG_W), (1024), 0, stream, tile_cnt, w.T, (const uint32_t *)seg_total, seg_off, tile_base, tile_base2, small_tiles);
-    SRS_LAUNCH((k_seg_pass<C, true>), (w.T), (WIDE_THREADS), 0, stream, wd, tile_cnt, w.T, seg_total, gkey, gpay, table_stride);
-    SRS_LAUNCH(k_hist_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)seg_off,
-               (const uint32_t *)tile_base, count, tile_hist);
-    SRS_LAUNCH(k_plan, (NSEG_W, 1), (PLAN_THREADS), 0, stream, (const uint32_t *)count, cursor, plan, w.plan_stride, w.levels, w.l0_log,
-               (uint32_t)ACC_L1_LOG, (const uint32_t *)seg_off);
-    SRS_LAUNCH(k_scan_seg_g, (SEG, NSEG_W), (1024), 0, stream, tile_hist, w.tiles_g, (const uint32_t *)tile_base, (const uint32_t *)plan,
-               w.plan_stride);
-    SRS_LAUNCH(k_group_g, (w.tiles_g), (SORT_THREADS), 0, stream, (const uint16_t *)gkey, (const uint32_t *)gpay, (const uint32_t *)seg_off,
-               (const uint32_t *)tile_base, (const uint32_t *)tile_hist, gkey2, gpay2);
-    SRS_LAUNCH(k_scatter2_g, (8 * ceil_div(ceil_div(w.M, tile2_host) + NSEG_W, 8)), (SORT_THREADS), 0, stream, (const uint16_t *)gkey2,
-               (const uint32_t *)gpay2, (const uint32_t *)seg_off, (const uint32_t *)tile_base2, cursor, sorted);
-    // threads by chain length, then the accumulation into the persistent buckets
-    SRS_LAUNCH(k_wcc_classes, (NSEG_W * NBUCKET / 1024), (1024), 0, stream, (const uint32_t *)plan, w.plan_stride, bins);
-    SRS_LAUNCH(k_wcc_perm, (NSEG_W * NBUCKET / 1024), (1024), 0, stream, (const uint32_t *)plan, w.plan_stride, (const uint32_t *)bins, cls_cur, perm);
-    SRS_LAUNCH_TIMED("msm_accum0", n, (k_accum_wb<C>), (NSEG_W * NBUCKET / ACC_THREADS), (ACC_THREADS), 0, stream, (const uint32_t *)sorted,
-                     (const uint32_t *)plan, w.plan_stride, (const uint32_t *)perm, (const uint32_t *)bins, (const affine_t *)k.table_w, k.wb,
-                     first ? 1 : 0, rep, cap);
-    SRS_HIP_CHECK(hipMemcpyAsync(k.h_ovf + (size_t)slot * BATCH_ARGS, rep, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    k.slot_mode[slot] = false;
-    k.wcc_set[slot] = true;
-    k.slot_wide[slot] = false;
-    ++k.stat_other_sets;
-    if (!last) return true;
-    const Link *no_link = nullptr;
-    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, NSEG_W), (128), 0, stream, (const xyzz_t *)k.wb, (const xyzz_t *)k.wb, (size_t)0,
-               (const xyzz_t *)k.wb, (size_t)0, (const uint32_t *)plan, w.plan_stride, rc, no_link, 1);
-    SRS_LAUNCH((k_reduce_final<C>), (4, NSEG_W), (RED_THREADS), 0, stream, (const xyzz_t *)rc, d_seg);
-    SRS_LAUNCH((k_wide_combine<C>), (1), (256), 0, stream, (const xyzz_t *)d_seg, d_out);
-    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
-    xyzz_t *land = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
-    SRS_HIP_CHECK(hipMemcpyAsync(land, d_out, 4 * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
-    k.slot_wide[slot] = true;
-    return true;
-}
-
-// ---- chunked commit with a deferred tail --------------------------------------------------------------------------------------
-// The chunks of a streamed commit (capi.hip: commit_streamed) used to run the whole pipeline each: sort, k_accum0, then the
-// latency-bound tail -- k_accum1 levels, k_accum_final, k_bucket_fold -- ~0.25 ms per chunk on a chip that is 60 % empty.  Here the
-// chunk sets occupy the BATCH SLOTS of one workspace (set j = slot j: own digits / sorted list / plan / parts), a chunk runs only its
-// front (sort + k_accum0), and the tail runs ONCE for all sets as a batch (grid.y = sets): the same additions in launches that fill
-// the chip, then k_bucket_sum adds the sets' buckets and the usual single reduction follows.  The sort kernels of set j + 1 may be
-// issued on a second stream: they then slip into the drain of k_accum0 of set j instead of waiting behind it.
-// MEASURED SLOWER than the plain flow (one workspace reused by every chunk, everything on the caller's stream) on the k = 20 step --
-// 14.7-15.3 against 14.3 ms, profiles/r03_ab_commit_pipeline.txt: the step is bound by the sum of the kernels' work, the overlap only
-// moves it around, and six workspaces instead of one cost more than the overlap gains.  OFF by default; SRS_COMMIT_SLOTS=1 turns it on.
-// SRS_COMMIT_DEFER=1   : the accumulation levels of all chunks run once, batched, after the last chunk (measured slower: the per-chunk
-//                        levels fill gaps in which the chip waits for the next upload anyway, profiles/r03_ab_commit_pipeline.txt).
-// SRS_COMMIT_SORT_WG=n : workgroup size of the histogram / scatter kernels on the side stream (default 256).
-static uint32_t chunked_sort_threads() {
-    static const uint32_t v = [] {
-        const char *e = std::getenv("SRS_COMMIT_SORT_WG");
-        const int t = e ? std::atoi(e) : 256;
-        return (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) ? (uint32_t)t : 256u;
-    }();
-    return v;
-}
-template <class C>
-static void chunked_front_t(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t s_sort,
-                            hipStream_t s_acc, hipEvent_t sorted_ev) {
-    Chunked &S = k.chunked;
-    if (j < LANDING_SLOTS) k.slot_mode[j] = false;       // this landing slot's set is not a slot-mode set (a stale flag would read an old overflow report)
-    const uint64_t M = S.M;
-    uint16_t *dig = S.dig + (size_t)j * M;
-    uint32_t *sorted = S.sorted + (size_t)j * M;
-    uint32_t *count = S.count + (size_t)j * NBUCKET, *cursor = S.cursor + (size_t)j * NBUCKET;
-    uint32_t *plan = S.plan + (size_t)j * S.plan_stride;
-    xyzz_t *ping = S.ping + (size_t)j * S.parts0_cap;
-    uint16_t *tb = S.tb + (size_t)j * S.parts0_cap;
-    BatchDesc bd;
-    for (uint32_t m = 0; m < BATCH_ARGS; ++m) {
-        bd.ptr[m] = m == 0 ? scalars_dev : nullptr;
-        bd.n[m] = m == 0 ? n : 0;
-        bd.base[m] = m == 0 ? base : 0;
-    }
-    SRS_LAUNCH((k_digits<C>), (ceil_div(n, 256), 1), (256), 0, s_sort, bd, dig, (size_t)M, is_mont, k.compact_scalars ? 0u : k.rank,
-               k.compact_scalars ? 1u : k.world, (uint32_t *)nullptr, 0u);      // the slots' counters are cleared by chunked_begin
-    uint32_t tile = (uint32_t)(((uint64_t)n * NWIN + SORT_TARGET_BLOCKS - 1) / SORT_TARGET_BLOCKS);
-    tile = (tile + 1023u) & ~1023u;
-    if (tile < SORT_TILE_MIN) tile = SORT_TILE_MIN;
-    const uint32_t tiles = ceil_div(n, tile);
-    // On a side stream the sort workgroups are SMALL (one wavefront per SIMD, < 56 VGPRs, the LDS k_accum0 does not use): they fit next to
-    // the three 150-VGPR waves k_accum0 keeps on every SIMD and run under the previous chunk's accumulation instead of after it.
-    const uint32_t sort_threads = s_sort != s_acc ? chunked_sort_threads() : SORT_THREADS;
-    SRS_LAUNCH(k_hist, (tiles, NWIN, 1), (sort_threads), 0, s_sort, (const uint16_t *)dig, (size_t)M, bd, count, tile, (uint32_t *)nullptr);
-    SRS_LAUNCH(k_plan, (1, S.levels + 1), (PLAN_THREADS), 0, s_sort, (const uint32_t *)count, cursor, plan, S.plan_stride, S.levels, S.l0_log,
-               (uint32_t)ACC_L1_LOG, (const uint32_t *)nullptr);
-    SRS_LAUNCH(k_scatter, (tiles, NWIN, 1), (sort_threads), 0, s_sort, (const uint16_t *)dig, (size_t)M, bd, cursor, sorted, (size_t)M,
-               (uint32_t)k.len, tile);
-    const Link *no_link = nullptr;
-    SRS_LAUNCH(k_expand, (NBUCKET / 4, 1), (256), 0, s_sort, (const uint32_t *)plan, S.plan_stride, tb, (size_t)S.parts0_cap, no_link, 1u);
-    if (s_sort != s_acc) {
-        SRS_HIP_CHECK(hipEventRecord(sorted_ev, s_sort));
-        SRS_HIP_CHECK(hipStreamWaitEvent(s_acc, sorted_ev, 0));
-    }
-    {
-        prof::Scope ps("msm_accum0", s_acc, n);
-        const uint64_t cap = ((uint64_t)n * NWIN >> S.l0_log) + NBUCKET + 1;          // this set's parts, not the slot's capacity
-        SRS_LAUNCH((k_accum0<C>), (ceil_div(cap, ACC_THREADS), 1), (ACC_THREADS), 0, s_acc, (const uint32_t *)sorted, (size_t)M,
-                   (const uint32_t *)plan, S.plan_stride, (const uint16_t *)tb, (size_t)S.parts0_cap, (const affine_t *)k.table, ping,
-                   (size_t)S.parts0_cap, 1u << S.l0_log, no_link);
-    }
-    if (!S.defer_tail) {             // this set's accumulation levels now (they fill the gaps in which the chip waits for the next upload)
-        xyzz_t *pong = S.pong + (size_t)j * S.parts1_cap, *buckets = S.buckets + (size_t)j * NBUCKET;
-        xyzz_t *cur = ping, *nxt = pong;
-        size_t cur_stride = S.parts0_cap, nxt_stride = S.parts1_cap;
-        uint64_t cap = ((uint64_t)n * NWIN >> S.l0_log) + NBUCKET + 1;
-        for (int level = 1; level < S.levels; ++level) {
-            cap = cap / ACC_L1 + NBUCKET + 1;
-            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS), 1), (ACC_THREADS), 0,
-                       s_acc, (const xyzz_t *)cur, cur_stride, (const uint32_t *)plan, S.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
-                       acc1_quad_max(), acc1_tree_max());
-            std::swap(cur, nxt);
-            std::swap(cur_stride, nxt_stride);
-        }
-        SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), 1), (FINAL_THREADS), 0, s_acc, (const xyzz_t *)ping, (size_t)S.parts0_cap,
-                   (const xyzz_t *)pong, (size_t)S.parts1_cap, (const uint32_t *)plan, S.plan_stride, buckets, no_link);
-        if (!k.fold_buckets) SRS_HIP_CHECK(hipMalloc((void **)&k.fold_buckets, (size_t)NBUCKET * sizeof(xyzz_t)));
-        SRS_LAUNCH((k_bucket_fold<C>), (NBUCKET / 64), (64), 0, s_acc, (const xyzz_t *)buckets, (const xyzz_t *)ping, (const xyzz_t *)pong,
-                   (const uint32_t *)plan, S.plan_stride, k.fold_buckets, j == 0 ? 1 : 0);
-    }
-}
-
-template <class C>
-static void chunked_tail_t(Key &k, hipStream_t stream, uint32_t slot) {
-    Chunked &S = k.chunked;
-    const uint32_t sets = S.sets;
-    const Link *no_link = nullptr;
-    k.slot_mode[slot] = false;
-    if (S.defer_tail) {
-        xyzz_t *cur = S.ping, *nxt = S.pong;
-        size_t cur_stride = S.parts0_cap, nxt_stride = S.parts1_cap;
-        uint64_t cap = S.parts0_cap;
-        for (int level = 1; level < S.levels; ++level) {
-            cap = cap / ACC_L1 + NBUCKET + 1;
-            SRS_LAUNCH((k_accum1<C>), (ceil_div(std::max<uint64_t>(cap, 4 * std::min<uint64_t>(cap, std::max(acc1_quad_max(), acc1_tree_max()))), ACC_THREADS), sets), (ACC_THREADS), 0,
-                       stream, (const xyzz_t *)cur, cur_stride, (const uint32_t *)S.plan, S.plan_stride, level, nxt, nxt_stride, (uint32_t)ACC_L1, no_link,
-                       acc1_quad_max(), acc1_tree_max());
-            std::swap(cur, nxt);
-            std::swap(cur_stride, nxt_stride);
-        }
-        SRS_LAUNCH((k_accum_final<C>), (NBUCKET / (FINAL_THREADS / 64), sets), (FINAL_THREADS), 0, stream, (const xyzz_t *)S.ping, (size_t)S.parts0_cap,
-                   (const xyzz_t *)S.pong, (size_t)S.parts1_cap, (const uint32_t *)S.plan, S.plan_stride, S.buckets, no_link);
-        if (!k.fold_buckets) SRS_HIP_CHECK(hipMalloc((void **)&k.fold_buckets, (size_t)NBUCKET * sizeof(xyzz_t)));
-        SRS_LAUNCH((k_bucket_sum<C>), (NBUCKET * 4 / 256), (256), 0, stream, (const xyzz_t *)S.buckets, (const xyzz_t *)S.ping, (size_t)S.parts0_cap,
-                   (const xyzz_t *)S.pong, (size_t)S.parts1_cap, (const uint32_t *)S.plan, S.plan_stride, sets, k.fold_buckets);
-    }
-    SRS_LAUNCH((k_rowcol<C>), (RED_ROWS / 2 + RED_COLS, 1), (128), 0, stream, (const xyzz_t *)k.fold_buckets, (const xyzz_t *)S.ping,
-               (size_t)S.parts0_cap, (const xyzz_t *)S.pong, (size_t)S.parts1_cap, (const uint32_t *)S.plan, S.plan_stride, S.rc, no_link, 1);
-    SRS_LAUNCH((k_reduce_final<C>), (3, 1), (RED_THREADS), 0, stream, (const xyzz_t *)S.rc, S.d_out);
-    if (!k.h_result) SRS_HIP_CHECK(hipHostMalloc(&k.h_result, 3 * (size_t)BATCH_ARGS * LANDING_SLOTS * sizeof(xyzz_t)));
-    xyzz_t *land = static_cast<xyzz_t *>(k.h_result) + 3 * (size_t)BATCH_ARGS * slot;
-    SRS_HIP_CHECK(hipMemcpyAsync(land, S.d_out, 3 * sizeof(xyzz_t), hipMemcpyDeviceToHost, stream));
-    k.slot_wide[slot] = false;
-}
-
-bool chunked_supported(const Key &k, uint32_t n_max, uint32_t sets) {
-    static const bool on = [] { const char *e = std::getenv("SRS_COMMIT_SLOTS"); return e && e[0] == '1'; }();
-    return on && sets >= 2 && sets <= BATCH_ARGS && !use_wide(k, n_max, 1) && !use_two_pass((uint64_t)n_max * NWIN, 1);
-}
-
-void chunked_begin(Key &k, uint32_t n_max, uint32_t sets, hipStream_t stream) {
-    Chunked &S = k.chunked;
-    static const bool defer = [] { const char *e = std::getenv("SRS_COMMIT_DEFER"); return e && e[0] == '1'; }();
-    S.defer_tail = defer;
-    S.sets = sets;
-    S.M = (uint64_t)n_max * NWIN;
-    S.levels = levels_for(S.M);
-    S.l0_log = l0_log_for(S.M);
-    S.plan_stride = (size_t)(S.levels + 1) * (NBUCKET + 1) + 4;
-    S.parts0_cap = (S.M >> S.l0_log) + NBUCKET + 1;
-    S.parts1_cap = S.parts0_cap / ACC_L1 + NBUCKET + 1;
-    Arena &A = k.arena;
-    size_t per = 0;
-    per += Arena::pad(S.M * sizeof(uint16_t)) + Arena::pad(S.M * sizeof(uint32_t));
-    per += 2 * Arena::pad(NBUCKET * sizeof(uint32_t)) + Arena::pad(S.plan_stride * sizeof(uint32_t));
-    per += Arena::pad(S.parts0_cap * sizeof(xyzz_t)) + Arena::pad(S.parts0_cap * sizeof(uint16_t)) + Arena::pad(S.parts1_cap * sizeof(xyzz_t));
-    per += Arena::pad((size_t)NBUCKET * sizeof(xyzz_t));
-    A.reserve(per * sets + Arena::pad((RED_ROWS + RED_COLS) * sizeof(xyzz_t)) + Arena::pad(3 * sizeof(xyzz_t)) + 16 * 4096);
-    A.reset();
-    S.d_out = A.take<xyzz_t>(3);
-    S.dig = A.take<uint16_t>(S.M * sets);
-    S.sorted = A.take<uint32_t>(S.M * sets);
-    S.count = A.take<uint32_t>((size_t)NBUCKET * sets);
-    S.cursor = A.take<uint32_t>((size_t)NBUCKET * sets);
-    S.plan = A.take<uint32_t>(S.plan_stride * sets);
-    S.ping = A.take<xyzz_t>(S.parts0_cap * sets);
-    S.tb = A.take<uint16_t>(S.parts0_cap * sets);
-    S.pong = A.take<xyzz_t>(S.parts1_cap * sets);
-    S.buckets = A.take<xyzz_t>((size_t)NBUCKET * sets);
-    S.rc = A.take<xyzz_t>(RED_ROWS + RED_COLS);
-    SRS_HIP_CHECK(hipMemsetAsync(S.count, 0, (size_t)NBUCKET * sets * sizeof(uint32_t), stream));
-}
-void chunked_front(Key &k, uint32_t j, const fe_t *scalars_dev, uint32_t n, uint32_t base, int is_mont, hipStream_t s_sort, hipStream_t s_acc,
-                   hipEvent_t sorted_ev) {
-    if (j >= k.chunked.sets || (uint64_t)n * NWIN > k.chunked.M || n == 0) {
-        set_error("internal: msm::chunked_front out of range");
-        throw DeviceError{5};
-    }
-    if (k.curve == 0) chunked_front_t<Bn256>(k, j, scalars_dev, n, base, is_mont, s_sort, s_acc, sorted_ev);
-    else chunked_front_t<Grumpkin>(k, j, scalars_dev, n, base, is_mont, s_sort, s_acc, sorted_ev);
-}
-void chunked_tail(Key &k, hipStream_t stream, uint32_t slot) {
-    if (k.curve == 0) chunked_tail_t<Bn256>(k, stream, slot); else chunked_tail_t<Grumpkin>(k, stream, slot);
 }
 
 // host end of enqueue_t, after `stream` has been synchronised:  S = RED_COLS * (2 A' + Z) + B  (10 group operations per MSM)
@@ -3041,19 +2339,9 @@ bool enqueue(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, con
     if (batch == 1 && fold == FOLD_NONE && use_wide(k, n_host[0], 1)) {      // the sets of a chunked commit stay on the 16-bit windows
         const uint32_t base = base_host ? base_host[0] : 0;
         k.slot_mode[slot] = false;
-        k.wcc_set[slot] = false;
         ++k.stat_other_sets;
         return k.curve == 0 ? enqueue_wide_t<Bn256>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot)
                             : enqueue_wide_t<Grumpkin>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot);
-    }
-    if (slot < LANDING_SLOTS) k.wcc_set[slot] = false;
-    if (batch == 1 && fold != FOLD_NONE) {                     // a set of a chunked commit: on the 20-bit windows when the key chooses so (its first set decides)
-        if (fold == FOLD_FIRST) k.wcc_active = use_wcc(k);
-        if (k.wcc_active) {
-            const uint32_t base = base_host ? base_host[0] : 0;
-            return k.curve == 0 ? enqueue_wcc_t<Bn256>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot, fold)
-                                : enqueue_wcc_t<Grumpkin>(k, scalars_dev[0], n_host[0], base, is_mont, stream, slot, fold);
-        }
     }
     uint32_t n_max = 0;
     for (uint32_t m = 0; m < batch; ++m) n_max = std::max(n_max, n_host[m]);
@@ -3075,7 +2363,6 @@ void finish(Key &k, uint32_t batch, uint32_t slot, bool launched, xyzz_t *result
 void reserve(Key &k, uint32_t n_max, uint32_t batch) {
     size_t b = use_wide(k, n_max, batch) ? std::max(workspace_bytes_wide(n_max), workspace_bytes(n_max, batch)) : workspace_bytes(n_max, batch);
     if (batch == 1) b = std::max(b, workspace_bytes_slots(n_max, batch));        // (a chunked commit's sets: slot mode)
-    if (batch == 1 && use_wcc(k)) b = std::max(b, workspace_bytes_wcc(n_max));    // (... or the 20-bit windows)
     k.arena.reserve(b);
 }
 
@@ -3089,8 +2376,6 @@ void release(Key &k) {
     if (k.slots) (void)hipFree(k.slots);
     k.slots = nullptr;
     k.slots_pts = 0;
-    if (k.wb) (void)hipFree(k.wb);
-    k.wb = nullptr;
     if (k.used) (void)hipFree(k.used);
     k.used = nullptr;
     if (k.h_ovf) (void)hipHostFree(k.h_ovf);
@@ -3115,7 +2400,9 @@ void run(Key &k, const fe_t *const *scalars_dev, const uint32_t *n_host, uint32_
                 SRS_HIP_CHECK(hipStreamSynchronize(stream));
                 SRS_HIP_CHECK(hipGetLastError());
             }
-            note_commit(k, &sl, 1);
+            uint64_t total = 0;
+            for (uint32_t m = 0; m < b; ++m) total += n_host[at + m];
+            note_commit(k, &sl, 1, total);
         }
         finish(k, b, 0, launched, result_host + at);
         prof::collect();

@@ -162,86 +162,6 @@ struct PassArgs {
     uint32_t radix_bits[4];   // widths of digit 1..p (digit 1 = most significant input bits)
 };
 
-// non-final pass: tile = (hi, 16 consecutive `rest`), in place, times inter-digit twiddle T
-template <uint32_t RBITS>
-__global__ void SRS_KERNEL_BOUNDS(1024, 1)
-    k_ntt_pass(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg,
-               const fe_t *__restrict__ T, Scale3 pre) {
-    __shared__ fe_t tile[(1u << RBITS) * COLS];
-    __shared__ fe_t W[1u << (RBITS - 1)];
-    const uint32_t rows = 1u << RBITS;
-    const uint32_t tiles_per_hi = 1u << (pa.lbits - COLS_LOG);    // lbits >= 4 >= COLS_LOG
-    const size_t hi = blockIdx.x / tiles_per_hi;
-    const uint32_t rest0 = (blockIdx.x % tiles_per_hi) * COLS;
-    const size_t base = (hi << (RBITS + pa.lbits)) + rest0;
-    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
-        uint32_t d = e / COLS, c = e % COLS;
-        size_t idx = base + ((size_t)d << pa.lbits) + c;
-        fe_t x = src[idx];
-        if (pre.on) x = apply_scale3(pre, x, idx);
-        tile[bitrev(d, RBITS) * COLS + c] = x;
-    }
-    for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
-    __syncthreads();
-    lds_stages<COLS>(tile, W, RBITS);
-    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
-        uint32_t kd = e / COLS, c = e % COLS;
-        size_t tidx = ((size_t)kd << pa.lbits) + rest0 + c;      // T[k_j][rest]
-        fe_t x = Fr::mul(tile[e], T[tidx]);
-        dst[base + ((size_t)kd << pa.lbits) + c] = x;
-    }
-}
-
-// final pass: tile = 16 consecutive k1 (most significant memory digit) x one contiguous run;
-// output index = digit reversal  k1 + N1*(k2 + N2*(...)) + (N1..N_{p-1}) * k_p
-template <uint32_t RBITS>
-__global__ void SRS_KERNEL_BOUNDS(1024, 1)
-    k_ntt_last(const fe_t *__restrict__ src, fe_t *__restrict__ dst, PassArgs pa, const fe_t *__restrict__ Wg, Scale3 fin) {
-    __shared__ fe_t tile[(1u << RBITS) * COLS];
-    __shared__ fe_t W[1u << (RBITS - 1)];
-    const uint32_t rows = 1u << RBITS;
-    const uint32_t r1 = pa.radix_bits[0];
-    const uint32_t mid_bits = pa.log_n - r1 - RBITS;              // digits 2..p-1
-    const uint32_t mid = blockIdx.x & ((1u << mid_bits) - 1);
-    const uint32_t k1_0 = (blockIdx.x >> mid_bits) * COLS;
-    // digit-reverse `mid` (memory order: digit 2 most significant) into output order (digit 2 least)
-    uint32_t out_mid = 0;
-    {
-        uint32_t m = mid, shift_out = 0;
-        // peel digits from the least significant memory digit (p-1) down to digit 2
-        uint32_t widths[2], nd = 0;
-        for (uint32_t j = pa.npass - 1; j >= 2; --j) widths[nd++] = pa.radix_bits[j - 1];   // digit j width
-        // total output offset of digit j = sum of widths of digits 2..j-1
-        uint32_t off_of[2];
-        for (uint32_t t = 0; t < nd; ++t) {
-            uint32_t j = pa.npass - 1 - t, off = 0;
-            for (uint32_t q = 2; q < j; ++q) off += pa.radix_bits[q - 1];
-            off_of[t] = off;
-        }
-        for (uint32_t t = 0; t < nd; ++t) {
-            uint32_t dg = m & ((1u << widths[t]) - 1);
-            m >>= widths[t];
-            out_mid |= dg << off_of[t];
-        }
-        (void)shift_out;
-    }
-    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
-        uint32_t c = e / rows, i = e % rows;
-        size_t idx = ((size_t)(k1_0 + c) << (pa.log_n - r1)) + ((size_t)mid << RBITS) + i;
-        tile[bitrev(i, RBITS) * COLS + c] = src[idx];
-    }
-    for (uint32_t i = threadIdx.x; i < (rows >> 1); i += blockDim.x) W[i] = Wg[i];
-    __syncthreads();
-    lds_stages<COLS>(tile, W, RBITS);
-    for (uint32_t e = threadIdx.x; e < rows * COLS; e += blockDim.x) {
-        uint32_t kp = e / COLS, c = e % COLS;
-        size_t oidx = (size_t)(k1_0 + c) + ((size_t)out_mid << r1) + ((size_t)kp << (pa.log_n - RBITS));
-        fe_t x = tile[e];
-        if (fin.on) x = apply_scale3(fin, x, oidx);
-        dst[oidx] = x;
-    }
-}
-
 // ---- the multi-pass kernels with the TILE ITSELF in the lazy 9 x 29-bit form (r04) --------------------------------------------------------
 // r03 measured the 29-bit multiplier with canonical 8 x 32 data in LDS: every product paid an unpack of both operands and a pack +
 // canonicalisation of the result (26 + 26 + 75 instructions for the 180 it saves) -- no gain.  Here an element is unpacked ONCE when the
@@ -437,7 +357,7 @@ __global__ void SRS_KERNEL_BOUNDS(1024, 1)
             dst[oidx] = Fr29::to_canonical_fe(Fr29::reduce_lazy(lazy::get(tile, e)));
             continue;
         }
-        const uint32_t r3 = fin.on == 1 ? (uint32_t)(oidx % 3) : 0u;          // (on == 2: SRS_NTT_CLOSE_MUL=1, the r04 closing product with one, for A/B)
+        const uint32_t r3 = (uint32_t)(oidx % 3);
         const f29_t m = r3 == 1 ? z1 : (r3 == 2 ? z2 : one);
         dst[oidx] = Fr29::to_canonical_fe(Fr29::mul(lazy::get(tile, e), m));
     }
@@ -500,11 +420,7 @@ static std::mutex g_mu;
 static uint32_t g_max_radix = 8;   // tuning knob (4..8): digits per pass; never changes results
 static std::map<std::pair<uint32_t, bool>, Plan> g_plans;
 // r04: multi-pass transforms run on the lazy 9 x 29-bit tile (k_ntt_pass_lazy / k_ntt_last_lazy) -- 2^24: fft 2.33 vs 2.65 ms, ifft 2.21 vs
-// 2.47, coset_ifft 2.12 vs 2.62; 2^20: 0.167 vs 0.201 (profiles/r04_ab_ntt_lazy_tile.txt).  SRS_NTT_MUL29=0: the canonical 8 x 32 tile.
-static bool use_mul29() {
-    static const bool on = [] { const char *e = std::getenv("SRS_NTT_MUL29"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// 2.47, coset_ifft 2.12 vs 2.62; 2^20: 0.167 vs 0.201 (profiles/r04_ab_ntt_lazy_tile.txt); the canonical 8 x 32 tile kernels are gone (r06).
 
 static void fill(fe_t *T, uint32_t log_entries, uint32_t lo_bits, const fe_t &base, const fe_t &scale, hipStream_t st) {
     size_t n = (size_t)1 << log_entries;
@@ -540,7 +456,7 @@ static Plan &get_plan(uint32_t log_n, bool inverse, hipStream_t st) {
             left -= r;
             if (r < 4) { set_error("ntt: digit narrower than 4 bits (raise max radix)"); throw DeviceError{4}; }
         }
-        p.mul29 = use_mul29();
+        p.mul29 = true;
         fe_t unit = Fr::one();              // the tables' common factor: 1, or 2^5 for the 2^261-radix multiplier (lazy tile)
         if (p.mul29)
             for (int d = 0; d < 5; ++d) unit = Fr::add(unit, unit);
@@ -589,41 +505,28 @@ void release_plans() {
 // Threads per workgroup of a pass.  The kernels hold ~124 VGPRs, i.e. 4 waves per SIMD: a 1024-thread workgroup is then ALONE on its CU
 // and its load, butterfly and store phases run one after the other with nothing to overlap them.  512 threads (each thread two
 // butterfly groups per stage) let two workgroups share a CU (2 x 68 KiB of LDS) and one computes while the other moves data.
-// SRS_NTT_THREADS=<n> overrides (A/B, profiles/r03_ab_ntt_threads.txt).
-static uint32_t pass_threads(uint32_t tile_elems) {
-    static const uint32_t forced = [] { const char *e = std::getenv("SRS_NTT_THREADS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-    uint32_t t = tile_elems >= 4096 ? 1024 : (tile_elems >= 1024 ? 512 : 256);
-    if (tile_elems >= 2048) t = 512;
-    if (forced == 128 || forced == 256 || forced == 512 || forced == 1024) t = std::min(forced, tile_elems >= 1024 ? 1024u : 256u);
-    return t;
-}
+// (A/B: profiles/r03_ab_ntt_threads.txt)
+static uint32_t pass_threads(uint32_t tile_elems) { return tile_elems >= 1024 ? 512u : 256u; }
 
 template <uint32_t R>
 static void launch_pass(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &pre,
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = pass_threads((1u << R) * COLS);
-    if (p.mul29) SRS_LAUNCH((k_ntt_pass_lazy<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
-    else SRS_LAUNCH((k_ntt_pass<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
+    SRS_LAUNCH((k_ntt_pass_lazy<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], (const fe_t *)p.T[j], pre);
 }
 template <uint32_t R>
 static void launch_last(const fe_t *src, fe_t *dst, const PassArgs &pa, const Plan &p, uint32_t j, const Scale3 &fin,
                         hipStream_t st) {
     uint32_t blocks = 1u << (pa.log_n - R - COLS_LOG);
     uint32_t threads = pass_threads((1u << R) * COLS);
-    if (p.mul29) {
-        // the closing product's constants in the multiplier's radix: one = 2^261 mod p, the coset factors times 2^5
-        Scale3 f29 = fin;
-        if (fin.on) {
-            f29.z1 = Fr::mul(fin.z1, p.unit);
-            f29.z2 = Fr::mul(fin.z2, p.unit);
-        }
-        static const bool close_mul = [] { const char *e = std::getenv("SRS_NTT_CLOSE_MUL"); return e && e[0] == '1'; }();
-        if (!fin.on && close_mul) f29.on = 2;
-        SRS_LAUNCH((k_ntt_last_lazy<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], f29, p.unit);
-    } else {
-        SRS_LAUNCH((k_ntt_last<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], fin);
+    // the closing product's constants in the multiplier's radix: one = 2^261 mod p, the coset factors times 2^5
+    Scale3 f29 = fin;
+    if (fin.on) {
+        f29.z1 = Fr::mul(fin.z1, p.unit);
+        f29.z2 = Fr::mul(fin.z2, p.unit);
     }
+    SRS_LAUNCH((k_ntt_last_lazy<R>), (blocks), (threads), 0, st, src, dst, pa, (const fe_t *)p.W[j], f29, p.unit);
 }
 #define DISPATCH_R(fn, r, ...)                          \
     switch (r) {                                        \

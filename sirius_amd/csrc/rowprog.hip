@@ -21,6 +21,7 @@
 #include "ntt.h"
 #include "prof.h"
 #include "jit.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -1344,7 +1345,7 @@ static void plan_sweep(Program &p, const FieldOps &f) {
     p.sweep_ok = false;
     p.sw_terms.clear();
     p.sw_clusters.clear();
-    if (p.result_vreg < 0 || p.vins.empty() || std::getenv("SRS_NO_SWEEP")) return;
+    if (p.result_vreg < 0 || p.vins.empty()) return;
     SweepBuilder B(p);
     B.lin(p.result_vreg, -1, +1, f, 0);
     if (p.sw_terms.empty() || p.sw_terms.size() > 4096) { p.sw_terms.clear(); return; }
@@ -1383,7 +1384,7 @@ static void plan_sweep(Program &p, const FieldOps &f) {
     // coefficients (no challenge in the uniform program: the ProtoGalaxy gate polynomials) -- need no evaluation per point: their
     // clusters compute the value at the first point and the slope (the same chain with the leaf's step in place of its value)
     // once, and every further point is one lazy addition.  chain(v) = number of advice leaves of a pure product chain, -1 otherwise.
-    bool const_u = !std::getenv("SRS_SWEEP_NO_LINEAR");
+    bool const_u = true;
     for (const UOp &u : p.uops) const_u = const_u && u.op != 1;
     std::function<int(int)> chain = [&](int v) -> int {
         if (v < 0) return 0;
@@ -1409,7 +1410,7 @@ static void plan_sweep(Program &p, const FieldOps &f) {
     auto load_cost = [&](int v) { return p.vins[B.def[v]].op == I_LD_ADV ? 16 : 8; };
     // a term q * (s * y) keeps the hoisted affine factor q s and its step in registers across the point loop (emit_sweep_source):
     // 18 VGPRs, while the fixed leaf q is only needed before the loop
-    static const int hoist_regs = [] { const char *e = std::getenv("SRS_SWEEP_HOIST_COST"); return e ? std::atoi(e) : 10; }();
+    constexpr int hoist_regs = 10;
     auto hoist_cost = [&](int v) -> int {
         if (v < 0) return 0;
         const VInsn &in = p.vins[B.def[v]];
@@ -1512,7 +1513,7 @@ std::string emit_sweep_source(const Program &p, const std::string &name, bool sh
         std::vector<Hoist> hoists;
         std::map<int, size_t> hoist_of;                       // v -> index
         std::vector<char> hoisted_inner(def.size(), 0);
-        if (!cl.linear && !std::getenv("SRS_SWEEP_NO_HOIST")) {
+        if (!cl.linear) {
             std::vector<int> uses(def.size(), 0);
             for (int v : cl.body) {
                 const VInsn &in = p.vins[def[v]];
@@ -1872,15 +1873,8 @@ static bool build_program(const Ast &ast, int root, const FieldOps &f, const Ctx
     p.spec_id = -1;
     for (size_t i = 0; i < sizeof(kSpecs) / sizeof(kSpecs[0]); ++i)
         if (kSpecs[i].fingerprint == p.fingerprint && kSpecs[i].id >= 0) p.spec_id = kSpecs[i].id;
-    if (std::getenv("SRS_NO_SPEC")) p.spec_id = -1;
     plan_sweep(p, f);               // appends coefficient entries to p.uops (the fingerprint above is that of the plain program)
-    if (!p.sweep_ok) p.spec_id = -1;   // the ahead-of-time kernels ARE the sweep form (SRS_NO_SWEEP: interpreter / point-by-point)
-    if (std::getenv("SRS_DEBUG_ROWPROG")) {
-        int cnt[9] = {0};
-        for (auto &in : p.insns) cnt[in.op]++;
-        std::fprintf(stderr, "rowprog: %zu insns (ld sel/fix/adv %d/%d/%d add %d sub %d mul %d sqr %d dbl %d neg %d), %u slots, %zu uniforms\n",
-                     p.insns.size(), cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], p.nslots, p.uops.size());
-    }
+    if (!p.sweep_ok) p.spec_id = -1;   // the ahead-of-time kernels ARE the sweep form
     return true;
 }
 
@@ -2002,7 +1996,7 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
         bool same = true;
         for (size_t g = 0; g < S->gate_progs.size(); ++g) same = same && kPgSpecs[e].fp[g] == S->gate_progs[g].fingerprint;
         for (size_t g = 0; g < S->gate_progs.size(); ++g) same = same && S->gate_progs[g].sweep_ok;      // the leaf kernels use the sweep form
-        if (same && !std::getenv("SRS_NO_SPEC")) S->pg_spec_id = kPgSpecs[e].id;
+        if (same) S->pg_spec_id = kPgSpecs[e].id;
     }
     // lookup / table polynomials see the advice COLUMNS only (LookupEvalDomain, src/plonk/eval.rs:106-134)
     {
@@ -2014,15 +2008,12 @@ Structure *create(int field, uint32_t k, size_t num_selectors, size_t num_fixed,
     // ---- no ahead-of-time kernel for this gate set: compile the cross-term program now (jit.hip).  Worth it from 2^14
     //      rows on (one hiprtc compile ~ a second); single-pass degrees only (the kernel body parks d + 1 <= 9 points).
     if (S->cross.spec_id < 0 && S->degree >= 1 && S->degree <= DMAX && !S->cross.insns.empty() && jit::enabled() &&
-        (k >= 14 || std::getenv("SRS_JIT_ALWAYS"))) {
-        const bool shared = std::getenv("SRS_JIT_INLINE_MUL") == nullptr;
+        (k >= 14 || tuning::get_or(tuning::JIT_ALWAYS, 0) != 0)) {
+        const bool shared = true;
         const std::string src = jit_translation_unit(emit_spec_source(S->cross, "jit_fn", shared) + emit_sweep_source(S->cross, "jit_fn_sweep", shared),
                                                      field, S->cross.sweep_ok);
         std::string log;
-        if (!jit::compile(src, "srs_jit_rowprog", S->cross.jit, log) && std::getenv("SRS_DEBUG_ROWPROG"))
-            std::fprintf(stderr, "rowprog: hiprtc compile failed, staying on the interpreter:\n%s\n", log.c_str());
-        else if (std::getenv("SRS_DEBUG_ROWPROG"))
-            std::fprintf(stderr, "rowprog: cross-term program compiled at run time in %.2f s\n", S->cross.jit.compile_seconds);
+        (void)jit::compile(src, "srs_jit_rowprog", S->cross.jit, log);      // on failure the structure stays on the interpreter (srs_structure_jit_info reports which)
     }
     // ---- device residency: programs, fixed columns, selectors
     rc = 5;
@@ -2346,11 +2337,6 @@ static void launch_pg_leaves(const PgArgs &A, uint32_t tiles, uint32_t gates, ui
 // mode 0: compute_F, 1: compute_G, 2: evaluate_e.  W_dev: J device witness pointers (J = 1 for F / e).
 // challenges_host: J arrays of n_ch challenges.  weights_in: betas (F, e) / betas_stroke (G), betas_count values.
 // out_host: points_F / points_G coefficients (after ifft) or the single value e.
-// SRS_PG_NO_HOIST=1: the reference's leaf rows evaluated per thread again (r03), for A/B and the equality test
-static bool pg_hoist_on() {
-    static const bool on = [] { const char *e = std::getenv("SRS_PG_NO_HOIST"); return !(e && e[0] == '1'); }();
-    return on;
-}
 
 int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
            const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
@@ -2367,7 +2353,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     // next_pow2(d_G + 1) roots of unity (2 multiplies per advice load to fold the witness, then an ifft) G is evaluated at
     // the integers 0..d_G (fold = halvings + additions, d_G + 1 points) and interpolated with the constant inverse
     // Vandermonde matrix: the same polynomial, hence the same coefficients (exact arithmetic), ~35 % less work.
-    const bool g_int = mode == 1 && J == 2 && !std::getenv("SRS_PG_G_FFT");
+    const bool g_int = mode == 1 && J == 2 && tuning::get_or(tuning::PG_G_FFT, 0) == 0;      // (tuning pg_g_fft: the L >= 2 route on L = 1, for the equality test)
     const uint32_t dG = (uint32_t)S->max_gate_degree;
     // ... and one of the d_G + 1 values is free for a caller that has F: at X = 1 the fold IS the accumulator (L_0(1) = 1), the
     // weights are betas_stroke = beta + alpha delta^(2^b), so G(1) = sum_i pow_i(betas_stroke) f_i(acc) = F(alpha) -- an
@@ -2376,7 +2362,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     // nodes are 1 .. d_G + 1.  Needs the sweep-form leaf kernel (below); otherwise all d_G + 1 points are evaluated.
     const uint32_t lpt_probe = S->k >= 10 ? 8u : 1u;
     const bool skip_one = g_int && g_at_one != nullptr && dG >= 2 && S->pg_spec_id >= 0 && lpt_probe == 8 && dG + 1 <= DMAX + 1 &&
-                          !std::getenv("SRS_NO_SWEEP") && !std::getenv("SRS_PG_G_ALL_POINTS");
+                          true;
     const uint32_t pt0 = skip_one ? 2u : 0u;
     const uint32_t P = g_int ? (skip_one ? dG : dG + 1) : P_out;   // evaluation points actually used
     const uint32_t leaf_pts = mode == 1 ? P : 1u;
@@ -2422,7 +2408,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     const uint32_t lpt = S->k >= 10 ? 8u : 1u;
     const uint32_t tile_log = lpt == 8 ? 10u : std::min<uint32_t>(7, S->k);
     // the specialised leaf kernel in sweep form (k_pg_leaves_sweep): integer-point G and evaluate_e of a known gate set
-    const bool sweep_leaves = S->pg_spec_id >= 0 && lpt == 8 && mode != 0 && (mode != 1 || g_int) && P <= DMAX + 1 && !std::getenv("SRS_NO_SWEEP");
+    const bool sweep_leaves = S->pg_spec_id >= 0 && lpt == 8 && mode != 0 && (mode != 1 || g_int) && P <= DMAX + 1;
     // ---- uniform tables per gate / leaf point
     uint32_t max_slots = 1;
     std::vector<GateProg> gp(n_gates);
@@ -2461,8 +2447,8 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     const size_t n_tiles_valid = (size_t)n_gates * tiles_per_gate;
     const size_t n_tiles_padded = sz.count_with_padding >> tile_log;
     // ---- compute_F with >= 1024 rows per gate: polynomial tree (see k_pg_F_leaves); the evaluate-and-interpolate route
-    //      below stays for small tables and as the cross-check (SRS_PG_F_EVAL=1)
-    if (mode == 0 && lpt == 8 && !std::getenv("SRS_PG_F_EVAL")) {
+    //      below stays for small tables and as the cross-check (tuning pg_f_eval = 1)
+    if (mode == 0 && lpt == 8 && tuning::get_or(tuning::PG_F_EVAL, 0) == 0) {
         const uint32_t TL = tile_log - 3, T = tile;
         const size_t n0 = n_tiles_padded * T;
         Arena &A = S->arena;
@@ -2517,7 +2503,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
                 else if (max_slots <= 16) SRS_LAUNCH((k_pg_F_leaves<Fr, 16, -1>), (tiles, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
                 else SRS_LAUNCH((k_pg_F_leaves<Fr, 32, -1>), (tiles, n_gates), (T), 0, st, a, lv, cur, (uint32_t)n0);
             };
-            if (compat && pg_hoist_on()) {                 // the gates at row 0 once, then the leaf pass reads them
+            if (compat) {                                  // the gates at row 0 once, then the leaf pass reads them
                 a.hoist_mode = 1;
                 leaves(1);
                 a.hoist_mode = 2;
@@ -2531,10 +2517,9 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         size_t n_in = n0, m_valid = n_tiles_valid * T;
         uint32_t deg = 3;
         size_t at = 0;
-        static const bool f_multi = [] { const char *e = std::getenv("SRS_PG_F_MULTI"); return !(e && e[0] == '0'); }();
         // (dynamic LDS of a launch stays below 48 KiB: degree <= 23 after the launch -- every table size an NTT of <= 2^28 allows; beyond, the r03 flow)
-        while (f_multi && at < order.size() && deg + std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at) <= 23) {
-            // up to six levels per launch (k_pg_F_multi); SRS_PG_F_MULTI=0: one launch per level + the one-workgroup tail (r03 flow, A/B)
+        while (at < order.size() && deg + std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at) <= 23) {
+            // up to six levels per launch (k_pg_F_multi); what is left beyond degree 23: one launch per level + the one-workgroup tail
             const uint32_t nlev = (uint32_t)std::min<size_t>(PG_F_MULTI_LEVELS, order.size() - at);
             PgFMulti tm;
             for (uint32_t l = 0; l < PG_F_MULTI_LEVELS; ++l) {
@@ -2554,7 +2539,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         for (; at < order.size(); ++at) {
             // the last levels (<= 32 nodes left) run in one workgroup (k_pg_F_tail)
             const size_t left = order.size() - at;
-            if (n_in <= 32 && left <= PG_F_TAIL_LEVELS && deg + left <= PG_F_TAIL_MAXDEG && !std::getenv("SRS_PG_F_NO_TAIL")) break;
+            if (n_in <= 32 && left <= PG_F_TAIL_LEVELS && deg + left <= PG_F_TAIL_MAXDEG) break;
             const uint32_t b = order[at];
             const size_t n_out = n_in / 2;
             SRS_LAUNCH((k_pg_F_level<Fr>), ((uint32_t)((n_out * (deg + 2) + 127) / 128)), (128), 0, st, (const fe_t *)cur, (uint32_t)n_in,
@@ -2636,7 +2621,7 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         a.hoist = d_hoist;
         a.hoist_mode = 0;
         if (S->pg_spec_id >= 0 && lpt == 8) {
-            if (sweep_leaves && compat && pg_hoist_on()) {     // k_pg_leaves_sweep<.., COMPAT>: the gates at row 0 once, then the leaf pass
+            if (sweep_leaves && compat) {     // k_pg_leaves_sweep<.., COMPAT>: the gates at row 0 once, then the leaf pass
                 a.hoist_mode = 1;
                 launch_pg_spec(S->pg_spec_id, a, P, n_gates, tile, st, sweep_leaves);      // one workgroup per (point, gate)
                 a.hoist_mode = 2;
@@ -2652,11 +2637,10 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
     size_t m_valid = n_tiles_valid, m = n_tiles_padded;
     uint32_t level0 = tile_log;
     fe_t *cur = buf0, *nxt = buf1;
-    static const bool reduce_par = [] { const char *e = std::getenv("SRS_PG_REDUCE_PAR"); return !(e && e[0] == '0'); }();
     while (m > 1) {
         uint32_t lv = std::min<uint32_t>(7, ilog2(m));
         uint32_t outs = (uint32_t)(m >> lv);
-        if (reduce_par && ((size_t)P << lv) <= PG_REDUCE_PAR_THREADS && (((size_t)P << lv) % 64 == 0 || outs == 1))
+        if (((size_t)P << lv) <= PG_REDUCE_PAR_THREADS && (((size_t)P << lv) % 64 == 0 || outs == 1))
             SRS_LAUNCH((k_pg_reduce_par<Fr>), (outs), (1u << lv, P), 0, st, (const fe_t *)cur, (uint32_t)m_valid, P, (const fe_t *)d_w, wpts,
                        level0, lv, nxt);
         else

@@ -16,6 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+def tune_env(**tunables):
+    """Environment of a test subprocess whose library gets the given tunables (srs_tuning_set via the mirror's SRS_TEST_TUNING hook) plus
+    any UPPER-CASE extra variables, e.g. tune_env(msm_sort=2, commit_chunks=3, N="100")."""
+    extra = {k: str(v) for k, v in tunables.items() if k.isupper()}
+    spec = ",".join(f"{k}={int(v)}" for k, v in tunables.items() if not k.isupper())
+    return dict(os.environ, SRS_TEST_TUNING=spec, **extra)
+
+
 def golden(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)

@@ -331,7 +331,7 @@ inline T atomicCAS(T *p, T cmp, T v) {
 typedef int hipError_t;
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorPeerAccessAlreadyEnabled = 704 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline const char *hipGetErrorString(hipError_t) { return "hipemu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -365,6 +365,7 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = null
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind,
                                    hipStream_t = nullptr) {
     for (size_t r = 0; r < height; ++r) std::memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);

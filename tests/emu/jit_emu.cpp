@@ -13,11 +13,14 @@
 #include <string>
 
 #include "jit.h"
+#include "tuning.h"
 
 namespace srs {
 namespace jit {
 
-bool enabled() { return std::getenv("SRS_EMU_JIT") != nullptr && std::getenv("SRS_NO_JIT") == nullptr; }
+bool enabled() {
+    return std::getenv("SRS_EMU_JIT") != nullptr && tuning::get_or(tuning::NO_JIT, std::getenv("SRS_NO_JIT") != nullptr ? 1 : 0) == 0;
+}
 
 static bool build(const std::string &source, const std::string &out_so, bool syntax_only, double &seconds, std::string &log) {
     static std::atomic<int> seq{0};

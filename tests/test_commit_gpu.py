@@ -317,7 +317,7 @@ def test_commit_config_k22_vs_oracle(srs, oracle):
 
 def test_two_pass_scatter_matches_single_pass(srs, oracle):
     """The MSD two-pass scatter (k_group + k_scatter2, used from 2^23 digit slots on) against the single-pass one and the
-    oracle on sizes the oracle can do: forced through SRS_MSM_SORT (read once per process -> subprocesses)."""
+    oracle on sizes the oracle can do: forced through the tunable msm_sort (a subprocess per mode)."""
     import os
     import subprocess
     import sys
@@ -337,12 +337,10 @@ def test_two_pass_scatter_matches_single_pass(srs, oracle):
         "bases = O.make_bases(0, 4, len(vd)); ck = S.CommitmentKey(0, bases)\n"
         "assert np.array_equal(ck.commit(vd), O.msm(0, vd, bases))\n"
         "print('ok')\n")
-    from conftest import ROOT
-    # "2" + SRS_MSM_SORTV=2: sort v2 (r05: digits recomputed, per-segment first pass, bucket counts from the grouped array; off by default)
-    for mode, extra in (("1", {}), ("2", {}), ("2", {"SRS_MSM_SORTV": "2"})):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_SORT=mode, **extra), capture_output=True,
-                           text=True, timeout=600)
-        assert r.returncode == 0 and "ok" in r.stdout, (mode, extra, r.stdout[-500:], r.stderr[-1500:])
+    from conftest import ROOT, tune_env
+    for mode in (1, 2):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=tune_env(msm_sort=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
 
 
 @pytest.mark.parametrize("cid", [0, 1])
@@ -353,7 +351,7 @@ def test_commit_upload_chunked(srs, oracle, cid):
     import os
     import subprocess
     import sys
-    from conftest import ROOT
+    from conftest import ROOT, tune_env
     code = (
         "import sys, numpy as np, torch; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
         "import oracle as O, sirius_amd as S\n"
@@ -374,7 +372,7 @@ def test_commit_upload_chunked(srs, oracle, cid):
         "    ck.close(); hb.close()\n"
         "print('ok')\n")
     for chunks in ("1", "2", "3", "7", "16"):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS=chunks), capture_output=True,
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=tune_env(commit_chunks=chunks), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])
 
@@ -477,7 +475,7 @@ def test_multi_device_key_in_a_prove(srs, oracle):
 
 def test_long_level0_parts_match_oracle(srs, oracle):
     """Large MSMs give every level-0 thread up to 128 gathered additions (msm.hip l0_log_for); forced here through
-    SRS_MSM_L0 on sizes the oracle can do (read once per process -> subprocesses), skewed and uniform scalars."""
+    the tunable msm_l0 on sizes the oracle can do (a subprocess per value), skewed and uniform scalars."""
     import os
     import subprocess
     import sys
@@ -490,9 +488,9 @@ def test_long_level0_parts_match_oracle(srs, oracle):
         "    vs = [seeded_scalars(O, cid, n, 9 + j, kind) for j in range(2)]\n"
         "    for g, v in zip(ck.commit_batch(vs), vs): assert np.array_equal(g, O.msm(cid, v, bases))\n"
         "print('ok')\n")
-    from conftest import ROOT
-    for l0 in ("5", "7"):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0=l0), capture_output=True,
+    from conftest import ROOT, tune_env
+    for l0 in (5, 7):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=tune_env(msm_l0=l0), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (l0, r.stdout[-500:], r.stderr[-1500:])
 
@@ -506,7 +504,7 @@ WIDE_CODE = (
     "    bases = O.make_bases(cid, 4, n); ck = S.CommitmentKey(cid, bases)\n"
     "    for j in range(2):\n"
     "        v = seeded_scalars(O, cid, n, 9 + j, kind); assert np.array_equal(ck.commit(v), O.msm(cid, v, bases)), (cid, n, kind)\n"
-    "    if n > 1000: assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases))     # SRS_COMMIT_CHUNKS=3: chunks slide the base offset\n"
+    "    if n > 1000: assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases))     # commit_chunks = 3: chunks slide the base offset\n"
     "for cid in (0, 1):\n"
     "    q = P.CURVES[cid].q\n"
     "    vals = [0, 1, 2, q - 1, q - 2, 1 << 19, (1 << 19) + 1, (1 << 19) - 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 1 << 253, (1 << 240) - 1,\n"
@@ -521,26 +519,26 @@ WIDE_CODE = (
 
 
 def test_wide_windows_match_oracle(srs, oracle):
-    """The 13 x 20-bit window pipeline of large MSMs (msm.hip, `wide`), forced on sizes the oracle can do (SRS_MSM_WIDE /
-    SRS_MSM_WIDE_MIN are read once per process -> subprocess): uniform and skewed scalars, both curves, digit-boundary values,
+    """The 13 x 20-bit window pipeline of large MSMs (msm.hip, `wide`), forced on sizes the oracle can do (tunables msm_wide /
+    msm_wide_min, in a subprocess): uniform and skewed scalars, both curves, digit-boundary values,
     every entry in one bucket, chunked uploads (base offsets)."""
     import os
     import subprocess
     import sys
-    from conftest import ROOT
-    r = subprocess.run([sys.executable, "-c", WIDE_CODE], cwd=ROOT, env=dict(os.environ, SRS_MSM_WIDE="1", SRS_MSM_WIDE_MIN="0", SRS_COMMIT_CHUNKS="3"),
+    from conftest import ROOT, tune_env
+    r = subprocess.run([sys.executable, "-c", WIDE_CODE], cwd=ROOT, env=tune_env(msm_wide=1, msm_wide_min=0, commit_chunks=3),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_wide_windows_equal_narrow_at_scale(srs, oracle):
-    """3 * 2^20 + 77 trace-like scalars: the wide pipeline (SRS_MSM_WIDE=1) against the 16-bit-window pipeline
-    (SRS_MSM_WIDE=0), one subprocess each -- same seeded inputs, same affine point."""
+    """3 * 2^20 + 77 trace-like scalars: the wide pipeline (msm_wide = 1) against the 16-bit-window pipeline
+    (msm_wide = 0), one subprocess each -- same seeded inputs, same affine point."""
     import os
     import subprocess
     import sys
     import torch
-    from conftest import ROOT
+    from conftest import ROOT, tune_env
     code = (
         "import sys, numpy as np, torch; sys.path.insert(0, '.')\n"
         "import sirius_amd as S\n"
@@ -552,8 +550,8 @@ def test_wide_windows_equal_narrow_at_scale(srs, oracle):
         "v[torch.rand(n, device='cuda', generator=g) < 0.2, 1:] = 0\n"
         "print('C', ck.commit(v).tobytes().hex())\n")
     outs = []
-    for wide in ("0", "1"):
-        env = dict(os.environ, SRS_MSM_WIDE=wide, SRS_MSM_WIDE_MIN="20")
+    for wide in (0, 1):
+        env = tune_env(msm_wide=wide, msm_wide_min=20)
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("C ")][-1])
@@ -659,10 +657,10 @@ def test_sharded_commit_upload_chunked(srs, oracle):
     import os
     import subprocess
     import sys
-    from conftest import ROOT
+    from conftest import ROOT, tune_env
     from test_emu_logic import SHARDED_UPLOAD_CODE
     code = "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\nimport sirius_amd as S\n" + SHARDED_UPLOAD_CODE
     for chunks in ("1", "3"):
-        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_COMMIT_CHUNKS=chunks), capture_output=True,
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=tune_env(commit_chunks=chunks), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])

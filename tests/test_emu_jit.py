@@ -23,15 +23,14 @@ def emu_jit():
     import sirius_amd as S
     from sirius_amd import _lib
     _lib.load(EMU_LIB)
-    old = {k: os.environ.get(k) for k in ("SRS_EMU_JIT", "SRS_JIT_ALWAYS")}
-    os.environ["SRS_EMU_JIT"] = "1"
-    os.environ["SRS_JIT_ALWAYS"] = "1"
-    yield S
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    old = os.environ.get("SRS_EMU_JIT")
+    os.environ["SRS_EMU_JIT"] = "1"          # tests/emu/jit_emu.cpp: compile the emitted source with g++ (the emulator's stand-in for hiprtc)
+    with S.tuning(jit_always=1):              # run-time compilation below k = 14 as well
+        yield S
+    if old is None:
+        os.environ.pop("SRS_EMU_JIT", None)
+    else:
+        os.environ["SRS_EMU_JIT"] = old
     _lib._lib = None
 
 
@@ -54,11 +53,8 @@ def _check(S, O, field, k, gates, nfix, nadv, seed, nsel=0):
     W1, W2 = rand_fe(rng, nadv * rows, 0.3), rand_fe(rng, nadv * rows)
     St = S.PlonkStructure(field, k, sels, fixed, nadv, gates)
     assert _kind(St) == -2, "expected the run-time compiled kernel"
-    os.environ["SRS_NO_JIT"] = "1"
-    try:
+    with S.tuning(no_jit=1):
         Si = S.PlonkStructure(field, k, sels, fixed, nadv, gates)
-    finally:
-        del os.environ["SRS_NO_JIT"]
     assert _kind(Si) == -1
     nch = St.num_challenges
     u1c, u1u, u2c = rand_fe(rng, nch), rand_fe(rng, 1)[0], rand_fe(rng, nch)

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, seeded_scalars
+from conftest import ROOT, seeded_scalars, tune_env
 
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libsirius_emu.so")
@@ -203,7 +203,7 @@ def test_emu_batch_invert_assigned(emu, oracle):
 
 
 def test_emu_two_pass_scatter():
-    """SRS_MSM_SORT=2 (two-pass scatter incl. the XCD-aware tile mapping; and the r05 sort v2 variant) on the emulator; the switches are read once per process."""
+    """tuning msm_sort = 2 (the two-pass scatter of large MSMs incl. the XCD-aware tile mapping) on a small MSM, on the emulator."""
     import sys
     code = (
         "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
@@ -230,18 +230,21 @@ def test_emu_two_pass_scatter():
         "    ve = O.ints_to_mont(O.SCALAR_FIELD[1], [x % q for x in vals])\n"
         "    assert np.array_equal(ck.commit(ve), O.msm(1, ve, bases[:len(vals)])), vals[-1]\n"
         "print('ok')\n")
-    # SRS_MSM_SORT=2: the two-pass flow (k_hist / k_scan_seg / k_group / k_scatter2); with SRS_MSM_SORTV=2 sort v2 (r05: k_seghist / k_scan_seg2 /
-    # k_group2 / k_count, no digit array -- measured slower and off by default, kept as the A/B variant)
-    jobs = [(tag, [sys.executable, "-c", code], dict(os.environ, SRS_MSM_SORT="2", **extra)) for tag, extra in (("two_pass", {}), ("v2", {"SRS_MSM_SORTV": "2"}))]
+    # msm_sort = 2: the two-pass flow (k_hist / k_scan_seg / k_group / k_scatter2)
+    jobs = [("two_pass", [sys.executable, "-c", code], tune_env(msm_sort=2))]
     for tag, r in _run_all(jobs, timeout=1800).items():
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stdout[-300:], r.stderr[-1500:])
 
 
-def test_emu_commit_upload_and_multi_device_key(emu, oracle, monkeypatch):
+def test_emu_commit_upload_and_multi_device_key(emu, oracle):
     """Host logic of srs_commit_upload (chunks with sliding base offsets, partial sums added on the host) and of the
     multi-device key (stripe partition of bases AND scalars, strided copies, partials per shard), on the emulator."""
     O = oracle
-    monkeypatch.setenv("SRS_COMMIT_CHUNKS", "3")          # read once per process by the library: set before the first upload
+    with emu.tuning(commit_chunks=3):
+        _commit_upload_and_multi_device_key(emu, O)
+
+
+def _commit_upload_and_multi_device_key(emu, O):
     for cid, shard_counts in ((1, (3,)),):
         bases = O.make_bases(cid, 7 + cid, 1100)
         sc = seeded_scalars(O, cid, 1097, 5, "trace")          # 1 whole stripe + a tail
@@ -405,31 +408,9 @@ def test_emu_sharded_commit_upload_chunked():
     code = ("import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\nfrom sirius_amd import _lib\n"
             f"_lib.load({EMU_LIB!r})\nimport sirius_amd as S\n" + SHARDED_UPLOAD_CODE)
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    res = _run_all([(chunks, [sys.executable, "-c", code], dict(os.environ, SRS_COMMIT_CHUNKS=chunks)) for chunks in ("1", "3")])
+    res = _run_all([(chunks, [sys.executable, "-c", code], tune_env(commit_chunks=chunks)) for chunks in ("1", "3")])
     for chunks, r in res.items():
         assert r.returncode == 0 and "ok" in r.stdout, (chunks, r.stdout[-500:], r.stderr[-1500:])
-
-
-def test_emu_commit_pipeline_variants():
-    """The measured-and-shelved pipelines of the streamed commit stay correct (msm::chunked_*, DESIGN.md 4.1): one workspace slot per
-    chunk with per-chunk accumulation levels (SRS_COMMIT_SLOTS=1), and the levels of all chunks once, batched (+ SRS_COMMIT_DEFER=1)."""
-    import sys
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
-        "from sirius_amd import _lib\n"
-        f"_lib.load({EMU_LIB!r})\n"
-        "import sirius_amd as S, oracle as O\n"
-        "from conftest import seeded_scalars\n"
-        "for cid, n, kind in ((0, 4096, 'trace'), (1, 3000, 'uniform'), (0, 2049, 'uniform')):\n"
-        "    bases = O.make_bases(cid, 4, n + 5); ck = S.CommitmentKey(cid, bases)\n"
-        "    v = seeded_scalars(O, cid, n, 19, kind)\n"
-        "    assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases[:n])), (cid, n)\n"
-        "print('ok')\n")
-    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    variants = ({"SRS_COMMIT_SLOTS": "1"}, {"SRS_COMMIT_SLOTS": "1", "SRS_COMMIT_DEFER": "1"})
-    res = _run_all([(str(extra), [sys.executable, "-c", code], dict(os.environ, SRS_COMMIT_CHUNKS="3", **extra)) for extra in variants])
-    for extra, r in res.items():
-        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_emu_chain_digest_vs_oracle():
@@ -513,7 +494,7 @@ SLOT_MODE_CODE = (
     "        sc = seeded_scalars(O, cid, n, 20 + rep, kind)\n"
     "        assert np.array_equal(ck.commit_upload(sc), O.msm(cid, sc, bases[:n])), (cid, rep, kind)\n"
     "    st = ck.msm_stats(); assert st['slot_sets'] >= 5 and st['hot_sets'] >= 2 and st['redo'] == int(os.environ['REDO']), st\n"
-    "    sc = seeded_scalars(O, cid, n, 31, 'trace'); assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases[:n]))      # a whole MSM (SRS_MSM_SLOTS=2: slot mode too)\n"
+    "    sc = seeded_scalars(O, cid, n, 31, 'trace'); assert np.array_equal(ck.commit(sc), O.msm(cid, sc, bases[:n]))      # a whole MSM (msm_slots = 2: slot mode too)\n"
     "    vs = [seeded_scalars(O, cid, m, 40 + i, k) for i, (m, k) in enumerate(((n, 'trace'), (n // 2, 'uniform'), (7, 'trace')))]\n"
     "    for g, v in zip(ck.commit_batch(vs), vs): assert np.array_equal(g, O.msm(cid, v, bases[:len(v)]))\n"
     "    for x in (1, 5):      # every scalar the same small value: ONE bucket holds everything\n"
@@ -526,49 +507,19 @@ def test_emu_slot_mode_commits():
     """msm.hip slot mode (r04): persistent per-bucket partial sums across the chunks of a streamed commit, the part length chosen on the
     device, parts beyond the slots through the level kernels into the last slot, the per-key prediction with its redo -- forced onto
     small inputs: 4, 8 and 32 slots per bucket (so that hot buckets overflow), three chunks, both sort paths, whole MSMs and batches in slot mode
-    (SRS_MSM_SLOTS=2), against the oracle; msm_stats must show the hot sets and exactly one redo per key that starts cold, none for one that
+    (tuning msm_slots = 2), against the oracle; msm_stats must show the hot sets and exactly one redo per key that starts cold, none for one that
     starts with the default prediction."""
     import sys
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
     jobs = []
-    # a new key EXPECTS hot buckets (r05): no commit runs twice; SRS_MSM_EXPECT_OVF=0 starts cold, so that the redo path stays covered
+    # a new key EXPECTS hot buckets (r05): no commit runs twice; msm_expect_ovf = 0 starts cold, so that the redo path stays covered
     for tag, slot_log, sort, n, curves, cold in (("s2", "2", "1", "5000", "0", "0"), ("s2g", "2", "2", "3000", "1", "0"), ("s3", "3", "2", "4000", "1", "0"),
                                                  ("s5", "5", "2", "4200", "0", "0"), ("s3warm", "3", "2", "3100", "0", "1")):
-        env = dict(os.environ, SRS_MSM_SLOTS="2", SRS_MSM_SLOT_LOG=slot_log, SRS_MSM_SORT=sort, SRS_COMMIT_CHUNKS="3", N=n, CURVES=curves,
-                   SRS_MSM_EXPECT_OVF=cold, REDO="1" if cold == "0" else "0")
+        env = tune_env(msm_slots=2, msm_slot_log=slot_log, msm_sort=sort, commit_chunks=3, msm_expect_ovf=cold, N=n, CURVES=curves,
+                       REDO="1" if cold == "0" else "0")
         jobs.append((tag, [sys.executable, "-c", SLOT_MODE_CODE], env))
     for tag, r in _run_all(jobs).items():
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stdout[-500:], r.stderr[-1500:])
-
-
-def test_emu_wide_chunked_commit():
-    """msm.hip's opt-in wide chunked commit (SRS_MSM_WCC; profiles/r05_ab_wide_chunked.txt: measured, not adopted): the sets of a streamed commit
-    on the 20-bit windows -- one thread per (segment, bucket) into persistent bucket sums, threads ordered by chain length; a bucket with more than
-    max(256, 4 x mean) entries in one set makes the commit run again on the standard pipeline (redo) -- against the oracle, both curves."""
-    import sys
-    code = (
-        "import os, sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
-        "from sirius_amd import _lib\n"
-        f"_lib.load({EMU_LIB!r})\n"
-        "import sirius_amd as S, oracle as O\n"
-        "from conftest import seeded_scalars\n"
-        "n = 1700\n"
-        "for cid, kinds in ((0, ('uniform', 'trace')), (1, ('uniform',))):\n"
-        "    bases = O.make_bases(cid, 7 + cid, n); ck = S.CommitmentKey(cid, bases)\n"
-        "    assert ck.has_wide_table\n"
-        "    for rep, kind in enumerate(kinds):\n"
-        "        sc = seeded_scalars(O, cid, n - 7 * rep, 20 + rep, kind)\n"
-        "        assert np.array_equal(ck.commit_upload(sc), O.msm(cid, sc, bases[:len(sc)])), (cid, rep, kind)\n"
-        "    st = ck.msm_stats(); assert st['slot_sets'] == 0 and st['redo'] == 0 and st['other_sets'] >= 2 * len(kinds), st\n"
-        "    if cid == 0:\n"
-        "        v = O.ints_to_mont(O.SCALAR_FIELD[cid], [5] * n); assert np.array_equal(ck.commit_upload(v), O.msm(cid, v, bases[:n]))      # ONE bucket holds everything\n"
-        "        st = ck.msm_stats(); assert st['redo'] == 1 and st['hot_sets'] >= 2, st\n"
-        "    ck.close()\n"
-        "print('ok')\n")
-    subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_WCC="2", SRS_MSM_WIDE="1", SRS_COMMIT_CHUNKS="3"),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_emu_long_level0_parts():
@@ -585,13 +536,13 @@ def test_emu_long_level0_parts():
         "    v = seeded_scalars(O, 1, 400, 9, kind); assert np.array_equal(ck.commit(v), O.msm(1, v, bases))\n"
         "print('ok')\n")
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0="6"), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=tune_env(msm_l0=6), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
-def test_emu_accum1_tree_mode():
-    """msm.hip k_accum1's tree mode (4 lanes per output, every lane a quarter of the parts, two exchange rounds) forced on a small MSM
-    whose heavy buckets have hundreds of 2-entry level-0 parts (repeated small / negative scalars), ragged part counts included."""
+def test_emu_accum1_lane_mode_deep_levels():
+    """msm.hip k_accum1 with one lane per output (the mode of levels too large for quads) forced on a small MSM whose heavy buckets have
+    hundreds of 2-entry level-0 parts (repeated small / negative scalars), ragged part counts included: several levels deep."""
     import sys
     code = (
         "import sys, numpy as np; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
@@ -607,7 +558,7 @@ def test_emu_accum1_tree_mode():
         "assert np.array_equal(ck.commit(v), O.msm(1, v, bases))\n"
         "print('ok')\n")
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SRS_MSM_L0="1", SRS_MSM_QUAD_MAX="1", SRS_MSM_TREE_MAX="17"),
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=tune_env(msm_l0=1, msm_quad_max=1),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
@@ -640,8 +591,7 @@ def test_emu_wide_windows():
         "assert np.array_equal(ck.commit(ve), O.msm(1, ve, bases[:1001]))\n"
         "print('ok')\n")
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    res = _run_all([(sort, [sys.executable, "-c", code], dict(os.environ, SRS_MSM_WIDE="1", SRS_MSM_WIDE_MIN="0", SRS_MSM_WIDE_SORT=sort))
-                    for sort in ("2", "1")], timeout=1800)                                  # two passes (default) / the single pass
+    res = _run_all([("wide", [sys.executable, "-c", code], tune_env(msm_wide=1, msm_wide_min=0))], timeout=1800)
     for sort, r in res.items():
         assert r.returncode == 0 and "ok" in r.stdout, (sort, r.stdout[-500:], r.stderr[-1500:])
 

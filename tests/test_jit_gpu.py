@@ -32,11 +32,8 @@ def test_jit_cross_terms(srs, oracle, field, gate_T):
     W1, W2 = rand_fe(rng, nadv * rows, 0.4), rand_fe(rng, nadv * rows)
     St = srs.PlonkStructure(field, k, [], fixed, nadv, gates)
     assert _kind(srs, St) == -2, "expected the run-time compiled kernel"
-    os.environ["SRS_NO_JIT"] = "1"
-    try:
+    with srs.tuning(no_jit=1):
         Si = srs.PlonkStructure(field, k, [], fixed, nadv, gates)
-    finally:
-        del os.environ["SRS_NO_JIT"]
     assert _kind(srs, Si) == -1
     nch = St.num_challenges
     u1c, u1u, u2c = rand_fe(rng, nch), rand_fe(rng, 1)[0], rand_fe(rng, nch)

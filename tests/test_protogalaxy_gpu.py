@@ -157,7 +157,6 @@ def test_cmp_with_direct_eval(srs, oracle):
 def test_fast_paths_equal_general_paths(srs, oracle):
     """compute_F polynomial tree == evaluate-and-interpolate, compute_G integer points == roots of unity + ifft (k = 13,
     both leaf modes): the fast paths are algebraic rewrites, the coefficient vectors must be identical."""
-    import os
     import random
     from oracle import pyref as P
     from sirius_amd import protogalaxy as PG
@@ -178,13 +177,9 @@ def test_fast_paths_equal_general_paths(srs, oracle):
     for compat in (True, False):
         fast_F = PG.compute_F(ctx, betas, delta, Ws[0], reference_compat=compat)
         fast_G = PG.compute_G(ctx, betas, Ws, reference_compat=compat)
-        os.environ["SRS_PG_F_EVAL"] = "1"
-        os.environ["SRS_PG_G_FFT"] = "1"
-        try:
+        with srs.tuning(pg_f_eval=1, pg_g_fft=1):      # the routes of small tables / of L >= 2 incoming traces, on this shape
             gen_F = PG.compute_F(ctx, betas, delta, Ws[0], reference_compat=compat)
             gen_G = PG.compute_G(ctx, betas, Ws, reference_compat=compat)
-        finally:
-            del os.environ["SRS_PG_F_EVAL"], os.environ["SRS_PG_G_FFT"]
         assert np.array_equal(fast_F, gen_F) and np.array_equal(fast_G, gen_G)
         assert fast_F[ctx.betas_count + 1:].any() == False      # degree t polynomial: higher coefficients are exactly zero
     St.close()
