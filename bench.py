@@ -1084,7 +1084,7 @@ def main():
             micro = extras_microbench(S, D, ck24) if ck24 is not None else (extras_microbench(S, D, pri.ck, log_key, 1) if D.emu else None)
             S.profile_enable(False)
             if D.rank == 0:
-                hd = extras_high_degree(S, D, args) if not D.emu else extras_high_degree(S, D, args, 4, 9, 1)
+                hd = extras_high_degree(S, D, args) if not D.emu else extras_high_degree(S, D, args, 4, 6, 1)
                 setup = extras_key_setup(S, D, ck24) if ck24 is not None else None
                 out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "survey_mixture": out.pop("survey_mixture", None),
                                     "device_resident": out.pop("device_resident", None), "pageable_witness": out.pop("pageable_witness", None),

@@ -205,6 +205,35 @@ struct Ec29 {
         o.zzz = F::mul(a.zzz, ppp);
         return o;
     }
+    // r06: the same addition WITHOUT its exceptional cases, for the inner loop of the bucket accumulation.  Identity operands and equal
+    // x coordinates (Q = +-acc) are not handled but DETECTED: `exc` is set and the caller recomputes its whole chain with madd_signed
+    // (one sticky flag per chain instead of two operand tests, a branch and the doubling path inside every addition: VERDICT r05 item 2).
+    // The value returned in an exceptional case is garbage within the limb bounds (every intermediate keeps its stated bound whatever
+    // the operands hold, so nothing overflows before the chain is redone).
+    //   Q = O   <=>  y == 0 (no point of a curve of odd order has y = 0; the table's identity is (0, 0))
+    //   acc = O <=>  zz == 0 exactly; it makes u2 = 0, p = -X1 ...: not detected by pp -- tested on its own
+    SRS_HD static xyzz29_t madd_signed_fast(const xyzz29_t &a, const aff29_t &q, bool neg, bool &exc) {
+        f29_t u2 = F::mul(a.zz, q.x);                                           // < 2P norm
+        f29_t s2 = F::mul(a.zzz, q.y);                                          // < 2P norm
+        f29_t p = F::normalize(F::template sub_lazy<10, 0>(u2, a.x));           // u2 - X1 + 10P in (P, 12P) norm
+        f29_t rpos = F::template sub_lazy<6, 0>(s2, a.y);                       //  s2 - Y1 + 6P in (P, 8P), limbs < 3 * 2^29
+        f29_t rneg = F::template neg_lazy<8, 1>(F::add_lazy(s2, a.y));          // -s2 - Y1 + 8P in (P, 8P], limbs < 3 * 2^29
+        f29_t r = F::normalize(F::select(neg, rneg, rpos));
+        f29_t pp = F::sqr(p);                                                   // 144 P^2: < 2P norm
+        f29_t rr = F::sqr(r);                                                   // 64 P^2
+        exc = exc || F::is_zero_mod(pp) || F::is_zero_exact(q.y) || F::is_zero_exact(a.zz);
+        f29_t ppp = F::mul(p, pp);                                              // 24 P^2
+        f29_t qv = F::mul(a.x, pp);                                             // 18 P^2
+        xyzz29_t o;
+        f29_t sub = F::add_lazy(ppp, F::add_lazy(qv, qv));                      // ppp + 2 qv < 6P, limbs < 3 * 2^29
+        o.x = F::normalize(F::template sub_lazy<7, 2>(rr, sub));                // (P, 9P) norm
+        f29_t t = F::normalize(F::template sub_lazy<10, 0>(qv, o.x));           // qv - X3 + 10P in (P, 12P) norm
+        f29_t yn = F::template neg_lazy<6, 0>(a.y);                             // 6P - Y1 in (P, 6P], limbs < 2^30
+        o.y = F::mul2(t, r, yn, ppp);                                           // 96 P^2 + 12 P^2: < 2P norm
+        o.zz = F::mul(a.zz, pp);
+        o.zzz = F::mul(a.zzz, ppp);
+        return o;
+    }
     // RAW table entry (8 x u32, R'-form, canonical) -> registers, no sign handling (madd_signed)
     SRS_HD static aff29_t load_raw(const affine_t &q) {
         aff29_t o;

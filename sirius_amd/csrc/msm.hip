@@ -1226,6 +1226,68 @@ __global__ void SRS_KERNEL_BOUNDS(256, 1)
     for (uint32_t t = s + lane; t < e; t += 64) out[t] = (uint16_t)b;
 }
 
+// The chain of gathered mixed additions of one level-0 part: init (nullptr: the identity) + sum of the entries src[s .. e), s < e.
+// Behind every addition travel the NEXT gathered point (its index arrived an addition ago) and the index after it (r04: with the index
+// loaded in the same round as the gather it addresses, every round parked the wave for a memory latency).
+// r06: the loop runs the addition WITHOUT its exceptional cases (Ec29::madd_signed_fast: no identity tests, no branch, no doubling
+// path in the loop body); a chain that met one -- an identity entry of a degenerate key, a partial sum that cancelled, an entry equal to
+// the running sum -- is detected by a sticky flag and recomputed from its start with the complete formulas.
+template <class C>
+__device__ __forceinline__ xyzz29_t accumulate_part(const uint32_t *__restrict__ src, uint32_t s, uint32_t e, const affine_t *__restrict__ table,
+                                                    const xyzz_t *__restrict__ init) {
+    using E29 = Ec29<C>;
+    using F = typename E29::F;
+    bool exc = false;
+    xyzz29_t acc;
+    {
+        uint32_t v = src[s];
+        uint32_t vn = s + 1 < e ? src[s + 1] : 0u;
+        affine_t p = table[v & 0x7FFFFFFFu];
+        uint32_t j = s;
+        if (init) {
+            acc = E29::unpack(*init);
+        } else {                              // a fresh part: the first entry IS the sum so far
+            affine_t pn = p;
+            uint32_t vnn = 0;
+            if (s + 1 < e) {
+                pn = table[vn & 0x7FFFFFFFu];
+                if (s + 2 < e) vnn = src[s + 2];
+            }
+            const aff29_t q = E29::load_raw(p);
+            acc.x = q.x;
+            acc.y = (v >> 31) ? F::normalize(F::template neg_lazy<1, 0>(q.y)) : q.y;      // P - y  (y != 0 unless Q = O: flagged)
+            acc.zz = E29::one();
+            acc.zzz = acc.zz;
+            exc = F::is_zero_exact(q.y);
+            v = vn;
+            vn = vnn;
+            p = pn;
+            j = s + 1;
+        }
+        for (; j < e; ++j) {
+            uint32_t vnn = 0;
+            affine_t pn = p;
+            if (j + 1 < e) {
+                pn = table[vn & 0x7FFFFFFFu];
+                if (j + 2 < e) vnn = src[j + 2];
+            }
+            acc = E29::madd_signed_fast(acc, E29::load_raw(p), (v >> 31) != 0, exc);
+            v = vn;
+            vn = vnn;
+            p = pn;
+        }
+    }
+    if (exc) {                                // rare: once more, complete
+        acc = init ? E29::unpack(*init) : E29::identity();
+#pragma unroll 1
+        for (uint32_t j = s; j < e; ++j) {
+            const uint32_t v = src[j];
+            acc = E29::madd_signed(acc, E29::load_raw(table[v & 0x7FFFFFFFu]), (v >> 31) != 0);
+        }
+    }
+    return acc;
+}
+
 template <class C>
 __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     k_accum0(const uint32_t *__restrict__ sorted, size_t sorted_stride, const uint32_t *__restrict__ plan,
@@ -1253,24 +1315,7 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     const uint32_t *src = link ? sorted : sorted + (size_t)m * sorted_stride;
     // the additions run on the 9 x 29-bit limb form (curve29.cuh); the table is stored in its Montgomery form
     using E29 = Ec29<C>;
-    xyzz29_t acc = E29::identity();
-    if (s < e) {
-        uint32_t v = src[s];
-        uint32_t vn = s + 1 < e ? src[s + 1] : 0u;
-        affine_t p = table[v & 0x7FFFFFFFu];
-        for (uint32_t j = s; j < e; ++j) {
-            uint32_t vnn = 0;             // the next point and the index after it travel behind the addition (see k_accum0s)
-            affine_t pn = p;
-            if (j + 1 < e) {
-                pn = table[vn & 0x7FFFFFFFu];
-                if (j + 2 < e) vnn = src[j + 2];
-            }
-            acc = E29::madd_signed(acc, E29::load_raw(p), (v >> 31) != 0);
-            v = vn;
-            vn = vnn;
-            p = pn;
-        }
-    }
+    const xyzz29_t acc = s < e ? accumulate_part<C>(src, s, e, table, nullptr) : E29::identity();
     parts[slot] = E29::pack(acc);                                // canonical R'-form: the later levels stay on the 29-bit multiplier
 }
 
@@ -1402,26 +1447,9 @@ __global__ void SRS_KERNEL_BOUNDS(ACC_THREADS, 1)
     using E29 = Ec29<C>;
     const bool regular = part < S - 1;
     xyzz_t *slot = regular ? slots + ((size_t)m * NBUCKET + b) * S + part : ovf + (size_t)m * ovf_stride + tpo[b] + (part - (S - 1));
-    xyzz29_t acc = E29::identity();
-    uint32_t v = src[s];                                   // a part is never empty: s < e
-    uint32_t vn = s + 1 < e ? src[s + 1] : 0u;
-    affine_t p = table[v & 0x7FFFFFFFu];
-    if (regular && !first && part < (uint32_t)used_prev[(size_t)m * NBUCKET + b]) acc = E29::unpack(*slot);
-    for (uint32_t j = s; j < e; ++j) {
-        // behind the addition: the NEXT gathered point (its index arrived an addition ago) and the index after it.  r04: with the index
-        // loaded in the same round as the gather it addresses, every round parked the wave for a memory latency (SQ_WAIT_ANY 23 %)
-        uint32_t vnn = 0;
-        affine_t pn = p;
-        if (j + 1 < e) {
-            pn = table[vn & 0x7FFFFFFFu];
-            if (j + 2 < e) vnn = src[j + 2];
-        }
-        acc = E29::madd_signed(acc, E29::load_raw(p), (v >> 31) != 0);
-        v = vn;
-        vn = vnn;
-        p = pn;
-    }
-    *slot = E29::pack(acc);
+    // a part is never empty (s < e); the slot's running sum is the start value when the slot holds one
+    const bool resume = regular && !first && part < (uint32_t)used_prev[(size_t)m * NBUCKET + b];
+    *slot = E29::pack(accumulate_part<C>(src, s, e, table, resume ? slot : nullptr));
 }
 
 // the wave-level pass of the overflow parts: one wavefront per bucket sums what the overflow levels left of it and adds the sum into the

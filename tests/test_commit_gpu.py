@@ -212,6 +212,22 @@ def _degenerate_bases_case(S, O, cid, n):
         vs.append(O.ints_to_mont(sf, vals))
     for g, v in zip(ck.commit_batch(vs), vs):
         assert np.array_equal(g, O.msm(cid, v, bases))
+    # (d) r06: the same collisions through the STREAMED commit in slot mode (three chunks): a slot's running sum that cancelled to the identity in
+    # one chunk is the start value of the next (accumulate_part's flagged chain, redone with the complete formulas), equal points meet the
+    # running sum of an earlier chunk, and an identity base sits in the key
+    bases[n // 3] = 0
+    ck2 = S.CommitmentKey(cid, bases)
+    with S.tuning(commit_chunks=3, msm_slots=2):
+        for v in vs[:2]:
+            assert np.array_equal(ck2.commit_upload(v), O.msm(cid, v, bases)), "streamed, degenerate key"
+        bases2 = np.empty((n, 8), np.uint64)
+        bases2[0::2], bases2[1::2] = pool[1], neg[1]
+        ck3 = S.CommitmentKey(cid, bases2)
+        sc = O.ints_to_mont(sf, [0x123456789ABCDEF] * n)
+        got = ck3.commit_upload(sc)
+        assert not got.any() and np.array_equal(got, O.msm(cid, sc, bases2))
+        ck3.close()
+    ck2.close()
     ck.close()
 
 

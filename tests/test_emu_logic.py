@@ -513,8 +513,8 @@ def test_emu_slot_mode_commits():
     subprocess.check_call(["make", "-C", EMU_DIR, "-j4"], stdout=subprocess.DEVNULL)
     jobs = []
     # a new key EXPECTS hot buckets (r05): no commit runs twice; msm_expect_ovf = 0 starts cold, so that the redo path stays covered
-    for tag, slot_log, sort, n, curves, cold in (("s2", "2", "1", "5000", "0", "0"), ("s2g", "2", "2", "3000", "1", "0"), ("s3", "3", "2", "4000", "1", "0"),
-                                                 ("s5", "5", "2", "4200", "0", "0"), ("s3warm", "3", "2", "3100", "0", "1")):
+    for tag, slot_log, sort, n, curves, cold in (("s2", "2", "1", "3000", "0", "0"), ("s2g", "2", "2", "2100", "1", "0"), ("s3", "3", "2", "2500", "1", "0"),
+                                                 ("s5", "5", "2", "2700", "0", "0"), ("s3warm", "3", "2", "2200", "0", "1")):
         env = tune_env(msm_slots=2, msm_slot_log=slot_log, msm_sort=sort, commit_chunks=3, msm_expect_ovf=cold, N=n, CURVES=curves,
                        REDO="1" if cold == "0" else "0")
         jobs.append((tag, [sys.executable, "-c", SLOT_MODE_CODE], env))
