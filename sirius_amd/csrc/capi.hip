@@ -2494,13 +2494,21 @@ int srs_pg_prove(srs_structure *S, srs_poseidon *ro, const srs_fe *betas, size_t
         ht.mark("alpha,betas'");
         // poly_K = compute_K(F(alpha), betas_stroke, accumulator, incoming)                               :437-443
         std::vector<fe_t> poly_G(z.points_G);
-        // G(1) = F(alpha) by definition (rowprog.hip, pg_sum): one evaluation point less for the leaf kernel
+        // G(1) = F(alpha) by definition (rowprog.hip, pg_sum): one evaluation point less for the leaf kernel.
+        // r06: with one incoming trace and a small K domain (every BASELINE config: 256 points) G's values stay on the device and K's points,
+        // the coset ifft and the copy of K follow in the same chain of launches -- one synchronisation instead of two, no host Horner
+        rowprog::PgGValues gv;
+        const bool k_on_device = n_instances == 2 && z.log_domain_K <= 12;
         erc = rowprog::pg_sum(s, 1, dW.data(), ch.data(), n_challenges, n_instances, bs.data(), bs.size(), nullptr, reference_compat, st,
-                              poly_G.data(), &n_out, err, &f_alpha);
+                              poly_G.data(), &n_out, err, &f_alpha, k_on_device ? &gv : nullptr);
         if (erc) return fail(erc, "srs_pg_prove (compute_G): " + err);
+        if (gv.vals_dev && !rowprog::pg_K_device_ok(gv, z.log_domain_K)) return fail(SRS_ERR_DEVICE, "srs_pg_prove: internal (device K on an unsupported shape)");
         ht.mark("compute_G");
-        erc = rowprog::pg_K_from_G(poly_G.data(), poly_G.size(), f_alpha, z.instances_to_fold, z.log_domain_K, st,
-                                   reinterpret_cast<fe_t *>(poly_K), err);
+        if (gv.vals_dev)
+            erc = rowprog::pg_K_from_G_device(s, gv, f_alpha, z.instances_to_fold, z.log_domain_K, st, reinterpret_cast<fe_t *>(poly_K), err);
+        else
+            erc = rowprog::pg_K_from_G(poly_G.data(), poly_G.size(), f_alpha, z.instances_to_fold, z.log_domain_K, st,
+                                       reinterpret_cast<fe_t *>(poly_K), err);
         if (erc) return fail(erc, "srs_pg_prove (compute_K_from_G): " + err);
         ht.mark("compute_K");
         const size_t n_K = (size_t)1 << z.log_domain_K;

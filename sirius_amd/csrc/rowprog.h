@@ -48,9 +48,21 @@ struct PgSizes {   // PolyContext, src/nifs/protogalaxy/poly/mod.rs:205-269
 bool pg_sizes(const Structure *S, size_t traces_len, PgSizes &out);
 std::vector<fe_t> lagrange_eval(const fe_t &X, uint32_t log_n);
 fe_t poly_eval(const fe_t *coeffs, size_t n, const fe_t &x);
+// compute_G's values left ON THE DEVICE for pg_K_from_G_device (r06): G at the integer nodes node0 .. node0 + n_vals - 1 (the first one
+// is `g_at_one`, a host value, when skip_one), valid until the structure's next pg_* call
+struct PgGValues {
+    const fe_t *vals_dev = nullptr;      // n_dev evaluated values
+    uint32_t n_dev = 0, degree = 0;      // degree = d_G: degree + 1 nodes in all
+    bool skip_one = false;               // nodes 1 .. d_G + 1, value at node 1 = F(alpha) (not in vals_dev); else nodes 0 .. d_G
+};
 int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
            const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
-           size_t *n_out, std::string &err, const fe_t *g_at_one = nullptr);
+           size_t *n_out, std::string &err, const fe_t *g_at_one = nullptr, PgGValues *keep_on_device = nullptr);
+// compute_K_from_G straight from compute_G's device values (one incoming trace, K domain <= 4096 points): interpolation, the K points and the
+// coset ifft in one chain of launches, ONE synchronisation (the host route: D2H of G, host interpolation and Horner, H2D of the points)
+bool pg_K_device_ok(const PgGValues &g, uint32_t log_domain_K);
+int pg_K_from_G_device(Structure *S, const PgGValues &g, const fe_t &f_alpha, size_t instances_to_fold, uint32_t log_domain_K, hipStream_t st,
+                       fe_t *out_host, std::string &err);
 int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t instances_to_fold, uint32_t log_domain_K,
                 hipStream_t st, fe_t *out_host, std::string &err);
 // world > 1: only the elements of rank's block-cyclic stripes (2^10 each) of out[0 .. n) are written

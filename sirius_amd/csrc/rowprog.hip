@@ -531,6 +531,31 @@ __global__ void k_pg_K_points(const fe_t *__restrict__ polyG, uint32_t nG, fe_t 
     out[i] = Fr::mul(Fr::sub(g, Fr::mul(f_alpha, l0)), Fr::inv(xn1));
 }
 
+constexpr uint32_t PG_K_SMALL_MAX_NODES = 32, PG_K_SMALL_MAX_LOG = 12;
+// r06: the same K points for a SMALL domain straight from compute_G's values at integer nodes (one incoming trace): every workgroup
+// interpolates G (coefficients c = M v, M = the constant inverse Vandermonde matrix of the nodes, v = the values, v[0] = g0 when
+// `has_g0`: G(1) = F(alpha)), then thread i evaluates G at X_i by Horner and applies the domain's precomputed L_0(X_i) and 1 / Z(X_i)
+// (tab = [xs | l0 | inv_z], count entries each).  Exact field arithmetic: the host route's values bit for bit.
+__global__ void k_pg_K_small(const fe_t *__restrict__ vals, uint32_t n_vals, fe_t g0, int has_g0, const fe_t *__restrict__ M, uint32_t n_nodes,
+                             fe_t f_alpha, const fe_t *__restrict__ tab, uint32_t count, fe_t *__restrict__ out) {
+    __shared__ fe_t c[PG_K_SMALL_MAX_NODES];
+    if (threadIdx.x < n_nodes) {
+        fe_t acc = Fr::zero();
+        for (uint32_t j = 0; j < n_nodes; ++j) {
+            const fe_t v = has_g0 ? (j == 0 ? g0 : vals[j - 1]) : vals[j];
+            acc = Fr::add(acc, Fr::mul(M[threadIdx.x * n_nodes + j], v));
+        }
+        c[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const fe_t X = tab[i];
+    fe_t g = Fr::zero();
+    for (uint32_t k = n_nodes; k-- > 0;) g = Fr::add(Fr::mul(g, X), c[k]);
+    out[i] = Fr::mul(Fr::sub(g, Fr::mul(f_alpha, tab[count + i])), tab[2 * count + i]);
+}
+
 // number of rows with a[i] != b[i] (b == nullptr: a[i] != 0): the deciders' mismatch count
 // (PlonkStructure::is_sat src/plonk/mod.rs:329-346; is_sat_accumulation src/nifs/sangria/mod.rs:352-376)
 __global__ void k_count_mismatch(const fe_t *__restrict__ a, const fe_t *__restrict__ b, size_t n, uint32_t *__restrict__ count) {
@@ -1850,6 +1875,7 @@ struct Structure {
     fe_t **d_fix_ptrs = nullptr;
     std::vector<void *> owned;
     fe_t *d_vinv = nullptr, *d_vinv29 = nullptr;
+    fe_t *d_kM[2] = {nullptr, nullptr};      // pg_K_from_G_device: the full inverse Vandermonde matrix of the nodes 0..d_G / 1..d_G+1 (made on first use)
     Arena arena;
     std::vector<uint8_t> host_stage;   // source of the per-call staging copy (must outlive the asynchronous copy)
     uint32_t shard_rank = 0, shard_world = 1;   // cross terms: evaluate only this rank's row stripes (set_shard)
@@ -2340,7 +2366,7 @@ static void launch_pg_leaves(const PgArgs &A, uint32_t tiles, uint32_t gates, ui
 
 int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *challenges_host, size_t n_ch, size_t J,
            const fe_t *weights_in, size_t n_weights, const fe_t *delta, int compat, hipStream_t st, fe_t *out_host,
-           size_t *n_out, std::string &err, const fe_t *g_at_one) {
+           size_t *n_out, std::string &err, const fe_t *g_at_one, PgGValues *keep_on_device) {
     if (S->field != 0) { err = "ProtoGalaxy polynomials need the 2-adic field bn256::Fr"; return 4; }
     if (J == 0 || J > JMAX) { err = "unsupported number of traces"; return 4; }
     PgSizes sz;
@@ -2651,6 +2677,14 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
         m_valid = outs;
         std::swap(cur, nxt);
     }
+    if (g_int && keep_on_device && dG + 1 <= PG_K_SMALL_MAX_NODES) {      // the caller goes on to K on the device (pg_K_from_G_device): no round trip through the host here
+        keep_on_device->vals_dev = cur;
+        keep_on_device->n_dev = P;
+        keep_on_device->degree = dG;
+        keep_on_device->skip_one = skip_one;
+        *n_out = 0;
+        return 0;
+    }
     if (g_int) {
         std::vector<fe_t> val(P);
         SRS_HIP_CHECK(hipMemcpyAsync(val.data(), cur, (size_t)P * sizeof(fe_t), hipMemcpyDeviceToHost, st));
@@ -2772,6 +2806,94 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
     SRS_HIP_CHECK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
     SRS_HIP_CHECK(hipStreamSynchronize(st));
     if (herr) { err = "Z(X) must be not equal to 0"; return 4; }
+    return 0;
+}
+
+// the small K domain's points X_i = zeta omega^i, L_0(X_i) and 1 / Z(X_i) on the device ([xs | l0 | inv_z]), per (domain, n, device)
+static const fe_t *k_domain_table_dev(uint32_t log_domain_K, size_t instances_to_fold, bool &zero_z) {
+    struct Tab { fe_t *dev = nullptr; bool zero_z = false; };
+    static std::mutex mu;
+    static std::map<std::tuple<int, uint32_t, size_t>, Tab> cache;
+    int device = 0;
+    SRS_HIP_CHECK(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_tuple(device, log_domain_K, instances_to_fold);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        const size_t count = (size_t)1 << log_domain_K;
+        std::vector<fe_t> h(3 * count), xn1(count), xm1(count), pref(2 * count);
+        const fe_t zeta = ntt::zeta(), omega = ntt::omega(log_domain_K, false), one = Fr::one();
+        const fe_t inv_n = Fr::inv(Fr::from_u64(instances_to_fold));
+        Tab t;
+        fe_t X = zeta, acc = one;
+        for (size_t i = 0; i < count; ++i) { h[i] = X; X = Fr::mul(X, omega); }
+        for (size_t i = 0; i < count; ++i) {
+            xn1[i] = Fr::sub(Fr::pow_u64(h[i], instances_to_fold), one);
+            xm1[i] = Fr::sub(h[i], one);
+            if (Fr::is_zero(xn1[i])) t.zero_z = true;
+        }
+        if (!t.zero_z) {                                   // one inversion for all denominators (Montgomery's trick), as the host route
+            for (size_t i = 0; i < count; ++i) {
+                pref[2 * i] = acc;
+                acc = Fr::mul(acc, xn1[i]);
+                pref[2 * i + 1] = acc;
+                acc = Fr::mul(acc, xm1[i]);
+            }
+            fe_t inv = Fr::inv(acc);
+            for (size_t i = count; i-- > 0;) {
+                const fe_t inv_xm1 = Fr::mul(inv, pref[2 * i + 1]);
+                inv = Fr::mul(inv, xm1[i]);
+                h[2 * count + i] = Fr::mul(inv, pref[2 * i]);
+                inv = Fr::mul(inv, xn1[i]);
+                h[count + i] = Fr::mul(inv_n, Fr::mul(xn1[i], inv_xm1));
+            }
+            SRS_HIP_CHECK(hipMalloc((void **)&t.dev, 3 * count * sizeof(fe_t)));        // kept for the life of the process (24 KiB per domain)
+            SRS_HIP_CHECK(hipMemcpy(t.dev, h.data(), 3 * count * sizeof(fe_t), hipMemcpyHostToDevice));
+        }
+        it = cache.emplace(key, t).first;
+    }
+    zero_z = it->second.zero_z;
+    return it->second.dev;
+}
+
+bool pg_K_device_ok(const PgGValues &g, uint32_t log_domain_K) {
+    return g.vals_dev != nullptr && g.degree + 1 <= PG_K_SMALL_MAX_NODES && log_domain_K <= PG_K_SMALL_MAX_LOG;
+}
+
+int pg_K_from_G_device(Structure *S, const PgGValues &g, const fe_t &f_alpha, size_t instances_to_fold, uint32_t log_domain_K, hipStream_t st,
+                       fe_t *out_host, std::string &err) {
+    if (!pg_K_device_ok(g, log_domain_K)) { err = "internal: pg_K_from_G_device on an unsupported shape"; return 5; }
+    const uint32_t n_nodes = g.degree + 1, count = 1u << log_domain_K;
+    bool zero_z = false;
+    const fe_t *tab = k_domain_table_dev(log_domain_K, instances_to_fold, zero_z);
+    if (zero_z) { err = "Z(X) must be not equal to 0"; return 4; }
+    fe_t *&M = S->d_kM[g.skip_one ? 1 : 0];
+    if (!M) {
+        FieldOps f{0};
+        std::vector<fe_t> full((size_t)n_nodes * n_nodes);
+        if (g.skip_one) {
+            full = !S->vinv_g1.empty() ? S->vinv_g1 : inverse_vandermonde_at(f, g.degree, 1);                   // [d + 1][d + 1], nodes 1 .. d + 1
+        } else {
+            const std::vector<fe_t> rows = !S->vinv_g.empty() ? S->vinv_g : (g.degree ? inverse_vandermonde(f, g.degree) : std::vector<fe_t>());
+            for (uint32_t j = 0; j < n_nodes; ++j) full[j] = j == 0 ? Fr::one() : Fr::zero();                       // coefficient 0 = G(0)
+            for (size_t i = 0; i < rows.size(); ++i) full[n_nodes + i] = rows[i];                                    // rows k = 1 .. d, nodes 0 .. d
+        }
+        SRS_HIP_CHECK(hipMalloc((void **)&M, full.size() * sizeof(fe_t)));
+        S->owned.push_back(M);
+        SRS_HIP_CHECK(hipMemcpy(M, full.data(), full.size() * sizeof(fe_t), hipMemcpyHostToDevice));
+    }
+    static thread_local Arena scratch;
+    scratch.reserve(Arena::pad((size_t)count * sizeof(fe_t)) + 256);
+    scratch.reset();
+    fe_t *d_out = scratch.take<fe_t>(count);
+    const uint32_t threads = std::max<uint32_t>(64u, std::min<uint32_t>(256u, count));
+    SRS_LAUNCH(k_pg_K_small, ((count + threads - 1) / threads), (threads), 0, st, g.vals_dev, g.n_dev, f_alpha, g.skip_one ? 1 : 0, (const fe_t *)M,
+               n_nodes, f_alpha, tab, count, d_out);
+    ntt::run(d_out, log_domain_K, count, 1, true, true, st);     // UnivariatePoly::coset_ifft
+    SRS_HIP_CHECK(hipMemcpyAsync(out_host, d_out, (size_t)count * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+    SRS_HIP_CHECK(hipStreamSynchronize(st));
+    SRS_HIP_CHECK(hipGetLastError());
+    prof::collect();
     return 0;
 }
 
