@@ -870,7 +870,7 @@ def extras_key_setup(S, D, ck24):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         held = free0 - torch.cuda.mem_get_info()[0]
-        out[name] = {"create_s": round(dt, 3), "hbm_bytes": int(held), "has_wide_table": bool(ck.has_wide_table)}
+        out[name] = {"create_s": round(dt, 3), "hbm_bytes": int(held), "has_wide_table": bool(ck.has_wide_table())}
         ck.close()
     out["note"] = ("srs_ck_create(2^24 bn256 bases from pageable host memory): 1 GiB upload + 15 (+ 13) windows of doublings and batched normalisations; "
                    "`narrow_only` = tuning msm_wide = 0 / environment SRS_MSM_WIDE=0 (whole MSMs of >= 2^23 scalars then stay on the 16-bit windows)")
@@ -1084,7 +1084,9 @@ def main():
             micro = extras_microbench(S, D, ck24) if ck24 is not None else (extras_microbench(S, D, pri.ck, log_key, 1) if D.emu else None)
             S.profile_enable(False)
             if D.rank == 0:
+                S.profile_enable(True)
                 hd = extras_high_degree(S, D, args) if not D.emu else extras_high_degree(S, D, args, 4, 6, 1)
+                S.profile_enable(False)
                 setup = extras_key_setup(S, D, ck24) if ck24 is not None else None
                 out["secondary"] = {"true_leaf_rows": out.pop("true_leaf_rows", None), "survey_mixture": out.pop("survey_mixture", None),
                                     "device_resident": out.pop("device_resident", None), "pageable_witness": out.pop("pageable_witness", None),

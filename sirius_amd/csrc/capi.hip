@@ -947,6 +947,16 @@ struct Seg {
     size_t off, len;
 };
 
+// true when `p` is ordinary (not page-locked, not registered) host memory
+static bool host_is_pageable(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();                    // unregistered host memory is reported as an error: that IS the pageable case
+        return true;
+    }
+    return attr.type == hipMemoryTypeUnregistered;
+}
+
 // uploads dst[a, b) = pieces + zero padding, on stream `cs`
 void upload_range(fe_t *dst, const std::vector<Seg> &segs, size_t a, size_t b, hipStream_t cs) {
     size_t at = a;
@@ -1094,11 +1104,21 @@ int commit_streamed_core(StreamRes ck_, const std::vector<Seg> &segs, size_t n, 
         const msm::Fold f = !fold ? msm::FOLD_NONE : (j == 0 ? msm::FOLD_FIRST : (j + 1 == chunks ? msm::FOLD_LAST : msm::FOLD_MIDDLE));
         launched[j] = msm::enqueue(ck->key, &ptr, &nn, &base, 1, repr == SRS_REPR_MONT, st, (uint32_t)j, f);
     };
-    // a pageable source makes hipMemcpyAsync block the caller: issue upload j+1 before MSM j so both are in flight either way
+    // Page-locked source: the uploads are asynchronous -- upload j + 1 is queued before the launches of MSM j, the copy engine never waits
+    // for the host.  PAGEABLE source (a Rust Vec<F>: the runtime stages it through its own pinned buffers and hipMemcpyAsync returns only
+    // when the chunk has been staged): the launches of MSM j go first, so that the device accumulates chunk j WHILE the host is held in
+    // the copy of chunk j + 1 (r06: with the r05 order MSM j could only be queued after upload j + 1 had returned -- the device ran one
+    // chunk behind the link, +1.3 ms on the k = 20 step, bench.py secondary.pageable_witness)
+    const bool pageable = !segs.empty() && segs[0].len && host_is_pageable(segs[0].src);
     upload(0);
     for (size_t j = 0; j < chunks; ++j) {
-        if (j + 1 < chunks) upload(j + 1);
-        launch(j);
+        if (pageable) {
+            launch(j);
+            if (j + 1 < chunks) upload(j + 1);
+        } else {
+            if (j + 1 < chunks) upload(j + 1);
+            launch(j);
+        }
     }
     ht.mark("enqueued");
     SRS_HIP_CHECK(hipStreamSynchronize(st));

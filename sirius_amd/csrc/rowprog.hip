@@ -181,13 +181,25 @@ __global__ void SRS_KERNEL_BOUNDS(RP_THREADS, 1) k_pg_leaves(PgArgs A) {
     __shared__ fe_t red[RP_THREADS];
     constexpr uint32_t LPT_LOG = LPT == 8 ? 3 : (LPT == 4 ? 2 : (LPT == 2 ? 1 : 0));
     const uint32_t gate = blockIdx.y, tile = blockIdx.x;
-    if (!pg_tile_is_mine(A, tile)) { pg_zero_partial(A, gate, tile); return; }
     const GateProg G = A.gates[gate];
+    if (A.compat && A.hoist_mode == 1) {      // r06, as the ahead-of-time kernels: the reference's leaf rows make every leaf of a gate that gate AT ROW 0 --
+        // the hoisting launch, grid = (leaf_pts, gates), evaluates it once per (gate, point); every lane computes the same value, lane 0 stores it
+        const fe_t x = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, 0u, tile, A.utab + G.utab_off + (size_t)tile * G.n_uniform);
+        if (threadIdx.x == 0) A.hoist[(size_t)gate * A.leaf_pts + tile] = x;
+        return;
+    }
+    if (!pg_tile_is_mine(A, tile)) { pg_zero_partial(A, gate, tile); return; }
     const uint32_t TL = A.tile_log - LPT_LOG;                          // log2(blockDim.x)
     const uint32_t row0 = (tile << A.tile_log) + threadIdx.x;          // < rows (rows is a multiple of the tile)
     fe_t v[LPT];
     for (uint32_t p = 0; p < A.P; ++p) {
-        if (A.leaf_pts > 1 || p == 0) {
+        if (A.compat && A.hoist_mode == 2) {                           // the leaf launch reads the hoisted values
+            if (A.leaf_pts > 1 || p == 0) {
+                const fe_t x = A.hoist[(size_t)gate * A.leaf_pts + (A.leaf_pts > 1 ? p : 0)];
+#pragma unroll
+                for (uint32_t l = 0; l < LPT; ++l) v[l] = x;
+            }
+        } else if (A.leaf_pts > 1 || p == 0) {
 #pragma unroll
             for (uint32_t l = 0; l < LPT; ++l)
                 v[l] = interp<F>(slots, G.prog, G.n_insn, G.result, A.ctx, A.compat ? 0u : row0 + (l << TL), p,
@@ -2654,10 +2666,20 @@ int pg_sum(Structure *S, int mode, const fe_t *const *W_dev, const fe_t *const *
             }
             launch_pg_spec(S->pg_spec_id, a, tiles_per_gate, n_gates, tile, st, sweep_leaves);
         }
-        else if (max_slots <= 8) launch_pg_leaves<8>(a, tiles_per_gate, n_gates, tile, lpt, st);
-        else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles_per_gate, n_gates, tile, lpt, st);
-        else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles_per_gate, n_gates, tile, lpt, st);
-        else launch_pg_leaves<32>(a, tiles_per_gate, n_gates, tile, lpt, st);
+        else {
+            auto leaves = [&](uint32_t tiles) {
+                if (max_slots <= 8) launch_pg_leaves<8>(a, tiles, n_gates, tile, lpt, st);
+                else if (max_slots <= 12) launch_pg_leaves<12>(a, tiles, n_gates, tile, lpt, st);
+                else if (max_slots <= 16) launch_pg_leaves<16>(a, tiles, n_gates, tile, lpt, st);
+                else launch_pg_leaves<32>(a, tiles, n_gates, tile, lpt, st);
+            };
+            if (compat) {                      // the interpreter too evaluates the gates at row 0 once per (gate, point), then runs the weighted trees
+                a.hoist_mode = 1;
+                leaves(leaf_pts);
+                a.hoist_mode = 2;
+            }
+            leaves(tiles_per_gate);
+        }
     }
     // ---- upper levels of the tree over the tile partials (zero padding beyond the real gates)
     size_t m_valid = n_tiles_valid, m = n_tiles_padded;
