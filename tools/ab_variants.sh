@@ -12,6 +12,6 @@ for lib in "" $R/variants/*.so; do
   SRS_AMD_LIB=$lib python bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 2 > $O/c20_$tag.json 2>/dev/null; pick $O/c20_$tag.json "k20 $tag"
 done
 for l0 in $AB_L0; do
-  SRS_MSM_L0=$l0 python bench.py --config sangria --no-cpu-baseline --steps 20 --warmup 3 > $O/s17_l0_$l0.json 2>/dev/null; pick $O/s17_l0_$l0.json "k17 L0=2^$l0"
-  SRS_MSM_L0=$l0 python bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 2 > $O/c20_l0_$l0.json 2>/dev/null; pick $O/c20_l0_$l0.json "k20 L0=2^$l0"
+  SRS_TEST_TUNING=msm_l0=$l0 python bench.py --config sangria --no-cpu-baseline --steps 20 --warmup 3 > $O/s17_l0_$l0.json 2>/dev/null; pick $O/s17_l0_$l0.json "k17 L0=2^$l0"
+  SRS_TEST_TUNING=msm_l0=$l0 python bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 2 > $O/c20_l0_$l0.json 2>/dev/null; pick $O/c20_l0_$l0.json "k20 L0=2^$l0"
 done

@@ -1,5 +1,5 @@
 """Wall time of ck.commit on device-resident scalars over a range of sizes (one key of 2^24 bases); run once per setting of the
-SRS_MSM_* switches (they are read once per process).  usage: python tools/msm_probe.py [log_key] [sizes...]"""
+tunables (SRS_TEST_TUNING="msm_sort=2,..." of the Python mirror).  usage: python tools/msm_probe.py [log_key] [sizes...]"""
 import sys, time, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

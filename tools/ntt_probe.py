@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""2^k-point fft / ifft timing (BASELINE configs[4]) for A/B runs of the butterfly multiplier (SRS_NTT_MUL29=0|1) and parity of
+"""2^k-point fft / ifft timing (BASELINE configs[4]) and parity of
 the two against each other at a size the caller picks.  usage: python tools/ntt_probe.py [log_n] -> one line per transform"""
 import hashlib
 import os
@@ -27,4 +27,4 @@ for name, fn in (("fft", S.fft.fft), ("ifft", S.fft.ifft), ("coset_fft", S.fft.c
     for _ in range(5):
         t0 = time.perf_counter(); fn(a); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     dt = min(ts)
-    print(f"mul29={os.environ.get('SRS_NTT_MUL29', '0')} 2^{log_n} {name:9s} {dt * 1e3:7.3f} ms  {64.0 * n / dt / 1e9:7.1f} GB/s algorithmic = {64.0 * n / dt / 8e12:.4f} of 8 TB/s  sha256 {digest}")
+    print(f"2^{log_n} {name:9s} {dt * 1e3:7.3f} ms  {64.0 * n / dt / 1e9:7.1f} GB/s algorithmic = {64.0 * n / dt / 8e12:.4f} of 8 TB/s  sha256 {digest}")

@@ -1,5 +1,5 @@
 """The support circuit's batched MSM alone (grumpkin, key 2^17: one trace of 3 * 2^15 scalars, 55 % zero, + two dense cross-term vectors of 2^15),
-device-resident, for A/B of the small-MSM switches (SRS_MSM_L0, SRS_MSM_QUAD_MAX, SRS_MSM_SORTV, ...; read once per process).
+device-resident, for A/B of the small-MSM tunables (SRS_TEST_TUNING="msm_l0=3,msm_quad_max=16").
 usage: python tools/small_msm_probe.py [reps]"""
 import os, sys, time
 import numpy as np, torch
@@ -20,4 +20,4 @@ for _ in range(reps):
     ck.commit_batch(vs)
 torch.cuda.synchronize()
 print("small batched MSM (3*2^15 + 2 x 2^15 grumpkin): %.1f us per call   env: %s" % ((time.perf_counter() - t) / reps * 1e6,
-      " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("SRS_MSM"))), flush=True)
+      " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("SRS_TEST_TUNING"))), flush=True)
