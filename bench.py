@@ -57,22 +57,22 @@ MAD_ISSUE_PER_S = 31.16e12
 MADD_MULT_INSNS = 8 * 171 + 2 * 135 - 90
 
 
-# No multi-GPU node was available to r01-r05: what the first measured SCALE record can be diffed against (derived from the
+# No multi-GPU node was available to r01-r06: what the first measured SCALE record can be diffed against (derived from the
 # kernel trace of the N = 1 step: per-row / per-scalar work divides by N, the chain's latency-bound part does not).
 PREDICTED_SCALING = {
     "note": "PREDICTION, not a measurement: k = 20 CycleFold step; strong scaling of ONE sequential chain",
     "process_per_gpu": {
         "how": "bench.py --gpus N (torchrun or self-launched): MSMs, leaves, cross terms, folds and the witness upload sharded by key / row stripes; RCCL all-gathers",
-        "ms_per_step": {"1": 10.8, "2": 7.3, "4": 4.7, "8": 3.7}, "speedup": {"1": 1.0, "2": 1.5, "4": 2.3, "8": 2.9},
-        "divisible_ms_at_1": 8.2, "replicated_ms": 2.6, "per_rank_overhead_ms_at_n_gt_1": 0.55,
+        "ms_per_step": {"1": 10.5, "2": 7.1, "4": 4.6, "8": 3.6}, "speedup": {"1": 1.0, "2": 1.5, "4": 2.3, "8": 2.9},
+        "divisible_ms_at_1": 8.0, "replicated_ms": 2.5, "per_rank_overhead_ms_at_n_gt_1": 0.55,
         "replicated": "transcript (Poseidon, host) 0.35, compute_F tree upper levels + K + e 0.35, bucket reductions + host finish 0.3, k_plan_s / "
                       "k_hist floors 0.07 per chunk (10 chunks at N <= 2, 2 at N >= 4), support circuit's latency-bound MSM 0.5, step-wise calls + five <= 2 KB all-gathers 0.45"},
     "single_process": {
         "how": "bench.py --gpus N --single-process (srs_ck_create_multi: what a single-process Rust IVC driver calls): every shard streams ITS stripes of the witness "
                "over its own link, overlapped with its MSM; the device copy is assembled on device 0 by peer copies; prove and support circuit on device 0",
-        "ms_per_step": {"1": 10.8, "2": 7.4, "4": 5.1, "8": 4.0}, "speedup": {"1": 1.0, "2": 1.5, "4": 2.1, "8": 2.7},
-        "divisible_ms_at_1": 8.1, "device0_ms": 2.0, "per_commit_overhead_ms_at_n_gt_1": 0.5,
-        "device0": "srs_pg_prove 1.0 (F / G / K / e + transcript), srs_sangria_prove_incoming 0.65 (the support key is a single-device key), Python 0.1, "
+        "ms_per_step": {"1": 10.5, "2": 7.2, "4": 5.0, "8": 3.9}, "speedup": {"1": 1.0, "2": 1.5, "4": 2.1, "8": 2.7},
+        "divisible_ms_at_1": 8.0, "device0_ms": 1.9, "per_commit_overhead_ms_at_n_gt_1": 0.5,
+        "device0": "srs_pg_prove 0.87 (F / G / K / e + transcript), srs_sangria_prove_incoming 0.63 (the support key is a single-device key), Python 0.1, "
                    "the deferred witness fold 0.24 under the upload; per commit: slot + bucket reductions per shard 0.3, worker hand-off and the peer-copy tail 0.2"},
     "msm_2p24_uniform_ms": {"1": 19.3, "2": 10.0, "4": 5.3, "8": 3.0},
 }
