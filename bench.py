@@ -27,6 +27,8 @@ Multi-GPU (torchrun, one rank per GPU): every MSM is sharded block-cyclically ov
 are all-gathered over RCCL and summed on the host; the row programs are sharded by the same row stripes (cross terms; the
 ProtoGalaxy leaves: partial F / G polynomials all-gathered and added), the witness upload is 1 / world per rank; K, the transcript
 and the folds over whole vectors stay replicated.  One IVC chain is sequential, so this is STRONG scaling of a single step.
+`--gpus N --threads` runs the same decomposition in ONE process, one host thread per GPU (srs_init_thread), partial sums exchanged in memory;
+`--gpus N --single-process` uses multi-device keys instead (the library owns the devices; the prove stays on device 0).
 
 Prints ONE JSON line (rank 0).  `roofline`: dominant kernel = MSM bucket accumulation; achieved = 96 B x scalars / launch time
 (HIP events on the launch stream, inside the library).  `cpu_baseline`: the CPU oracle (oracle/, a C port of the reference's
@@ -113,6 +115,10 @@ def parse():
                     help="with --gpus N: ONE process, the commitment keys are multi-device keys (srs_ck_create_multi: the library owns N devices / "
                          "shards, partitions the scalars, adds the partial sums on the host) -- the path a single-process Rust IVC driver calls. "
                          "More logical shards than physical devices are allowed (shard d runs on device d % count)")
+    ap.add_argument("--threads", action="store_true",
+                    help="with --gpus N: ONE process, N host threads, thread r bound to device r %% count (srs_init_thread) with its own SHARDED handles -- "
+                         "the process-per-GPU decomposition (commits, leaves, cross terms, folds and uploads sharded by stripes) without processes and "
+                         "without a collective: partial commitments / polynomials are exchanged in memory")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU exchange; lets 2 ranks share one GPU in tests)")
     args = ap.parse_args()
     args.ro_challenge = args.challenges == "poseidon-ro" or args.ro_challenge
@@ -205,6 +211,61 @@ class Dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=red)
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
+
+
+class ThreadGroup:
+    """what N threads of one process share: a barrier and one slot per rank for the exchanges"""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.barrier = world, threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class DistThreads:
+    """Dist for `--gpus N --threads`: rank = host thread, bound to device rank % count; exchanges go through ThreadGroup's slots (two
+    barriers per exchange: all written, all read), the sums through the library's host entries as in sirius_amd.distributed."""
+
+    def __init__(self, args, rank, group):
+        import torch
+        import sirius_amd as S
+        self.world, self.rank, self.group, self.emu, self.multi, self.dist = group.world, rank, group, args.emu, 0, None
+        if self.emu:
+            self.dev = torch.device("cpu")
+        else:
+            d = rank % group.n_devices
+            torch.cuda.set_device(d)
+            self.dev = torch.device("cuda", d)
+            S.init_thread(d)
+
+    def _all(self, x):
+        g = self.group
+        g.slots[self.rank] = x
+        g.barrier.wait()
+        out = list(g.slots)
+        g.barrier.wait()
+        return out
+
+    def combine(self, curve, partial):
+        import sirius_amd as S
+        parts = np.stack([np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 8) for p in self._all(partial)])     # (world, m, 8)
+        res = np.stack([S.point_sum(curve, parts[:, j, :]) for j in range(parts.shape[1])])
+        return res if np.ndim(partial) == 2 else res[0]
+
+    def sum_field(self, field, partial):
+        from sirius_amd.field import ints_to_mont
+        from sirius_amd.protogalaxy import fold_witness
+        parts = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in self._all(partial)]
+        return fold_witness(field, parts, ints_to_mont(field, [1] * self.world)).reshape(np.shape(partial))
+
+    def barrier(self):
+        import torch
+        if not self.emu:
+            torch.cuda.synchronize()
+        self.group.barrier.wait()
+
+    def max_over_ranks(self, dt):
+        return max(self._all(dt))
 
 
 def make_key(S, D, curve, n, seed):
@@ -903,7 +964,7 @@ def extras_msm_sharded(S, D, ck, log_n, reps=3):
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process and not args.threads:
         spawn_ranks(args)
     import torch
     if args.emu:
@@ -911,7 +972,33 @@ def main():
         _lib.load(os.path.join(ROOT, "tests", "emu", "libsirius_emu.so"))
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    D = Dist(args)
+    if args.threads and args.gpus > 1:
+        import threading
+        group, errs = ThreadGroup(args.gpus), []
+        if not args.emu:
+            torch.cuda.init()                    # (torch's lazy CUDA initialisation is not safe to enter from several threads at once)
+            group.n_devices = torch.cuda.device_count()
+
+        def body(rank):
+            try:
+                run(args, DistThreads(args, rank, group))
+            except BaseException as e:           # a dead rank must not leave the others in a barrier
+                errs.append((rank, repr(e)))
+                group.barrier.abort()
+                raise
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(args.gpus)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            sys.exit(f"bench.py --threads: {errs}")
+        return
+    run(args, Dist(args))
+
+
+def run(args, D):
+    import torch
     import sirius_amd as S
 
     out = None
@@ -978,7 +1065,8 @@ def main():
                            "witness": "55 % zero scalars, 45 % uniform 254-bit: 7.2 non-zero 16-bit digits (= bucket additions) per scalar, no hot buckets; "
                                       "SURVEY.md 8d(ii)'s mixture with bits and small values costs ~2.4 per scalar (tests/conftest.py seeded_scalars 'trace')",
                            "msm": "16 x 16-bit windows, streamed commit in 10 chunks, slot mode (per-bucket persistent partial sums, one reduction per commit)",
-                           "parallelism": (f"msm+leaf-shard{D.world}" if getattr(pri, "sharded", False) else f"msm-shard{D.world}") if D.world > 1
+                           "parallelism": ((f"msm+leaf-shard{D.world}" if getattr(pri, "sharded", False) else f"msm-shard{D.world}") +
+                                           ("-threads (one process, one host thread per device)" if isinstance(D, DistThreads) else "")) if D.world > 1
                                           else (f"msm-multi{D.multi}-single-process ({pri.ck.num_shards} shards on {torch.cuda.device_count() if not D.emu else 0} device(s))"
                                                 if D.multi else "single-gpu")},
                 "msm_scalars_per_s": round(scalars_per_step * args.steps / dt, 1),
@@ -1141,7 +1229,7 @@ def main():
                 out["cpu_baseline"] = cpu
     if D.rank == 0:
         print(json.dumps(out), flush=True)
-    if D.world > 1:
+    if D.world > 1 and D.dist is not None:
         D.dist.barrier()
         D.dist.destroy_process_group()
 

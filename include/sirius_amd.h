@@ -59,7 +59,12 @@ enum { SRS_SPACE_HOST = 0, SRS_SPACE_DEVICE = 1 };
 enum { SRS_REPR_MONT = 0, SRS_REPR_CANON = 1 };
 
 /* ---- library ---- */
-int srs_init(int device_ordinal);            /* binds the calling thread's HIP device; checks gfx950 */
+int srs_init(int device_ordinal);            /* binds the PROCESS to a device (-1: the current one); checks gfx950 */
+/* Binds the CALLING THREAD to a device (-1: back to the process's device): one process may drive one GPU per host thread, every thread
+ * with its own handles -- e.g. sharded keys and structures (srs_ck_create_sharded, srs_structure_set_shard) with rank = thread index;
+ * the caller adds the ranks' partial commitments / polynomials itself (srs_point_sum, field additions).  A handle must be used by
+ * threads bound to the device it was created on.  No reference counterpart (the reference is single-device CPU code). */
+int srs_init_thread(int device_ordinal);
 const char *srs_last_error(void);
 const char *srs_version(void);
 /* Run-time tunables (csrc/tuning.h holds the table): each selects among code paths the library takes by default for SOME input size

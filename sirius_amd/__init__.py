@@ -17,6 +17,11 @@ from .poseidon import PoseidonHash  # noqa: F401,E402
 from .plonk import PlonkStructure, RelaxedPlonkWitness, SparseMatrix, VanillaFS, batch_invert_assigned, sangria_prove  # noqa: F401,E402
 
 
+def init_thread(device):
+    """bind the CALLING host thread to a device (srs_init_thread; -1: back to the process's device)"""
+    _lib.check(_lib.lib().srs_init_thread(int(device)))
+
+
 def profile_enable(on=True):
     _lib.lib().srs_profile_enable(1 if on else 0)
 

@@ -28,6 +28,7 @@ def _prototypes():
     vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
     return {
         "srs_init": (i32, [i32]),
+        "srs_init_thread": (i32, [i32]),
         "srs_last_error": (C.c_char_p, []),
         "srs_version": (C.c_char_p, []),
         "srs_tuning_set": (i32, [C.c_char_p, C.c_int64]),

@@ -301,15 +301,22 @@ void to_affine_batch(int curve, const xyzz_t *in, affine_t *out, size_t n) {
 }
 
 bool g_device_ok = false;
-int g_device = -1;        // the one device of this process (one process per GPU); bound by the first srs_init
+int g_device = -1;        // the process's device (one process per GPU); bound by the first srs_init
+// r06: a host thread may bind ITSELF to another device (srs_init_thread): one process, one thread per GPU, every thread with its own
+// handles -- sharded keys and structures (srs_ck_create_sharded, srs_structure_set_shard) then put commits, leaves, cross terms and folds
+// on every device of a node from a single process; the partial sums are added by the caller (no collective needed inside a process).
+static thread_local int t_device = -1;
+int home_device() { return t_device >= 0 ? t_device : (g_device < 0 ? 0 : g_device); }
 
 // HIP's current device is per host thread: a caller's worker thread starts on device 0.  Every entry point rebinds the
-// calling thread to the process's device so that handles created on one thread work from any other.
+// calling thread to its device (srs_init_thread) or the process's (srs_init), so that handles created on one thread work from any
+// other thread bound to the same device.
 int ensure_device() {
-    if (!g_device_ok) return srs_init(-1);
+    if (!g_device_ok && t_device < 0) return srs_init(-1);
+    const int want = t_device >= 0 ? t_device : g_device;
     int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != g_device) {
-        if (hipSetDevice(g_device) != hipSuccess) return fail(SRS_ERR_DEVICE, "hipSetDevice failed");
+    if (hipGetDevice(&cur) != hipSuccess || cur != want) {
+        if (hipSetDevice(want) != hipSuccess) return fail(SRS_ERR_DEVICE, "hipSetDevice failed");
     }
     return SRS_OK;
 }
@@ -424,7 +431,7 @@ int create_multi(int curve, size_t len, int n_devices, Fill fill, srs_ck **out) 
     if (phys <= 0) return fail(SRS_ERR_DEVICE, "no HIP device visible: libsirius_amd has no CPU path");
     const uint32_t world = n_devices > 0 ? (uint32_t)n_devices : (uint32_t)phys;
     if (world > 64) return fail(SRS_ERR_INVALID, "srs_ck_create_multi: more than 64 shards");
-    const int home = g_device < 0 ? 0 : g_device;
+    const int home = home_device();
     srs_ck *ck = new srs_ck();
     ck->key.curve = curve;
     ck->key.global_len = len;
@@ -514,6 +521,26 @@ int srs_init(int device_ordinal) {
             return fail(SRS_ERR_DEVICE, "device is " + arch + ", kernels are built for gfx950 only");
         g_device = dev;
         g_device_ok = true;
+        return SRS_OK;
+    });
+}
+
+int srs_init_thread(int device_ordinal) {
+    return guarded([&]() -> int {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+            return fail(SRS_ERR_DEVICE, "no HIP device visible: libsirius_amd has no CPU path");
+        if (device_ordinal < 0) {            // unbind: back to the process's device
+            t_device = -1;
+            return SRS_OK;
+        }
+        if (device_ordinal >= count) return fail(SRS_ERR_INVALID, "device ordinal out of range");
+        SRS_HIP_CHECK(hipSetDevice(device_ordinal));
+        std::string arch;
+        if (!rt::device_arch(device_ordinal, arch)) return fail(SRS_ERR_DEVICE, "hipGetDeviceProperties failed");
+        if (arch.compare(0, 6, "gfx950") != 0)
+            return fail(SRS_ERR_DEVICE, "device is " + arch + ", kernels are built for gfx950 only");
+        t_device = device_ordinal;
         return SRS_OK;
     });
 }
@@ -837,7 +864,7 @@ int srs_ck_shard_stats(const srs_ck *ck, int shard, uint64_t *out) {
     for (int i = 0; i < 4; ++i) out[i] = 0;
     if (ck->shards.empty()) {
         if (shard != 0) return fail(SRS_ERR_INVALID, "srs_ck_shard_stats: no such shard");
-        out[3] = (uint64_t)(g_device < 0 ? 0 : g_device);
+        out[3] = (uint64_t)home_device();
         return SRS_OK;
     }
     if ((size_t)shard >= ck->shards.size()) return fail(SRS_ERR_INVALID, "srs_ck_shard_stats: no such shard");
@@ -1228,7 +1255,7 @@ std::vector<size_t> commit_cuts(size_t n, size_t align, size_t n_eff = 0, double
 // crosses ONE link, and nothing is uploaded twice.  The caller's stream waits for the forwarded stripes; the partial sums are added here.
 int multi_commit_streamed(srs_ck *ck, const std::vector<Seg> &segs, size_t n, fe_t *dev_copy, int repr, hipStream_t st, srs_affine *out) {
     const uint32_t world = (uint32_t)ck->shards.size();
-    const int home = g_device < 0 ? 0 : g_device;
+    const int home = home_device();
     const size_t align = (size_t)world << msm::STRIPE_LOG;
     const std::vector<size_t> cut = commit_cuts(n, align, n / world, key_density(ck->shards[0]->key));
     std::vector<xyzz_t> parts(world);

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <vector>
 
@@ -418,7 +419,7 @@ struct Plan {
 
 static std::mutex g_mu;
 static uint32_t g_max_radix = 8;   // tuning knob (4..8): digits per pass; never changes results
-static std::map<std::pair<uint32_t, bool>, Plan> g_plans;
+static std::map<std::tuple<int, uint32_t, bool>, Plan> g_plans;      // per (device, length, direction): the tables live in that device's HBM
 // r04: multi-pass transforms run on the lazy 9 x 29-bit tile (k_ntt_pass_lazy / k_ntt_last_lazy) -- 2^24: fft 2.33 vs 2.65 ms, ifft 2.21 vs
 // 2.47, coset_ifft 2.12 vs 2.62; 2^20: 0.167 vs 0.201 (profiles/r04_ab_ntt_lazy_tile.txt); the canonical 8 x 32 tile kernels are gone (r06).
 
@@ -429,7 +430,9 @@ static void fill(fe_t *T, uint32_t log_entries, uint32_t lo_bits, const fe_t &ba
 
 static Plan &get_plan(uint32_t log_n, bool inverse, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto key = std::make_pair(log_n, inverse);
+    int device = 0;
+    SRS_HIP_CHECK(hipGetDevice(&device));
+    auto key = std::make_tuple(device, log_n, inverse);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
     Plan p;

@@ -23,6 +23,7 @@ struct Pending {
     const char *name;
     hipEvent_t e0, e1;
     uint64_t units;
+    int device = 0;                 // events belong to the device they were created on (r06: one process may drive several)
 };
 struct State {
     bool on = false;
@@ -31,8 +32,13 @@ struct State {
     std::mutex mu;
     std::map<std::string, Stat> stats;
     std::vector<Pending> pending;
-    std::vector<hipEvent_t> pool;
+    std::map<int, std::vector<hipEvent_t>> pool;      // per device
 };
+inline int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
 State &state();
 
 inline bool enabled() { return state().on; }
@@ -46,9 +52,11 @@ struct Scope {
         State &s = state();
         if (!s.on) return;
         std::lock_guard<std::mutex> lk(s.mu);
+        p.device = current_device();
+        std::vector<hipEvent_t> &pool = s.pool[p.device];
         auto take = [&]() {
             hipEvent_t e;
-            if (!s.pool.empty()) { e = s.pool.back(); s.pool.pop_back(); return e; }
+            if (!pool.empty()) { e = pool.back(); pool.pop_back(); return e; }
             if (hipEventCreate(&e) != hipSuccess) e = nullptr;
             return e;
         };
@@ -57,8 +65,8 @@ struct Scope {
         p.e0 = take();
         p.e1 = take();
         if (!p.e0 || !p.e1) {
-            if (p.e0) s.pool.push_back(p.e0);
-            if (p.e1) s.pool.push_back(p.e1);
+            if (p.e0) pool.push_back(p.e0);
+            if (p.e1) pool.push_back(p.e1);
             return;
         }
         (void)hipEventRecord(p.e0, st);
@@ -84,9 +92,11 @@ struct KernelEvents {
         if (!s.on) return;
         std::lock_guard<std::mutex> lk(s.mu);
         if (s.sample_every > 1 && (s.seen[name]++ % s.sample_every) != 0) return;      // not this launch
+        p.device = current_device();
+        std::vector<hipEvent_t> &pool = s.pool[p.device];
         auto take = [&]() {
             hipEvent_t e;
-            if (!s.pool.empty()) { e = s.pool.back(); s.pool.pop_back(); return e; }
+            if (!pool.empty()) { e = pool.back(); pool.pop_back(); return e; }
             if (hipEventCreate(&e) != hipSuccess) e = nullptr;
             return e;
         };
@@ -96,8 +106,8 @@ struct KernelEvents {
         p.e1 = take();
         live = p.e0 && p.e1;
         if (!live) {                              // the one event that could be had goes back to the pool
-            if (p.e0) s.pool.push_back(p.e0);
-            if (p.e1) s.pool.push_back(p.e1);
+            if (p.e0) pool.push_back(p.e0);
+            if (p.e1) pool.push_back(p.e1);
         }
     }
     void launched() {

@@ -21,8 +21,8 @@ void collect() {
             st.launches += 1;
             st.units += p.units;
         }
-        s.pool.push_back(p.e0);
-        s.pool.push_back(p.e1);
+        s.pool[p.device].push_back(p.e0);
+        s.pool[p.device].push_back(p.e1);
     }
     s.pending.clear();
 }

@@ -218,7 +218,8 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
             "r2": (bench + ["--gpus", "2", "--dist-backend", "gloo"] + [a for a in common if a != "--no-extras"], env2),
             "r1t": (bench + ["--gpus", "1", "--leaf-rows", "true"] + common, env),
             "r2t": (bench + ["--gpus", "2", "--dist-backend", "gloo", "--leaf-rows", "true"] + common, env2),
-            "r3s": (bench + ["--gpus", "3", "--single-process"] + common, env2)}       # one process, multi-device keys of 3 logical shards
+            "r3s": (bench + ["--gpus", "3", "--single-process"] + common, env2),       # one process, multi-device keys of 3 logical shards
+            "r2th": (bench + ["--gpus", "2", "--threads"] + common, env2)}            # one process, one host thread per (logical) device, sharded handles
     procs = {k: subprocess.Popen(a, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k, (a, e) in jobs.items()}
     res = {}
     for k, p in procs.items():
@@ -231,6 +232,8 @@ def test_bench_world2_matches_world1_on_emulator(tmp_path):
     assert one["state_digest"] == two["state_digest"]
     assert one["config"]["leaf_rows"] == "compat" and one["config"]["challenges"] == "poseidon-ro"      # the headline configuration
     assert two["secondary"]["microbench_msm_sharded"]["msm_uniform"]["n_gpus"] == 2
+    thr = last_json(res["r2th"][1])           # r06: srs_init_thread -- the process-per-GPU decomposition on threads, exchanges in memory
+    assert thr["n_gpus"] == 2 and thr["config"]["parallelism"].startswith("msm+leaf-shard2-threads") and thr["state_digest"] == one["state_digest"]
     multi = last_json(res["r3s"][1])
     assert multi["n_gpus"] == 3 and multi["config"]["parallelism"].startswith("msm-multi3-single-process") and multi["state_digest"] == one["state_digest"]
     # ... and every link carried its third of the 12 * 2^11 * 32 B witness, once (srs_ck_shard_stats): nothing goes to device 0 first

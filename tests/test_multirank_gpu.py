@@ -37,6 +37,27 @@ def test_bench_two_ranks_one_gpu_same_chain(srs, config, k, log_key):
     assert one["state_digest"] == two["state_digest"]
 
 
+def test_bench_threads_same_chain(srs):
+    """`bench.py --gpus N --threads` (r06): ONE process, one host thread per device (srs_init_thread), every thread with its own sharded key and
+    row-sharded structure, partial commitments / polynomials exchanged in memory -- folds the chain `--gpus 1` folds.  On a one-GPU box the
+    threads share device 0 (N = 2 logical ranks); on a multi-GPU node every thread drives its own device (N = min(devices, 8))."""
+    import torch
+    n = max(2, min(torch.cuda.device_count(), 8))
+    while (1 << 7) % n:
+        n -= 1
+    common = ["--k", "17", "--log-key", "21", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = [sys.executable, os.path.join(ROOT, "bench.py")]
+    r1 = subprocess.run(bench + ["--gpus", "1"] + common, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    rn = subprocess.run(bench + ["--gpus", str(n), "--threads"] + common, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert rn.returncode == 0, rn.stdout[-2000:] + rn.stderr[-4000:]
+    last = lambda so: json.loads([l for l in so.strip().splitlines() if l.startswith("{")][-1])
+    one, many = last(r1.stdout), last(rn.stdout)
+    assert many["n_gpus"] == n and many["config"]["parallelism"].startswith(f"msm+leaf-shard{n}-threads")
+    assert one["state_digest"] == many["state_digest"]
+
+
 def test_bench_rccl_all_devices_same_chain(srs):
     """When the box has >= 2 devices (the driver's 8-GPU node): `bench.py --gpus N` with the REAL backend (nccl = RCCL over xGMI), one rank
     per GPU, must fold the chain `--gpus 1` folds -- partial commitments and partial polynomials through RCCL all_gather with N > 1 ranks.
