@@ -1186,6 +1186,7 @@ def run(args, D):
                 out["summary"] = {
                     "cyclefold_k20_ms_per_step": out["ms_per_step"], "fold_steps_per_s": out["value"],
                     "resident_ms": (out["secondary"]["device_resident"] or {}).get("ms_per_step"),
+                    "resident_fold_steps_per_s": (out["secondary"]["device_resident"] or {}).get("fold_steps_per_s"),      # inputs in HBM before the step (`value` is PCIe-inclusive: the conservative figure)
                     "pageable_ms": (out["secondary"]["pageable_witness"] or {}).get("ms_per_step"),
                     "survey_mixture_ms": (out["secondary"]["survey_mixture"] or {}).get("ms_per_step"),
                     "true_rows_ms": (out["secondary"]["true_leaf_rows"] or {}).get("ms_per_step"),
