@@ -46,6 +46,37 @@ def test_host_only_entries():
         assert np.array_equal(S.point_sum(cid, np.zeros((0, 8), np.uint64)), np.zeros(8, np.uint64))
 
 
+def test_tunables_table():
+    """srs_tuning_set / _get / _reset / _name (host code): the ONE table of run-time tunables that replaced the environment switches (r06).
+    Every name listed in include/sirius_amd.h is known, unknown names are refused, values round-trip, the context manager restores."""
+    import sirius_amd as S
+    from sirius_amd import _lib
+    names = S.tuning.names()
+    header = open(os.path.join(ROOT, "include", "sirius_amd.h")).read()
+    listed = re.search(r"Names \(srs_tuning_name.*?:(.*?)\.\s+Process-wide", header, flags=re.S).group(1)
+    assert sorted(names) == sorted(n.strip() for n in re.sub(r"[*\n]", " ", listed).split(",")), (names, listed)
+    assert all(S.tuning.get(n) is None for n in names)
+    with S.tuning(msm_sort=2, commit_chunks=3):
+        assert S.tuning.get("msm_sort") == 2 and S.tuning.get("commit_chunks") == 3
+        with S.tuning(msm_sort=1):
+            assert S.tuning.get("msm_sort") == 1
+        assert S.tuning.get("msm_sort") == 2
+    assert S.tuning.get("msm_sort") is None and S.tuning.get("commit_chunks") is None
+    try:
+        S.tuning.set("no_such_tunable", 1)
+    except S.SiriusAmdError as e:
+        assert e.rc == _lib.ERR_INVALID and "no_such_tunable" in str(e)
+    else:
+        raise AssertionError("unknown tunable accepted")
+    S.tuning.set("msm_l0", 5)
+    _lib.lib().srs_tuning_reset()
+    assert S.tuning.get("msm_l0") is None
+    # the library itself reads a fixed, short list of environment variables (INTEGRATION.md 6b)
+    src = "".join(open(os.path.join(ROOT, "sirius_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "sirius_amd", "csrc"))
+                  if f.endswith((".hip", ".h", ".cuh")) )
+    assert sorted(set(re.findall(r'getenv\("(\w+)"\)', src))) == ["ROCM_PATH", "SRS_HOST_TRACE", "SRS_JIT_DUMP", "SRS_MSM_WIDE", "SRS_NO_JIT", "SRS_POSEIDON_SCALAR"]
+
+
 def test_lagrange_values_on_and_off_the_domain():
     """srs_lagrange_eval (host code, one batched inversion): iter_eval_lagrange_poly_for_cyclic_group (src/polynomial/lagrange.rs:50-75)
     for challenges off the domain, ON the domain (X = w^i: the unit vector, the branch the reference special-cases) and X = 0."""
