@@ -692,7 +692,10 @@ def msm_roofline(S, units_note, nz_madds=None, world=1, total_units=None, sample
         roof["alu"] = {"unit": "G mixed-add/s", "achieved": round(rate / 1e9, 3), "peak": round(peak / 1e9, 3),
                        "frac": round(rate / peak, 4),
                        "peak_source": "instruction issue: 31.2 T v_mad_u64_u32/s (profiles/r02_ubench29_gfx950.txt) / 1548 multiplier "
-                                      "instructions per mixed addition (8 products x 171 + 2 squares x 135 - 90: one shared reduction)"}
+                                      "instructions per mixed addition (8 products x 171 + 2 squares x 135 - 90: one shared reduction)",
+                       "clock": "power-managed: 2.20-2.25 GHz inside k_accum0s under the product's chunk schedule, 1.8-2.0 GHz when the launches "
+                                "run back to back (advertised 2.4 GHz); per shader cycle the kernel is at the multiplier's issue rate "
+                                "(profiles/r06_clock_under_load.txt)"}
     return roof
 
 
