@@ -662,7 +662,7 @@ def msm_roofline(S, units_note, nz_madds=None, world=1, total_units=None, sample
         nz_madds = nz_madds * acc0["units"] / total_units
     achieved = MSM_BYTES_PER_SCALAR * acc0["units"] / sec / 1e9
     traffic, src = None, None
-    for name in ("r05_pmc_accum0.json", "r04_pmc_accum0.json", "r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
+    for name in ("r06_pmc_accum0.json", "r05_pmc_accum0.json", "r04_pmc_accum0.json", "r03_pmc_accum0.json", "r02_pmc_accum0.json", "r01_pmc_accum0.json"):
         try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if world == 1:
