@@ -51,7 +51,7 @@ struct HostTrace {
 };
 // device scratch of the handle-less entry points (folds, lookup h/g) when they are given HOST operands: grow-only, one
 // per calling thread, so that a fold does not pay a hipMalloc + hipFree (an implicit device synchronisation) per call
-static thread_local srs::Arena g_scratch;
+static thread_local srs::ThreadArena g_scratch;
 void set_error(const std::string &msg) { g_err = msg; }
 const char *get_error() { return g_err.c_str(); }
 }  // namespace srs

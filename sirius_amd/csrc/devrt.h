@@ -90,4 +90,17 @@ struct Arena {
     }
 };
 
+// A grow-only scratch arena owned by a host THREAD (a `static thread_local`), not by a handle: it follows its thread when srs_init_thread
+// re-binds the thread to another device (the memory of the old device is released; handle-owned arenas never move).
+struct ThreadArena : Arena {
+    int dev = -1;
+    void reserve(size_t bytes) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (base && cur != dev) release();
+        dev = cur;
+        Arena::reserve(bytes);
+    }
+};
+
 }  // namespace srs

@@ -2751,7 +2751,7 @@ int pg_K_from_G(const fe_t *polyG_host, size_t nG, const fe_t &f_alpha, size_t i
                 hipStream_t st, fe_t *out_host, std::string &err) {
     if (log_domain_K > ntt::FR_S) { err = "k=" + std::to_string(log_domain_K) + " should no larger than F::S=28"; return 3; }   // fft.rs:13
     const size_t count = (size_t)1 << log_domain_K;
-    static thread_local Arena scratch;                         // grow-only: no hipMalloc / hipFree (implicit sync) per call
+    static thread_local ThreadArena scratch;                         // grow-only: no hipMalloc / hipFree (implicit sync) per call
     scratch.reserve(Arena::pad((nG + 1) * sizeof(fe_t)) + Arena::pad(count * sizeof(fe_t)) + Arena::pad(sizeof(int)) + 256);
     scratch.reset();
     fe_t *d_g = scratch.take<fe_t>(nG + 1), *d_out = scratch.take<fe_t>(count);
@@ -2904,7 +2904,7 @@ int pg_K_from_G_device(Structure *S, const PgGValues &g, const fe_t &f_alpha, si
         S->owned.push_back(M);
         SRS_HIP_CHECK(hipMemcpy(M, full.data(), full.size() * sizeof(fe_t), hipMemcpyHostToDevice));
     }
-    static thread_local Arena scratch;
+    static thread_local ThreadArena scratch;
     scratch.reserve(Arena::pad((size_t)count * sizeof(fe_t)) + 256);
     scratch.reset();
     fe_t *d_out = scratch.take<fe_t>(count);
