@@ -639,15 +639,35 @@ def chain_digest(pri, sup):
 
 
 # ------------------------------------------------------------------------------------------ measurement helpers
+class quiet_gc:
+    """No collection of the INTERPRETER inside a timed region (what `timeit` does too): with torch loaded a generation-2 pass of CPython's
+    cycle collector takes ~35 ms, and where it lands is a matter of allocation counts -- r06 found one inside the ten timed steps of
+    `secondary.device_resident` (13.0 instead of 9.5 ms per step whenever --steps was 10; tools/resident_in_bench.py).  The collector runs
+    right BEFORE the region instead.  The caller of the C-ABI is Rust: the product has no collector."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+
+
 def timed(D, fn, steps, after=None):
-    D.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    if after:
-        after()
-    D.barrier()
-    return D.max_over_ranks(time.perf_counter() - t0)
+    with quiet_gc():
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        if after:
+            after()
+        D.barrier()
+        dt = time.perf_counter() - t0
+    return D.max_over_ranks(dt)
 
 
 def msm_roofline(S, units_note, nz_madds=None, world=1, total_units=None, sample_every=1, gather_peak_g=40.0):
@@ -824,12 +844,13 @@ def extras_microbench(S, D, ck24, log_n=24, reps=3):
     def timeit(fn):
         for _ in range(3):           # plan / table creation and the clock ramp stay outside (the first transforms of a process run ~10 % slower)
             fn()
-        D.barrier()
-        t = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        D.barrier()
-        return (time.perf_counter() - t) / reps
+        with quiet_gc():
+            D.barrier()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            D.barrier()
+            return (time.perf_counter() - t) / reps
     a = up(D, rand_fe(rng, n))
     S.fft.fft(a)
     pmc = None
@@ -953,12 +974,14 @@ def extras_msm_sharded(S, D, ck, log_n, reps=3):
         d = up(D, rand_fe(rng, n, zero_frac=0.55 if kind == "trace" else 0.0))
         fn = lambda: D.combine(S.CURVE_BN256, ck.commit(d))
         fn()
-        D.barrier()
-        t = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        D.barrier()
-        dt = D.max_over_ranks((time.perf_counter() - t) / reps)
+        with quiet_gc():
+            D.barrier()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            D.barrier()
+            dt = (time.perf_counter() - t) / reps
+        dt = D.max_over_ranks(dt)
         out[f"msm_{kind}"] = {"ms": round(dt * 1e3, 3), "scalars_per_s": round(n / dt), "n_gpus": D.world}
         del d
     return out
