@@ -639,22 +639,39 @@ def chain_digest(pri, sup):
 
 
 # ------------------------------------------------------------------------------------------ measurement helpers
+_GC_HOLD = {"depth": 0, "was": False}
+
+
+def gc_hold():
+    """Run the interpreter's cycle collector NOW and keep it off until the matching gc_release().  With torch loaded a generation-2 pass of
+    CPython's collector takes ~35 ms, and where it lands is a matter of allocation counts: r06 found one inside the ten timed steps of
+    `secondary.device_resident` in every default run (13.0 instead of 9.5 ms per step; profiles/r06_bench_gc_pause.txt).  Called BEFORE a
+    leg's warm-up steps, not right before its timed region: 35 ms of idle device let the clocks fall, and the first three timed steps
+    after it ran 1.3 / 0.4 / 0.3 ms slow (same record).  `timeit` of the standard library keeps the collector off too; the product is
+    called from Rust and has none."""
+    import gc
+    if _GC_HOLD["depth"] == 0:
+        _GC_HOLD["was"] = gc.isenabled()
+        gc.collect()
+        gc.disable()
+    _GC_HOLD["depth"] += 1
+
+
+def gc_release():
+    import gc
+    _GC_HOLD["depth"] -= 1
+    if _GC_HOLD["depth"] == 0 and _GC_HOLD["was"]:
+        gc.enable()
+
+
 class quiet_gc:
-    """No collection of the INTERPRETER inside a timed region (what `timeit` does too): with torch loaded a generation-2 pass of CPython's
-    cycle collector takes ~35 ms, and where it lands is a matter of allocation counts -- r06 found one inside the ten timed steps of
-    `secondary.device_resident` (13.0 instead of 9.5 ms per step whenever --steps was 10; tools/resident_in_bench.py).  The collector runs
-    right BEFORE the region instead.  The caller of the C-ABI is Rust: the product has no collector."""
+    """a region without a pass of the collector (nested inside gc_hold() it changes nothing: the collection happened before the warm-up)"""
 
     def __enter__(self):
-        import gc
-        gc.collect()
-        self.was = gc.isenabled()
-        gc.disable()
+        gc_hold()
 
     def __exit__(self, *exc):
-        import gc
-        if self.was:
-            gc.enable()
+        gc_release()
 
 
 def timed(D, fn, steps, after=None):
@@ -808,10 +825,12 @@ def extras_sangria(S, D, args, k=17, log_key=21, steps=20, warmup=3):
     sangria_step(S, D, pri, sec, False, ro, count=True)
     out = {"challenges": "poseidon-ro" if ro else "seeded"}
     for name, from_host in (("device_resident", False), ("host_witness", True)):
+        gc_hold()
         for _ in range(warmup):
             sangria_step(S, D, pri, sec, from_host, ro)
         S.profile_reset()
         dt = timed(D, lambda: sangria_step(S, D, pri, sec, from_host, ro), steps, after=lambda: (pri.settle(), sec.settle()))
+        gc_release()
         out[name] = {"fold_steps_per_s": round(steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4)}
         if not from_host:
             nz = sum(nonzero_rows(sd.inW) + sd.nz_terms for sd in (pri, sec))
@@ -842,6 +861,7 @@ def extras_microbench(S, D, ck24, log_n=24, reps=3):
     out = {"workload": f"2^{log_n}-point MSM (bn256 G1) + 2^{log_n}-point NTT (Fr), device-resident (BASELINE configs[4])"}
 
     def timeit(fn):
+        gc_hold()
         for _ in range(3):           # plan / table creation and the clock ramp stay outside (the first transforms of a process run ~10 % slower)
             fn()
         with quiet_gc():
@@ -850,7 +870,9 @@ def extras_microbench(S, D, ck24, log_n=24, reps=3):
             for _ in range(reps):
                 fn()
             D.barrier()
-            return (time.perf_counter() - t) / reps
+            dt = (time.perf_counter() - t) / reps
+        gc_release()
+        return dt
     a = up(D, rand_fe(rng, n))
     S.fft.fft(a)
     pmc = None
@@ -920,9 +942,11 @@ def extras_high_degree(S, D, args, k=22, degree=15, reps=5):
     def prove():
         ro.reset().absorb_field(delta.reshape(1, 4))
         return PG.prove(ctx, betas, delta, [accW, inW], ro=ro, reference_compat=compat, fold=True)
+    gc_hold()
     prove()
     S.profile_reset()
     dt = timed(D, prove, reps)
+    gc_release()
     prof = {}
     for name in ("pg_F_leaves", "pg_G_leaves"):
         st = S.profile_get(name)
@@ -973,6 +997,7 @@ def extras_msm_sharded(S, D, ck, log_n, reps=3):
     for kind in ("uniform", "trace"):
         d = up(D, rand_fe(rng, n, zero_frac=0.55 if kind == "trace" else 0.0))
         fn = lambda: D.combine(S.CURVE_BN256, ck.commit(d))
+        gc_hold()
         fn()
         with quiet_gc():
             D.barrier()
@@ -981,6 +1006,7 @@ def extras_msm_sharded(S, D, ck, log_n, reps=3):
                 fn()
             D.barrier()
             dt = (time.perf_counter() - t) / reps
+        gc_release()
         dt = D.max_over_ranks(dt)
         out[f"msm_{kind}"] = {"ms": round(dt * 1e3, 3), "scalars_per_s": round(n / dt), "n_gpus": D.world}
         del d
@@ -1051,12 +1077,14 @@ def run(args, D):
         if resident:
             cyclefold_step(S, D, pri, sup, args.ro_challenge)      # (both witnesses have been committed from the host once: set_resident's check)
             pri.set_resident(D, True)
+        gc_hold()                  # (the collector runs here, BEFORE the warm-up steps, and stays off through the timed ones)
         for _ in range(args.warmup):
             cyclefold_step(S, D, pri, sup, args.ro_challenge, resident=resident)
         S.profile_enable(True)
         S.profile_sampling(PROF_SAMPLE)
         S.profile_reset()
         dt = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge, resident=resident), args.steps, after=lambda: (pri.settle(), sup.settle()))
+        gc_release()
         if resident:
             pri.set_resident(D, False)
         S.profile_enable(False)
@@ -1119,10 +1147,12 @@ def run(args, D):
                 # beside the headline: the same step with every leaf at ITS OWN row (what the reference's `index & 2^k` was meant
                 # to be) -- more memory traffic in compute_F / compute_G, everything else identical
                 pri.compat = False
+                gc_hold()
                 for _ in range(min(args.warmup, 2)):
                     cyclefold_step(S, D, pri, sup, args.ro_challenge)
                 n_true = max(1, min(args.steps, 5))
                 dt_true = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), n_true, after=lambda: (pri.settle(), sup.settle()))
+                gc_release()
                 pri.compat = True
                 out["true_leaf_rows"] = {"fold_steps_per_s": round(n_true / dt_true, 4), "ms_per_step": round(dt_true / n_true * 1e3, 4),
                                          "steps": n_true, "note": "--leaf-rows true: leaf i evaluated at row i mod 2^k instead of row 0"}
@@ -1132,12 +1162,14 @@ def run(args, D):
                 # levels -> k_ovf_final) on EVERY set of every commit
                 st0 = pri.ck.msm_stats()
                 pri.set_witness("survey")
+                gc_hold()
                 for _ in range(3):                      # the first commit meets the hot buckets unexpectedly (one redo), then they are expected
                     cyclefold_step(S, D, pri, sup, args.ro_challenge)
                 st1 = pri.ck.msm_stats()
                 n_sv = max(1, min(args.steps, 5))
                 S.profile_reset()
                 dt_sv = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), n_sv, after=lambda: (pri.settle(), sup.settle()))
+                gc_release()
                 st2 = pri.ck.msm_stats()
                 acc_sv = S.profile_get("msm_accum0") or dict(total_ms=0.0, launches=0)
                 out["survey_mixture"] = {
@@ -1156,10 +1188,12 @@ def run(args, D):
                 # witness is not uploaded but committed where it lies -- one 12 * 2^k MSM (20-bit windows from 2^23 scalars on) instead of the
                 # streamed, PCIe-paced commit.  Same witnesses, same chain: every resident commitment is asserted equal to the streamed one.
                 pri.set_resident(D, True)
+                gc_hold()
                 for _ in range(2):
                     cyclefold_step(S, D, pri, sup, args.ro_challenge, resident=True)
                 n_rs = max(1, min(args.steps, 10))
                 dt_rs = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge, resident=True), n_rs, after=lambda: (pri.settle(), sup.settle()))
+                gc_release()
                 out["device_resident"] = {
                     "fold_steps_per_s": round(n_rs / dt_rs, 4), "ms_per_step": round(dt_rs / n_rs * 1e3, 4), "steps": n_rs,
                     "note": "the step with the new primary witness and the support trace already in HBM when it starts (no PCIe inside the timed "
@@ -1170,10 +1204,12 @@ def run(args, D):
                 # beside the headline: the same step fed from PAGEABLE host memory (a Rust Vec<F>; the headline alternates between two page-locked
                 # buffers): the runtime stages pageable sources through its own pinned buffers
                 pri.set_pageable(True)
+                gc_hold()
                 for _ in range(2):
                     cyclefold_step(S, D, pri, sup, args.ro_challenge)
                 n_pg = max(1, min(args.steps, 10))
                 dt_pg = timed(D, lambda: cyclefold_step(S, D, pri, sup, args.ro_challenge), n_pg, after=lambda: (pri.settle(), sup.settle()))
+                gc_release()
                 pri.set_pageable(False)
                 out["pageable_witness"] = {"fold_steps_per_s": round(n_pg / dt_pg, 4), "ms_per_step": round(dt_pg / n_pg * 1e3, 4), "steps": n_pg,
                                            "note": "the new 12 * 2^k witness comes from plain pageable numpy memory (what a Rust Vec<F> is) instead of the "
