@@ -29,3 +29,16 @@ for idle in (0.005, 0.02, 0.05, 0.2, 1.0, 3.0):
         ts.append((step(), step(), step()))
     print("after %5.3f s idle: first step %s ms, second %s, third %s" % (idle, " ".join("%.2f" % t[0] for t in ts), " ".join("%.2f" % t[1] for t in ts),
                                                                          " ".join("%.2f" % t[2] for t in ts)))
+# does a short burst of device work before the step bring the clocks back?  (what INTEGRATION.md 6c suggests a shim may do)
+y = torch.zeros(64 << 20, dtype=torch.int64, device="cuda")      # 512 MB: one add_ ~0.2 ms
+for burst in (2, 10, 40):
+    ts = []
+    for rep in range(3):
+        time.sleep(1.0)
+        t0 = time.perf_counter()
+        for _ in range(burst):
+            y.add_(1)
+        torch.cuda.synchronize()
+        b_ms = (time.perf_counter() - t0) * 1e3
+        ts.append((b_ms, step()))
+    print("after 1 s idle + a burst of %2d x add_ (%s ms): step %s ms" % (burst, " ".join("%.1f" % t[0] for t in ts), " ".join("%.2f" % t[1] for t in ts)))
